@@ -1,0 +1,86 @@
+/*
+ * oracle/pixel.c — SAD / SAD search / SSE / residual + the fused headline chain.
+ * TEST INFRASTRUCTURE ONLY (see svt_oracle.h).
+ */
+#include "svt_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* fast_loop_nx_m_sad_kernel, C_DEFAULT/EbComputeSAD_C.c:48-70 */
+uint32_t svt_oracle_sad(const uint8_t *src, uint32_t src_stride, const uint8_t *ref,
+                        uint32_t ref_stride, uint32_t height, uint32_t width) {
+    uint32_t acc = 0;
+    for (uint32_t y = 0; y < height; y++, src += src_stride, ref += ref_stride)
+        for (uint32_t x = 0; x < width; x++) acc += (uint32_t)abs((int)src[x] - (int)ref[x]);
+    return acc;
+}
+
+/* sad_loop_kernel, EbComputeSAD_C.c:72-120: raster search (y outer, x inner),
+ * strict '<' keeps the FIRST minimum; best starts at 0xffffff; candidate rows
+ * advance by src_stride_raw while rows inside a block advance by ref_stride. */
+void svt_oracle_sad_loop(const uint8_t *src, uint32_t src_stride, const uint8_t *ref,
+                         uint32_t ref_stride, uint32_t height, uint32_t width,
+                         uint64_t *best_sad, int16_t *xc, int16_t *yc, uint32_t src_stride_raw,
+                         int16_t saw, int16_t sah) {
+    *best_sad = 0xffffff;
+    for (int16_t ys = 0; ys < sah; ys++, ref += src_stride_raw)
+        for (int16_t xs = 0; xs < saw; xs++) {
+            const uint32_t s = svt_oracle_sad(src, src_stride, ref + xs, ref_stride, height, width);
+            if (s < *best_sad) { *best_sad = s; *xc = xs; *yc = ys; }
+        }
+}
+
+/* spatial_full_distortion_kernel, C_DEFAULT/EbPictureOperators_C.c:40-65 */
+uint64_t svt_oracle_sse(const uint8_t *a, uint32_t a_stride, const uint8_t *b, uint32_t b_stride,
+                        uint32_t width, uint32_t height) {
+    uint64_t acc = 0;
+    for (uint32_t y = 0; y < height; y++, a += a_stride, b += b_stride)
+        for (uint32_t x = 0; x < width; x++) { int64_t d = (int64_t)a[x] - b[x]; acc += (uint64_t)(d * d); }
+    return acc;
+}
+
+/* full_distortion_kernel32_bits, EbPictureOperators.c:283-315 */
+void svt_oracle_full_distortion32(const int32_t *coeff, uint32_t coeff_stride, const int32_t *recon,
+                                  uint32_t recon_stride, uint64_t out[2], uint32_t width, uint32_t height) {
+    uint64_t resid = 0, pred = 0;
+    for (uint32_t y = 0; y < height; y++, coeff += coeff_stride, recon += recon_stride)
+        for (uint32_t x = 0; x < width; x++) {
+            int64_t d = (int64_t)coeff[x] - (int64_t)recon[x], c = coeff[x];
+            resid += (uint64_t)(d * d);
+            pred += (uint64_t)(c * c);
+        }
+    out[0] = resid; out[1] = pred;
+}
+
+/* residual_kernel_c, EbPictureOperators.c:166-193 */
+void svt_oracle_residual(const uint8_t *src, uint32_t src_stride, const uint8_t *pred,
+                         uint32_t pred_stride, int16_t *res, uint32_t res_stride, uint32_t width,
+                         uint32_t height) {
+    for (uint32_t y = 0; y < height; y++, src += src_stride, pred += pred_stride, res += res_stride)
+        for (uint32_t x = 0; x < width; x++) res[x] = (int16_t)((int)src[x] - (int)pred[x]);
+}
+
+/* The headline unit of work: the encoder's Av1EncodeLoop sequence
+ * EbCodingLoop.c:617 (residual) -> :655 (av1_estimate_transform) -> :673
+ * (quantize, highbd semantics == AVX2 production path) plus the SAD of the
+ * same (src, pred) pair (EbProductCodingLoop.c:1259). */
+void svt_oracle_fwd_quant_sad(const uint8_t *src, uint32_t src_stride, const uint8_t *pred,
+                              uint32_t pred_stride, int tx_size, int tx_type, const int16_t *zbin,
+                              const int16_t *round, const int16_t *quant, const int16_t *quant_shift,
+                              const int16_t *dequant, int32_t *coeff, int32_t *qcoeff,
+                              int32_t *dqcoeff, uint16_t *eob, uint32_t *sad) {
+    const int w = svt_oracle_tx_wide(tx_size), h = svt_oracle_tx_high(tx_size);
+    int16_t *res = (int16_t *)malloc(sizeof(int16_t) * w * h);
+    int16_t *scan = (int16_t *)malloc(sizeof(int16_t) * 1024 * 2), *iscan = scan + 1024;
+    svt_oracle_residual(src, src_stride, pred, pred_stride, res, (uint32_t)w, (uint32_t)w, (uint32_t)h);
+    svt_oracle_fwd_txfm2d(res, coeff, (uint32_t)w, tx_type, tx_size, 8);
+    svt_oracle_fwd_txfm2d_pack64(coeff, tx_size);
+    const int n = svt_oracle_get_scan(tx_size, tx_type, scan, iscan);
+    /* av1_get_tx_scale (EbTransforms.h:317-329): 0 for <=256 px, 1 for <=1024, 2 above */
+    const int pels = w * h;
+    const int log_scale = pels > 1024 ? 2 : (pels > 256 ? 1 : 0);
+    svt_oracle_quantize_b(coeff, n, 0, zbin, round, quant, quant_shift, qcoeff, dqcoeff, dequant, eob,
+                          scan, iscan, log_scale, 0);
+    *sad = svt_oracle_sad(src, src_stride, pred, pred_stride, (uint32_t)h, (uint32_t)w);
+    free(res); free(scan);
+}

@@ -1,0 +1,111 @@
+/*
+ * oracle/ref_bench.c — OUR harness around the reference's own kernels; it is
+ * compiled into oracle/_ref/libsvtref.so together with the reference sources
+ * (oracle/Makefile).  TEST INFRASTRUCTURE ONLY.
+ *
+ *  - ref_get_scan(): hands out the reference's scan/iscan tables
+ *    (av1_scan_orders, EbTransforms.h:3349) so tests can pin the oracle's
+ *    rule-generated scans against them.
+ *  - ref_bench_fwd_quant_sad(): the CPU baseline of the headline metric —
+ *    per block, from a pthread pool, exactly the production call sequence
+ *    (BASELINE.md §4): ResidualKernel_avx2 -> av1_fwd_txfm2d_32x32_avx2 ->
+ *    aom_highbd_quantize_b_32x32_avx2 -> compute32x_m_sad_avx2_intrin
+ *    (or the scalar-C column when avx2 == 0).
+ */
+#define _GNU_SOURCE
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+#include <time.h>
+#include "EbDefinitions.h"
+#include "EbTransforms.h"
+
+const int16_t *ref_get_scan(int tx_size, int tx_type, int want_iscan) {
+    const SCAN_ORDER *so = &av1_scan_orders[tx_size][tx_type];
+    return want_iscan ? so->iscan : so->scan;
+}
+
+/* reference prototypes (called directly, never through the RTCD pointers) */
+void ResidualKernel_avx2(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride,
+                         int16_t *residual, uint32_t residual_stride, uint32_t area_width, uint32_t area_height);
+void residual_kernel_c(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride,
+                       int16_t *residual, uint32_t residual_stride, uint32_t area_width, uint32_t area_height);
+void av1_fwd_txfm2d_32x32_avx2(int16_t *input, int32_t *output, uint32_t stride, TxType tx_type, uint8_t bd);
+void Av1TransformTwoD_32x32_c(int16_t *input, int32_t *output, uint32_t stride, TxType tx_type, uint8_t bd);
+void aom_highbd_quantize_b_32x32_avx2(const tran_low_t *coeff_ptr, intptr_t n_coeffs, int skip_block,
+    const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr, const int16_t *quant_shift_ptr,
+    tran_low_t *qcoeff_ptr, tran_low_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
+    const int16_t *scan, const int16_t *iscan);
+void aom_highbd_quantize_b_32x32_c(const tran_low_t *coeff_ptr, intptr_t n_coeffs, int32_t skip_block,
+    const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr, const int16_t *quant_shift_ptr,
+    tran_low_t *qcoeff_ptr, tran_low_t *dqcoeff_ptr, const int16_t *dequant_ptr, uint16_t *eob_ptr,
+    const int16_t *scan, const int16_t *iscan);
+uint32_t compute32x_m_sad_avx2_intrin(const uint8_t *src, uint32_t src_stride, const uint8_t *ref,
+                                      uint32_t ref_stride, uint32_t height, uint32_t width);
+uint32_t fast_loop_nx_m_sad_kernel(const uint8_t *src, uint32_t src_stride, const uint8_t *ref,
+                                   uint32_t ref_stride, uint32_t height, uint32_t width);
+
+typedef struct {
+    const uint8_t *src, *pred;       /* n blocks x 1024 bytes, block-major */
+    int32_t *coeff, *qcoeff, *dqcoeff; /* n x 1024 (may be NULL: per-thread scratch) */
+    uint16_t *eob; uint32_t *sad;
+    const int16_t *zbin, *round, *quant, *quant_shift, *dequant; /* int16[8], 16-B aligned */
+    size_t begin, end; int avx2;
+} ChainJob;
+
+static void *chain_worker(void *arg) {
+    ChainJob *j = (ChainJob *)arg;
+    const int16_t *scan = av1_scan_orders[TX_32X32][DCT_DCT].scan;
+    const int16_t *iscan = av1_scan_orders[TX_32X32][DCT_DCT].iscan;
+    int16_t *res; int32_t *sc;
+    if (posix_memalign((void **)&res, 32, 1024 * sizeof(int16_t))) return NULL;
+    if (posix_memalign((void **)&sc, 32, 3 * 1024 * sizeof(int32_t))) return NULL;
+    for (size_t b = j->begin; b < j->end; b++) {
+        uint8_t *s = (uint8_t *)j->src + b * 1024, *p = (uint8_t *)j->pred + b * 1024;
+        int32_t *co = j->coeff ? j->coeff + b * 1024 : sc;
+        int32_t *qc = j->qcoeff ? j->qcoeff + b * 1024 : sc + 1024;
+        int32_t *dq = j->dqcoeff ? j->dqcoeff + b * 1024 : sc + 2048;
+        uint16_t eob;
+        if (j->avx2) {
+            ResidualKernel_avx2(s, 32, p, 32, res, 32, 32, 32);
+            av1_fwd_txfm2d_32x32_avx2(res, co, 32, DCT_DCT, 8);
+            aom_highbd_quantize_b_32x32_avx2(co, 1024, 0, j->zbin, j->round, j->quant, j->quant_shift,
+                                             qc, dq, j->dequant, &eob, scan, iscan);
+            j->sad[b] = compute32x_m_sad_avx2_intrin(s, 32, p, 32, 32, 32);
+        } else {
+            residual_kernel_c(s, 32, p, 32, res, 32, 32, 32);
+            Av1TransformTwoD_32x32_c(res, co, 32, DCT_DCT, 8);
+            aom_highbd_quantize_b_32x32_c(co, 1024, 0, j->zbin, j->round, j->quant, j->quant_shift,
+                                          qc, dq, j->dequant, &eob, scan, iscan);
+            j->sad[b] = fast_loop_nx_m_sad_kernel(s, 32, p, 32, 32, 32);
+        }
+        j->eob[b] = eob;
+    }
+    free(res); free(sc);
+    return NULL;
+}
+
+/* returns elapsed seconds for n blocks on `threads` pthreads */
+double ref_bench_fwd_quant_sad(const uint8_t *src, const uint8_t *pred, size_t n, int threads, int avx2,
+                               const int16_t *zbin, const int16_t *round, const int16_t *quant,
+                               const int16_t *quant_shift, const int16_t *dequant,
+                               int32_t *coeff, int32_t *qcoeff, int32_t *dqcoeff,
+                               uint16_t *eob, uint32_t *sad) {
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    ChainJob *jobs = (ChainJob *)malloc(sizeof(ChainJob) * threads);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < threads; t++) {
+        ChainJob j = {src, pred, coeff, qcoeff, dqcoeff, eob, sad, zbin, round, quant, quant_shift, dequant,
+                      n * t / threads, n * (t + 1) / threads, avx2};
+        jobs[t] = j;
+        pthread_create(&th[t], NULL, chain_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(th); free(jobs);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
