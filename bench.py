@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — headline metric of BASELINE.json:
+
+    blocks/sec for the fused chain  residual -> FwdTxfm2d 32x32 DCT_DCT ->
+    quantize_b_32x32 -> SAD 32x32, 8-bit, batched blocks resident in HBM.
+
+A "step" is one pass of the hot path (one fused-kernel launch through the C ABI,
+svt_hip_fwd_quant_sad_batch) over one batch of 2^20 synthetic blocks per GPU
+(BASELINE.json configs[1]: "FwdTxfm2d + quantize 32x32 8-bit, 1M-block batch").
+One process per GPU; blocks are sharded across ranks with no data-path
+collective (weak scaling: per-GPU batch fixed); the only exchange is the
+barrier + max-reduce of the elapsed time.
+
+Prints ONE JSON line on rank 0, including
+  roofline     algorithmic bytes (14 342 B/block) / average kernel
+               duration measured with HIP events on the launch stream, vs the
+               8 TB/s HBM3E peak (MI355X_MICROARCH.md)
+  cpu_baseline the reference's own AVX2 kernels (oracle/_ref, compiled from
+               /root/reference) on the GPU box's host cores, bounded sample
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BYTES_PER_BLOCK = 2 * 1024 + 3 * 4096 + 2 + 4      # 14 342
+HBM_PEAK_GBS = 8000.0                               # MI355X HBM3E spec peak
+QINDEX = 100
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(src_np, pred_np, qrow, gpu_out, budget_s=12.0):
+    """Time the reference's production AVX2 path (kind 'reference') on all host
+    cores over a bounded sample of the same workload; verify GPU == CPU on it."""
+    import svtlibs
+    P = svtlibs.ptr
+    R = svtlibs.ref()
+    cores = host_cores()
+    tabs = [np.ascontiguousarray(qrow[k]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
+    navail = src_np.shape[0]
+
+    def run_ref(n, threads, keep):
+        co = np.zeros((n, 1024), np.int32) if keep else None
+        q = np.zeros((n, 1024), np.int32) if keep else None
+        dq = np.zeros((n, 1024), np.int32) if keep else None
+        eob = np.zeros(n, np.uint16); sad = np.zeros(n, np.uint32)
+        t = R.ref_bench_fwd_quant_sad(P(src_np), P(pred_np), ctypes.c_size_t(n), threads, 1, P(tabs[0]), P(tabs[1]),
+                                      P(tabs[2]), P(tabs[3]), P(tabs[4]), P(co) if keep else None,
+                                      P(q) if keep else None, P(dq) if keep else None, P(eob), P(sad))
+        return t, (co, q, dq, eob, sad)
+
+    if R is not None:
+        kind = "reference"
+        ncal = min(4096, navail)
+        t1, _ = run_ref(ncal, 1, False)                       # calibrate, 1 thread
+        rate1 = ncal / t1
+        n = int(min(navail, max(ncal, rate1 * cores * budget_s * 0.6)))
+        run_ref(min(n, 8192), cores, False)                   # warm the pool / caches
+        t, _ = run_ref(n, cores, False)
+        value = n / t
+        # parity of the GPU run against the reference on a verified sub-sample
+        nv = min(n, 16384)
+        _, (co, q, dq, eob, sad) = run_ref(nv, cores, True)
+        sample = f"{n} of the step's blocks, {cores} pthreads, reference AVX2 kernels (oracle/_ref), qindex {QINDEX}"
+        one = {"value_1thread": rate1}
+    else:                                                    # no reference build here: scalar port
+        kind = "port"
+        O = svtlibs.oracle()
+        cores = 1
+        n = nv = min(navail, 2048)
+        co = np.zeros((n, 1024), np.int32); q = np.zeros((n, 1024), np.int32); dq = np.zeros((n, 1024), np.int32)
+        eob = np.zeros(n, np.uint16); sad = np.zeros(n, np.uint32)
+        t0 = time.perf_counter()
+        for i in range(n):
+            O.svt_oracle_fwd_quant_sad(P(src_np[i]), 32, P(pred_np[i]), 32, 3, 0, P(tabs[0]), P(tabs[1]), P(tabs[2]),
+                                       P(tabs[3]), P(tabs[4]), P(co[i]), P(q[i]), P(dq[i]), P(eob[i:i + 1]),
+                                       P(sad[i:i + 1]))
+        value = n / (time.perf_counter() - t0)
+        sample = f"{n} blocks, 1 thread, scalar C oracle (oracle/_ref not present)"
+        one = {}
+    g_co, g_q, g_dq, g_eob, g_sad = gpu_out
+    ok = (np.array_equal(g_co[:nv].cpu().numpy(), co[:nv]) and np.array_equal(g_q[:nv].cpu().numpy(), q[:nv])
+          and np.array_equal(g_dq[:nv].cpu().numpy(), dq[:nv])
+          and np.array_equal(g_eob[:nv].cpu().numpy().view(np.uint16), eob[:nv])
+          and np.array_equal(g_sad[:nv].cpu().numpy().view(np.uint32), sad[:nv]))
+    out = {"value": value, "unit": "blocks/s", "cores": cores, "kind": kind, "sample": sample,
+           "gpu_equals_cpu_on_sample": bool(ok), "verified_blocks": int(nv)}
+    out.update(one)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=1 << 20, help="32x32 blocks per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as ge
+    import svtlibs
+    pkg = ge.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dsp = pkg.SvtHipDsp(local_rank)               # raises if the HIP library/device is unusable
+
+    n = args.blocks
+    g = torch.Generator(device=dev)
+    g.manual_seed(13596 + rank)                   # seed constant of test/random.h:103
+    src = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device=dev, generator=g)
+    pred = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device=dev, generator=g)
+    qt = svtlibs.quant_tables(8)
+    qrow = {k: v[QINDEX].copy() for k, v in qt.items()}
+    _, iscan_np = svtlibs.scan_tables(pkg.TX_32X32, pkg.DCT_DCT)
+    iscan = torch.from_numpy(iscan_np).to(dev)
+    outs = (torch.empty((n, 1024), dtype=torch.int32, device=dev), torch.empty((n, 1024), dtype=torch.int32, device=dev),
+            torch.empty((n, 1024), dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int16, device=dev),
+            torch.zeros(n, dtype=torch.int32, device=dev))
+
+    def step():
+        dsp.fwd_quant_sad(src, pred, pkg.TX_32X32, pkg.DCT_DCT, qrow, iscan, outs=outs)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    # HIP events on the stream the kernel is launched on (torch's current stream)
+    stream = torch.cuda.current_stream(dev)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)    # one kernel per step, back to back
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    result = None
+    if rank == 0:
+        total_blocks = n * world * args.steps
+        achieved = BYTES_PER_BLOCK * n / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("blocks") == n:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "blocks/sec (FwdTxfm2d+quant+SAD, 32x32 8-bit)",
+            "value": total_blocks / elapsed,
+            "unit": "blocks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]+SAD: fused residual->FwdTxfm2d 32x32 DCT_DCT->quantize_b_32x32->SAD, "
+                                   "8-bit, qindex 100, uniform u8 src/pred",
+                       "blocks_per_gpu": n, "global_blocks": n * world, "tx_size": "TX_32X32",
+                       "tx_type": "DCT_DCT", "parallelism": f"block-range shard x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_block": BYTES_PER_BLOCK, "kernel_ms": kernel_ms,
+                         "kernel": "fwd_quant_sad_32x32_kernel"},
+            "device": dsp.device_name(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ns = min(n, 1 << 18)
+            result["cpu_baseline"] = cpu_baseline(src[:ns].cpu().numpy(), pred[:ns].cpu().numpy(), qrow,
+                                                  tuple(o[:ns] for o in outs))
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,228 @@
+"""cidana-svt-av1_amd — MI355X-native SVT-AV1 block-DSP hot path.
+
+The product is ``libsvt_hip_dsp.so`` (C ABI: include/svt_hip_dsp.h, hand-written
+gfx950 HIP kernels under csrc/).  This Python module is only the host-side
+mirror used by the tests and the benchmark: it binds the C ABI with ctypes and
+passes raw device pointers taken from torch tensors (torch is plumbing for
+device memory, streams and torch.distributed — nothing is computed in torch).
+
+There is deliberately NO fallback: if the shared library is missing or the HIP
+device cannot be initialised, construction raises.
+
+The directory name contains '-', so import it through
+``__graft_entry__.load_package()`` (importlib) rather than ``import``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_int, c_int16, c_int32, c_size_t, c_uint32, c_void_p
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libsvt_hip_dsp.so")
+
+TX_SIZE_NAMES = ["TX_4X4", "TX_8X8", "TX_16X16", "TX_32X32", "TX_64X64", "TX_4X8", "TX_8X4", "TX_8X16",
+                 "TX_16X8", "TX_16X32", "TX_32X16", "TX_32X64", "TX_64X32", "TX_4X16", "TX_16X4", "TX_8X32",
+                 "TX_32X8", "TX_16X64", "TX_64X16"]
+TX_W = [4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64]
+TX_H = [4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16]
+TX_TYPE_NAMES = ["DCT_DCT", "ADST_DCT", "DCT_ADST", "ADST_ADST", "FLIPADST_DCT", "DCT_FLIPADST",
+                 "FLIPADST_FLIPADST", "ADST_FLIPADST", "FLIPADST_ADST", "IDTX", "V_DCT", "H_DCT", "V_ADST",
+                 "H_ADST", "V_FLIPADST", "H_FLIPADST"]
+TX_32X32 = 3
+DCT_DCT = 0
+
+SVT_HIP_OK = 0
+
+
+class SvtHipError(RuntimeError):
+    pass
+
+
+def tx_log_scale(tx_size: int) -> int:
+    """av1_get_tx_scale (EbTransforms.h:317-329)."""
+    pels = TX_W[tx_size] * TX_H[tx_size]
+    return 2 if pels > 1024 else (1 if pels > 256 else 0)
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise SvtHipError(f"{path} not built - run `python __graft_entry__.py build` (no CPU fallback exists)")
+    L = ctypes.CDLL(path)
+    L.svt_hip_last_error.restype = ctypes.c_char_p
+    L.svt_hip_device_name.restype = ctypes.c_char_p
+    L.svt_hip_malloc.restype = c_void_p
+    L.svt_hip_malloc.argtypes = [c_size_t]
+    L.svt_hip_free.argtypes = [c_void_p]
+    L.svt_hip_fwd_txfm2d_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]
+    L.svt_hip_pack64_batch.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+    L.svt_hip_inv_txfm2d_add_batch.argtypes = [c_void_p, c_void_p, c_int, c_int32, c_size_t, c_void_p, c_size_t,
+                                               c_int, c_int, c_int, c_void_p]
+    L.svt_hip_quantize_b_batch.argtypes = [c_void_p, c_size_t, c_int] + [c_void_p] * 4 + [c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_int, c_size_t, c_void_p]
+    L.svt_hip_fwd_quant_sad_batch.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_int] + [c_void_p] * 5 + \
+                                             [c_void_p] * 6 + [c_void_p]
+    for name in ("svt_hip_sad_batch", "svt_hip_sse_batch"):
+        getattr(L, name).argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t, c_uint32, c_uint32,
+                                     c_void_p, c_size_t, c_void_p]
+    L.svt_hip_residual_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t, c_void_p, c_uint32,
+                                         c_size_t, c_uint32, c_uint32, c_size_t, c_void_p]
+    L.svt_hip_sad_search_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_uint32, c_size_t,
+                                           c_uint32, c_uint32, c_int16, c_int16, c_void_p, c_void_p, c_void_p, c_size_t,
+                                           c_void_p]
+    if hasattr(L, "svt_hip_intra_pred_batch"):
+        L.svt_hip_intra_pred_batch.argtypes = [c_void_p, c_int32, c_size_t, c_void_p, c_void_p, c_int32, c_int, c_int,
+                                               c_int, c_int, c_int, c_size_t, c_void_p]
+    return L
+
+
+def _np16(a):
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.int16))
+    assert a.size >= 2
+    return a
+
+
+class SvtHipDsp:
+    """Batched device API on torch CUDA(HIP) tensors.  Names follow the reference's
+    dispatch slots (aom_dsp_rtcd.h): fwd_txfm2d <-> av1_fwd_txfm2d_WxH, ..."""
+
+    def __init__(self, device: int = 0):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        rc = self.lib.svt_hip_init(int(device))
+        if rc != SVT_HIP_OK:
+            raise SvtHipError(f"svt_hip_init({device}) = {rc}: {self.lib.svt_hip_last_error().decode()}")
+        self.device = torch.device("cuda", device)
+
+    # -- helpers ----------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != SVT_HIP_OK:
+            raise SvtHipError(f"{what} = {rc}: {self.lib.svt_hip_last_error().decode()}")
+
+    def _stream(self):
+        return c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return c_void_p(t.data_ptr())
+
+    def device_name(self):
+        return self.lib.svt_hip_device_name().decode()
+
+    # -- K1 ---------------------------------------------------------------------
+    def fwd_txfm2d(self, residual, tx_size, tx_type, bd=8, out=None):
+        """residual: int16 [n, H, W] contiguous (dense blocks). -> int32 [n, H*W]"""
+        t = self.torch
+        w, h = TX_W[tx_size], TX_H[tx_size]
+        n = residual.shape[0]
+        assert residual.dtype == t.int16 and residual.is_contiguous() and tuple(residual.shape[1:]) == (h, w)
+        if out is None:
+            out = t.empty((n, h * w), dtype=t.int32, device=residual.device)
+        self._check(self.lib.svt_hip_fwd_txfm2d_batch(self._p(residual), w, w * h, self._p(out), n, tx_size, tx_type,
+                                                       bd, self._stream()), "svt_hip_fwd_txfm2d_batch")
+        return out
+
+    def pack64(self, coeff, tx_size, want_energy=True):
+        t = self.torch
+        n = coeff.shape[0]
+        energy = t.zeros(n, dtype=t.int64, device=coeff.device) if want_energy else None
+        self._check(self.lib.svt_hip_pack64_batch(self._p(coeff), self._p(energy) if want_energy else None, n, tx_size,
+                                                   self._stream()), "svt_hip_pack64_batch")
+        return energy
+
+    # -- K2 ---------------------------------------------------------------------
+    def inv_txfm2d_add(self, coeff, dst, tx_size, tx_type, bd=8, dst_stride=None, dst_block_pitch=None, offsets=None):
+        """coeff int32 [n, min(W,32)*min(H,32)]; dst uint8/int16(as uint16) tensor updated in place."""
+        t = self.torch
+        w, h = TX_W[tx_size], TX_H[tx_size]
+        n = coeff.shape[0]
+        is16 = 0 if dst.dtype == t.uint8 else 1
+        if dst_stride is None:
+            dst_stride, dst_block_pitch = w, w * h
+        self._check(self.lib.svt_hip_inv_txfm2d_add_batch(self._p(coeff), self._p(dst), is16, dst_stride,
+                                                           dst_block_pitch or 0,
+                                                           self._p(offsets) if offsets is not None else None, n,
+                                                           tx_size, tx_type, bd, self._stream()),
+                    "svt_hip_inv_txfm2d_add_batch")
+        return dst
+
+    # -- K3 ---------------------------------------------------------------------
+    def quantize_b(self, coeff, qrow, iscan, log_scale, skip_block=0):
+        """coeff int32 [n, ncoef]; qrow: dict of int16[8] rows (zbin, round, quant, quant_shift, dequant);
+        iscan: int16 device tensor [ncoef]. -> (qcoeff, dqcoeff, eob[uint16 as int16 view])"""
+        t = self.torch
+        n, nc = coeff.shape
+        q = t.empty_like(coeff)
+        dq = t.empty_like(coeff)
+        eob = t.zeros(n, dtype=t.int16, device=coeff.device)
+        tabs = [_np16(qrow[k]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
+        self._check(self.lib.svt_hip_quantize_b_batch(self._p(coeff), nc, skip_block, tabs[0].ctypes.data,
+                                                       tabs[1].ctypes.data, tabs[2].ctypes.data, tabs[3].ctypes.data,
+                                                       self._p(q), self._p(dq), tabs[4].ctypes.data, self._p(eob),
+                                                       self._p(iscan), log_scale, n, self._stream()),
+                    "svt_hip_quantize_b_batch")
+        return q, dq, eob
+
+    # -- headline chain -----------------------------------------------------------
+    def fwd_quant_sad(self, src, pred, tx_size, tx_type, qrow, iscan, outs=None, want_sad=True):
+        """src, pred: uint8 [n, H, W].  -> coeff, qcoeff, dqcoeff (int32 [n, ncoef]), eob, sad"""
+        t = self.torch
+        n = src.shape[0]
+        nc = min(TX_W[tx_size], 32) * min(TX_H[tx_size], 32)
+        if outs is None:
+            outs = (t.empty((n, nc), dtype=t.int32, device=src.device), t.empty((n, nc), dtype=t.int32, device=src.device),
+                    t.empty((n, nc), dtype=t.int32, device=src.device), t.zeros(n, dtype=t.int16, device=src.device),
+                    t.zeros(n, dtype=t.int32, device=src.device))
+        co, q, dq, eob, sad = outs
+        tabs = [_np16(qrow[k]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
+        self._check(self.lib.svt_hip_fwd_quant_sad_batch(self._p(src), self._p(pred), n, tx_size, tx_type,
+                                                          tabs[0].ctypes.data, tabs[1].ctypes.data, tabs[2].ctypes.data,
+                                                          tabs[3].ctypes.data, tabs[4].ctypes.data, self._p(iscan),
+                                                          self._p(co), self._p(q), self._p(dq), self._p(eob),
+                                                          self._p(sad) if want_sad else None, self._stream()),
+                    "svt_hip_fwd_quant_sad_batch")
+        return outs
+
+    # -- K4 / K7 / K8 ---------------------------------------------------------------
+    def sad(self, a, b):
+        """a, b: uint8 [n, H, W] dense -> int32 [n] (uint32 values)"""
+        t = self.torch
+        n, h, w = a.shape
+        out = t.zeros(n, dtype=t.int32, device=a.device)
+        self._check(self.lib.svt_hip_sad_batch(self._p(a), w, w * h, self._p(b), w, w * h, w, h, self._p(out), n,
+                                                self._stream()), "svt_hip_sad_batch")
+        return out
+
+    def sse(self, a, b):
+        t = self.torch
+        n, h, w = a.shape
+        out = t.zeros(n, dtype=t.int64, device=a.device)
+        self._check(self.lib.svt_hip_sse_batch(self._p(a), w, w * h, self._p(b), w, w * h, w, h, self._p(out), n,
+                                                self._stream()), "svt_hip_sse_batch")
+        return out
+
+    def residual(self, src, pred):
+        t = self.torch
+        n, h, w = src.shape
+        out = t.empty((n, h, w), dtype=t.int16, device=src.device)
+        self._check(self.lib.svt_hip_residual_batch(self._p(src), w, w * h, self._p(pred), w, w * h, self._p(out), w,
+                                                     w * h, w, h, n, self._stream()), "svt_hip_residual_batch")
+        return out
+
+    # -- K5 -----------------------------------------------------------------------
+    def sad_search(self, src, ref, search_w, search_h, ref_stride=None, ref_stride_raw=None):
+        """src uint8 [n, H, W]; ref uint8 [n, RH, RW] private windows. -> best_sad int64, x int16, y int16"""
+        t = self.torch
+        n, h, w = src.shape
+        _, rh, rw = ref.shape
+        rs = rw if ref_stride is None else ref_stride
+        rraw = rw if ref_stride_raw is None else ref_stride_raw
+        best = t.zeros(n, dtype=t.int64, device=src.device)
+        x = t.zeros(n, dtype=t.int16, device=src.device)
+        y = t.zeros(n, dtype=t.int16, device=src.device)
+        self._check(self.lib.svt_hip_sad_search_batch(self._p(src), w, w * h, self._p(ref), rs, rraw, rw * rh, w, h,
+                                                       search_w, search_h, self._p(best), self._p(x), self._p(y), n,
+                                                       self._stream()), "svt_hip_sad_search_batch")
+        return best, x, y

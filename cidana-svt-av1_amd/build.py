@@ -1,0 +1,61 @@
+"""Build everything native, in-tree:
+
+  cidana-svt-av1_amd/libsvt_hip_dsp.so   the product: HIP kernels + C ABI (gfx950)
+  oracle/libsvt_oracle.so                CPU checker (test infrastructure)
+  oracle/_ref/libsvtref.so               reference sources compiled as-is, only
+                                         when /root/reference is present
+
+hipcc cross-compiles gfx950 without a GPU.  Nothing is installed outside the
+repo; the .so files are git-ignored but travel with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIB = os.path.join(PKG, "libsvt_hip_dsp.so")
+SOURCES = ["csrc/svt_hip_dsp.hip"]
+DEPS = ["csrc/svt_hip_dsp.hip", "csrc/dev_common.h", "csrc/kernel_fused32.h", "csrc/kernel_txfm.h",
+        "csrc/kernel_pixel.h", "csrc/kernel_intra.h", "csrc/gen/txfm1d_gen.h", "../include/svt_hip_dsp.h"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-fwrapv",
+               "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_product(force=False, verbose=True):
+    gen = os.path.join(PKG, "csrc", "gen", "txfm1d_gen.h")
+    tools = [os.path.join(PKG, "tools", f) for f in ("txfm_net.py", "gen_device.py")]
+    if _stale(gen, tools):
+        subprocess.check_call([sys.executable, os.path.join(PKG, "tools", "gen_device.py")])
+    deps = [os.path.join(PKG, d) for d in DEPS]
+    if force or _stale(LIB, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB] + [os.path.join(PKG, s) for s in SOURCES]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=PKG)
+    return LIB
+
+
+def build_oracle(verbose=True):
+    odir = os.path.join(ROOT, "oracle")
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", odir, "oracle"], stdout=out)
+    if os.path.exists("/root/reference/Source/Lib/Common/Codec/EbTransforms.c"):
+        subprocess.check_call(["make", "-C", odir, "-j8", "ref"], stdout=out)
+
+
+def build_all(force=False, verbose=True):
+    build_product(force=force, verbose=verbose)
+    build_oracle(verbose=verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,93 @@
+// dev_common.h — device-side helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace svtdev {
+
+// Quantizer scalars for one launch: index 0 = DC (coefficient 0), 1 = AC.
+// Derived on the host from the reference's five int16[8] tables
+// (EbFullLoop.c:239-296): zbin/round already ROUND_POWER_OF_TWO'ed by
+// log_scale; quant_m = quant + 65536 (so ((t*quant)>>16)+t == (t*quant_m)>>16).
+struct QParams {
+    int32_t zbin[2];
+    int32_t round[2];
+    uint32_t quant_m[2];
+    int32_t quant_shift[2];
+    int32_t dequant[2];
+    int32_t log_scale;
+};
+
+// Orders this wave's LDS traffic: LDS instructions of one wave execute in
+// issue order, so a compiler-level fence is all that is needed between a
+// phase that writes a tile and a phase in which OTHER lanes of the same wave
+// read it.  (Tiles are never shared between waves.)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// (a * b) >> sh for a, b < 2^24, 0 < sh < 32, result < 2^32: two full-rate
+// 24-bit multiplies + v_alignbit instead of a 64-bit multiply.
+__device__ __forceinline__ uint32_t mul24_shr(uint32_t a, uint32_t b, int sh) {
+    const uint64_t p = (uint64_t)(a & 0xffffffu) * (uint64_t)(b & 0xffffffu);
+    return (uint32_t)(p >> sh);
+}
+
+// One coefficient through highbd_quantize_b_helper_c (EbFullLoop.c:239-296),
+// flat quant matrix.  FAST24 = operands proven < 2^24 (8/10-bit transform
+// output); otherwise exact 64-bit arithmetic.
+template <bool FAST24>
+__device__ __forceinline__ void quant_one(int c, int ac, const QParams& qp, int& q, int& dq) {
+    const int s = c >> 31;
+    const int a = (c ^ s) - s;
+    const bool keep = a >= qp.zbin[ac];
+    int aq, adq;
+    if (FAST24) {
+        const uint32_t tw = (uint32_t)(a + qp.round[ac]) << 5;
+        const uint32_t t2 = mul24_shr(tw, qp.quant_m[ac], 16);
+        aq = (int)mul24_shr(t2, (uint32_t)qp.quant_shift[ac], 21 - qp.log_scale);
+        adq = (int)(((uint32_t)aq & 0xffffffu) * ((uint32_t)qp.dequant[ac] & 0xffffffu)) >> qp.log_scale;
+    } else {
+        const long long tw = ((long long)a + qp.round[ac]) * 32;
+        const long long t2 = ((tw * (long long)((int)qp.quant_m[ac] - 65536)) >> 16) + tw;
+        aq = (int)((t2 * (long long)qp.quant_shift[ac]) >> (21 - qp.log_scale));
+        adq = (int)((uint32_t)aq * (uint32_t)qp.dequant[ac]) >> qp.log_scale;
+    }
+    q = keep ? (aq ^ s) - s : 0;
+    dq = keep ? (adq ^ s) - s : 0;
+}
+
+// max / sum over the 32 lanes of each half-wave (lanes 0-31 and 32-63 reduce
+// independently); result valid in every lane of the half.
+__device__ __forceinline__ int half_wave_max(int v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned half_wave_sum(unsigned v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+// reductions over an aligned group of G lanes (G power of two <= 64)
+template <int G>
+__device__ __forceinline__ int group_max(int v) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ unsigned group_sum(unsigned v) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ unsigned long long group_sum64(unsigned long long v) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+}  // namespace svtdev

@@ -1,0 +1,168 @@
+// kernel_fused32.h — the headline kernel: 32x32 8-bit
+//   residual(src,pred) -> FwdTxfm2d (DCT_DCT) -> quantize_b_32x32 -> SAD(src,pred)
+// fused so that the residual and the un-quantized intermediate never touch HBM.
+//
+// Replaces, per block, the reference call sequence
+//   ResidualKernel                (EbCodingLoop.c:617  -> EbPictureOperators.c:166)
+//   av1_fwd_txfm2d_32x32          (EbFullLoop.c:763    -> EbTransforms.c:4466 / AVX2 :4080)
+//   aom_highbd_quantize_b_32x32   (EbFullLoop.c:780    -> EbFullLoop.c:239 / AVX2 :422)
+//   NxMSadKernel 32x32            (EbProductCodingLoop.c:1259 -> EbComputeSAD_C.c:48)
+//
+// Mapping (CDNA4, wave64): one wave owns TWO blocks (lanes 0-31 / 32-63).  In
+// the column pass lane c holds column c in 32 VGPRs and runs the straight-line
+// generated DCT32; a swizzled LDS tile transposes; in the row pass lane r holds
+// row r.  A second swizzled tile re-orders the rows into the linear block
+// layout so that quantisation happens on, and all three 4 KB outputs are stored
+// from, fully coalesced 16-B-per-lane positions.  Each wave uses a private LDS
+// region: no workgroup barrier anywhere.
+//
+// HBM traffic per block = 2 x 1024 B in + 3 x 4096 + 2 + 4 B out = 14 342 B
+//  — the algorithmic minimum; everything else lives in VGPR/LDS.
+#pragma once
+#include "dev_common.h"
+#include "gen/txfm1d_gen.h"
+
+namespace svtdev {
+
+constexpr int F32_WAVES = 4;                 // waves per workgroup
+constexpr int F32_TILE_WORDS = 1024;         // one 32x32 int32 tile per block
+constexpr int F32_COS_BIT = 12;              // fwd_cos_bit_col/row[3][3] (EbTransforms.h:141-156)
+
+// LDS byte offset of 16-B slot `s` (0..7) of row `r` in a 32x32 int32 tile whose
+// slots are XOR-swizzled by f: conflict-free for the access pairs used below.
+__device__ __forceinline__ int tile_slot(int r, int s, int f) { return r * 128 + ((s ^ f) << 4); }
+
+template <bool WITH_SAD>
+__global__ __launch_bounds__(F32_WAVES * 64) void fwd_quant_sad_32x32_kernel(
+    const uint8_t* __restrict__ src, const uint8_t* __restrict__ pred, int32_t* __restrict__ coeff,
+    int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff, uint16_t* __restrict__ eob,
+    uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp, uint32_t nblocks) {
+    __shared__ __attribute__((aligned(16))) int32_t lds[F32_WAVES * 2 * F32_TILE_WORDS];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5;      // which of the wave's two blocks
+    const int li = lane & 31;        // column index (pass 1) / row index (pass 2)
+    char* tile = reinterpret_cast<char*>(lds + (wave * 2 + half) * F32_TILE_WORDS);
+
+    // iscan+1 for the 32 linear positions this lane quantises: position
+    // (k*32 + li)*4 + j, k = 0..7, j = 0..3  (same for every block).
+    uint2 isc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        isc[k] = *reinterpret_cast<const uint2*>(iscan + (k * 32 + li) * 4);
+        isc[k].x += 0x00010001u;   // iscan <= 1023: no carry between the packed halves
+        isc[k].y += 0x00010001u;
+    }
+
+    const uint32_t npairs = (nblocks + 1) >> 1;
+    const uint32_t wave_stride = gridDim.x * F32_WAVES;
+    for (uint32_t pair = blockIdx.x * F32_WAVES + wave; pair < npairs; pair += wave_stride) {
+        const uint32_t blk = pair * 2 + half;
+        const bool valid = blk < nblocks;
+        const size_t pix_off = (size_t)blk * 1024;
+
+        // ---- load 2 x 1 KB, coalesced 16 B per lane --------------------------------
+        uint4 s0 = {0, 0, 0, 0}, s1 = s0, p0 = s0, p1 = s0;
+        if (valid) {
+            const uint4* s4 = reinterpret_cast<const uint4*>(src + pix_off);
+            const uint4* p4 = reinterpret_cast<const uint4*>(pred + pix_off);
+            s0 = s4[li]; s1 = s4[li + 32]; p0 = p4[li]; p1 = p4[li + 32];
+        }
+        // ---- SAD on the raw bytes (v_sad_u8: 4 pixels per instruction) -------------
+        unsigned sad_acc = 0;
+        if (WITH_SAD) {
+            sad_acc = __builtin_amdgcn_sad_u8(s0.x, p0.x, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s0.y, p0.y, sad_acc);
+            sad_acc = __builtin_amdgcn_sad_u8(s0.z, p0.z, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s0.w, p0.w, sad_acc);
+            sad_acc = __builtin_amdgcn_sad_u8(s1.x, p1.x, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s1.y, p1.y, sad_acc);
+            sad_acc = __builtin_amdgcn_sad_u8(s1.z, p1.z, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s1.w, p1.w, sad_acc);
+        }
+        // ---- residual as packed int16 pairs -> LDS ---------------------------------
+        // lane li, chunk k holds row k*16 + li/2, columns (li&1)*16 .. +15.  Part p
+        // (8 residuals = 16 B) goes to byte (2k+p)*544 + li*16: linear (conflict-free)
+        // stores; the 544-B part stride keeps the column reads conflict-free too.
+        {
+            const uint32_t sw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+            for (int kp = 0; kp < 4; kp++) {   // kp = 2k + p
+                uint32_t r[4];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {
+                    const uint32_t a = sw[kp * 2 + h2], b = pw[kp * 2 + h2];
+                    const int d0 = (int)(a & 0xff) - (int)(b & 0xff);
+                    const int d1 = (int)((a >> 8) & 0xff) - (int)((b >> 8) & 0xff);
+                    const int d2 = (int)((a >> 16) & 0xff) - (int)((b >> 16) & 0xff);
+                    const int d3 = (int)(a >> 24) - (int)(b >> 24);
+                    r[h2 * 2 + 0] = ((uint32_t)d0 & 0xffffu) | ((uint32_t)d1 << 16);
+                    r[h2 * 2 + 1] = ((uint32_t)d2 & 0xffffu) | ((uint32_t)d3 << 16);
+                }
+                *reinterpret_cast<uint4*>(tile + kp * 544 + li * 16) = make_uint4(r[0], r[1], r[2], r[3]);
+            }
+        }
+        wave_lds_fence();
+        // ---- column pass: lane li owns column li ------------------------------------
+        int x[32];
+        {
+            // element (r, li): writer lane (r&15)*2 + (li>>4), part (li>>3)&1, item li&7
+            const char* colbase = tile + ((li >> 3) & 1) * 544 + (li >> 4) * 16 + (li & 7) * 2;
+#pragma unroll
+            for (int r = 0; r < 32; r++) {
+                const short v = *reinterpret_cast<const short*>(colbase + (r >> 4) * 1088 + (r & 15) * 32);
+                x[r] = (int)v * 4;                                   // shift[0] = 2 (fwd_shift_32x32)
+            }
+        }
+        svtgen::svt_fdct32<F32_COS_BIT>(x);
+#pragma unroll
+        for (int r = 0; r < 32; r++) x[r] = (x[r] + 8) >> 4;      // shift[1] = -4
+        wave_lds_fence();
+        // ---- transpose 1: write column, read row (swizzle f = (row>>1)&7) ------------
+#pragma unroll
+        for (int r = 0; r < 32; r++)
+            *reinterpret_cast<int*>(tile + tile_slot(r, li >> 2, (r >> 1) & 7) + (li & 3) * 4) = x[r];
+        wave_lds_fence();
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const int4 v = *reinterpret_cast<const int4*>(tile + tile_slot(li, s, (li >> 1) & 7));
+            x[s * 4 + 0] = v.x; x[s * 4 + 1] = v.y; x[s * 4 + 2] = v.z; x[s * 4 + 3] = v.w;
+        }
+        // ---- row pass: lane li owns row li (shift[2] = 0) ---------------------------
+        svtgen::svt_fdct32<F32_COS_BIT>(x);
+        wave_lds_fence();
+        // ---- transpose 2: rows -> linear block order (swizzle f = row&7) --------------
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+            *reinterpret_cast<int4*>(tile + tile_slot(li, s, li & 7)) =
+                make_int4(x[s * 4 + 0], x[s * 4 + 1], x[s * 4 + 2], x[s * 4 + 3]);
+        wave_lds_fence();
+        int4* co4 = reinterpret_cast<int4*>(coeff + pix_off);
+        int4* qc4 = reinterpret_cast<int4*>(qcoeff + pix_off);
+        int4* dq4 = reinterpret_cast<int4*>(dqcoeff + pix_off);
+        int eob_acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int row = 4 * k + (li >> 3);
+            const int4 c = *reinterpret_cast<const int4*>(tile + tile_slot(row, li & 7, row & 7));
+            int4 q, d;
+            // only linear position 0 (k == 0, li == 0, .x) uses the DC entries
+            quant_one<true>(c.x, (k == 0 && li == 0) ? 0 : 1, qp, q.x, d.x);
+            quant_one<true>(c.y, 1, qp, q.y, d.y);
+            quant_one<true>(c.z, 1, qp, q.z, d.z);
+            quant_one<true>(c.w, 1, qp, q.w, d.w);
+            const int e0 = q.x ? (int)(isc[k].x & 0xffffu) : 0, e1 = q.y ? (int)(isc[k].x >> 16) : 0;
+            const int e2 = q.z ? (int)(isc[k].y & 0xffffu) : 0, e3 = q.w ? (int)(isc[k].y >> 16) : 0;
+            eob_acc = max(eob_acc, max(max(e0, e1), max(e2, e3)));
+            if (valid) { co4[k * 32 + li] = c; qc4[k * 32 + li] = q; dq4[k * 32 + li] = d; }
+        }
+        // eob = 1 + last scan position with a non-zero level (iscan max)
+        eob_acc = half_wave_max(eob_acc);
+        if (WITH_SAD) sad_acc = half_wave_sum(sad_acc);
+        if (valid && li == 0) {
+            eob[blk] = (uint16_t)eob_acc;
+            if (WITH_SAD) sad[blk] = sad_acc;
+        }
+        wave_lds_fence();   // tile is re-used by the next pair
+    }
+}
+
+}  // namespace svtdev

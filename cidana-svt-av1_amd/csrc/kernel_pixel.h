@@ -1,0 +1,192 @@
+// kernel_pixel.h — batched quantize_b, SAD, SAD search, SSE, residual kernels.
+#pragma once
+#include "dev_common.h"
+
+namespace svtdev {
+
+// ---------------------------------------------------------------------------
+// quantize_b on already-transformed coefficients (aom_highbd_quantize_b*,
+// EbFullLoop.c:239-333; AVX2 highbd_quantize_intrin_avx2.c:127-484).
+// n coefficients per block (dense), LPB = min(64, n/4) lanes per block, each
+// lane handles int4 chunks at coalesced positions.
+// ---------------------------------------------------------------------------
+template <int LPB>
+__global__ __launch_bounds__(256) void quantize_b_kernel(
+    const int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
+    uint16_t* __restrict__ eob, const int16_t* __restrict__ iscan, QParams qp, int n, int skip_block,
+    uint32_t nblocks) {
+    constexpr int BPW = 64 / LPB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPB, l = lane % LPB;
+    const uint32_t blk = (blockIdx.x * 4 + wave) * BPW + sub;
+    const bool valid = blk < nblocks;
+    const int4* c4 = reinterpret_cast<const int4*>(coeff + (size_t)blk * n);
+    int4* q4 = reinterpret_cast<int4*>(qcoeff + (size_t)blk * n);
+    int4* d4 = reinterpret_cast<int4*>(dqcoeff + (size_t)blk * n);
+    int eob_acc = 0;
+    for (int i = l; i < n / 4; i += LPB) {
+        int4 c = {0, 0, 0, 0}, q = c, d = c;
+        if (valid && !skip_block) {
+            c = c4[i];
+            const uint2 is = *reinterpret_cast<const uint2*>(iscan + i * 4);
+            quant_one<false>(c.x, i == 0 ? 0 : 1, qp, q.x, d.x);
+            quant_one<false>(c.y, 1, qp, q.y, d.y);
+            quant_one<false>(c.z, 1, qp, q.z, d.z);
+            quant_one<false>(c.w, 1, qp, q.w, d.w);
+            const int e0 = q.x ? (int)(is.x & 0xffffu) + 1 : 0, e1 = q.y ? (int)(is.x >> 16) + 1 : 0;
+            const int e2 = q.z ? (int)(is.y & 0xffffu) + 1 : 0, e3 = q.w ? (int)(is.y >> 16) + 1 : 0;
+            eob_acc = max(eob_acc, max(max(e0, e1), max(e2, e3)));
+        }
+        if (valid) { q4[i] = q; d4[i] = d; }
+    }
+    eob_acc = group_max<LPB>(eob_acc);
+    if (valid && l == 0) eob[blk] = (uint16_t)eob_acc;
+}
+
+// ---------------------------------------------------------------------------
+// plain NxM SAD / SSE of block pairs (fast_loop_nx_m_sad_kernel,
+// C_DEFAULT/EbComputeSAD_C.c:48; spatial_full_distortion_kernel,
+// C_DEFAULT/EbPictureOperators_C.c:40).  Blocks dense or at offsets; one
+// LPB-lane group per block, lane = (row, 4-pixel group) walking the block.
+// ---------------------------------------------------------------------------
+template <bool SSE>
+__global__ __launch_bounds__(256) void sad_sse_kernel(
+    const uint8_t* __restrict__ a, uint32_t a_stride, size_t a_block_pitch,
+    const uint8_t* __restrict__ b, uint32_t b_stride, size_t b_block_pitch,
+    uint32_t width, uint32_t height, void* __restrict__ out, uint32_t nblocks) {
+    // 16 lanes per block, 4 blocks per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, l = lane & 15;
+    const uint32_t blk = (blockIdx.x * 4 + wave) * 4 + sub;
+    const bool valid = blk < nblocks;
+    const uint8_t* pa = a + (size_t)blk * a_block_pitch;
+    const uint8_t* pb = b + (size_t)blk * b_block_pitch;
+    unsigned long long acc = 0;
+    if (valid) {
+        const uint32_t total = width * height;
+        for (uint32_t i = l; i < total; i += 16) {
+            const uint32_t y = i / width, x = i - y * width;
+            const int d = (int)pa[(size_t)y * a_stride + x] - (int)pb[(size_t)y * b_stride + x];
+            acc += SSE ? (unsigned)(d * d) : (unsigned)(d < 0 ? -d : d);
+        }
+    }
+    acc = group_sum64<16>(acc);
+    if (valid && l == 0) {
+        if (SSE) reinterpret_cast<unsigned long long*>(out)[blk] = acc;
+        else reinterpret_cast<uint32_t*>(out)[blk] = (uint32_t)acc;
+    }
+}
+
+// residual_kernel_c (EbPictureOperators.c:166): int16 res = src - pred
+__global__ __launch_bounds__(256) void residual_kernel(
+    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
+    const uint8_t* __restrict__ pred, uint32_t pred_stride, size_t pred_block_pitch,
+    int16_t* __restrict__ res, uint32_t res_stride, size_t res_block_pitch, uint32_t width,
+    uint32_t height, uint32_t nblocks) {
+    const size_t per = (size_t)width * height;
+    const size_t total = per * nblocks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t blk = i / per;
+        const uint32_t j = (uint32_t)(i - blk * per), y = j / width, x = j - y * width;
+        res[blk * res_block_pitch + (size_t)y * res_stride + x] =
+            (int16_t)((int)src[blk * src_block_pitch + (size_t)y * src_stride + x] -
+                      (int)pred[blk * pred_block_pitch + (size_t)y * pred_stride + x]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// SAD search (sad_loop_kernel, C_DEFAULT/EbComputeSAD_C.c:72-120): for every
+// candidate (x, y) of a search_area_width x search_area_height window, SAD of
+// the W x H source block against ref + x + y*ref_stride_raw; first strict
+// minimum in raster order wins.  One wave per block: the source block and the
+// reference window are staged in LDS; lane t evaluates candidates t, t+64, ...
+// v_sad_u8 on dwords rebuilt from aligned LDS words with v_alignbyte.
+// The argmin key (sad << 32 | candidate index) reproduces the tie-break.
+// ---------------------------------------------------------------------------
+// LDS per wave = src_lds_bytes + ref_lds_bytes (host-computed, 16-B multiples);
+// blockDim.x / 64 waves per workgroup, dynamic LDS sized accordingly.
+__global__ __launch_bounds__(256) void sad_search_kernel(
+    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
+    const uint8_t* __restrict__ ref, uint32_t ref_stride, uint32_t ref_stride_raw, size_t ref_block_pitch,
+    uint32_t width, uint32_t height, int search_w, int search_h,
+    unsigned long long* __restrict__ best_sad, int16_t* __restrict__ best_x, int16_t* __restrict__ best_y,
+    uint32_t src_lds_bytes, uint32_t ref_lds_bytes, uint32_t nblocks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t blk = blockIdx.x * (blockDim.x >> 6) + wave;
+    // window geometry in LDS: rows of `wpitch` bytes (multiple of 4, + 4 spare)
+    const uint32_t win_w = width + search_w - 1;
+    // rows of the window that can be touched: candidate row ys adds ys*ref_stride_raw,
+    // block row y adds y*ref_stride; stage (row, offset) pairs as needed.
+    const uint32_t wpitch = (win_w + 3 + 8) & ~3u;   // host uses the same formula
+    const uint32_t spitch = (width + 3) & ~3u;
+    uint8_t* s_src = smem + (size_t)wave * (src_lds_bytes + ref_lds_bytes);
+    uint8_t* s_ref = s_src + src_lds_bytes;
+    if (blk >= nblocks) return;   // whole wave exits together (blk is wave-uniform)
+    const uint8_t* gs = src + (size_t)blk * src_block_pitch;
+    const uint8_t* gr = ref + (size_t)blk * ref_block_pitch;
+    // stage the source block
+    for (uint32_t i = lane; i < spitch * height; i += 64) {
+        const uint32_t y = i / spitch, x = i - y * spitch;
+        s_src[i] = x < width ? gs[(size_t)y * src_stride + x] : 0;
+    }
+    // stage the reference rows.  Row index space: rr = ys * height + y  ->
+    // address ys*ref_stride_raw + y*ref_stride (covers line-skipping callers where
+    // ref_stride = 2*ref_stride_raw).  When ref_stride == ref_stride_raw the rows
+    // overlap and only search_h + height - 1 distinct rows are staged.
+    const bool plain = (ref_stride == ref_stride_raw);
+    const uint32_t nrows = plain ? (uint32_t)(search_h + height - 1) : (uint32_t)search_h * height;
+    for (uint32_t i = lane; i < wpitch * nrows; i += 64) {
+        const uint32_t rr = i / wpitch, x = i - rr * wpitch;
+        size_t off;
+        if (plain) off = (size_t)rr * ref_stride_raw;
+        else off = (size_t)(rr / height) * ref_stride_raw + (size_t)(rr % height) * ref_stride;
+        s_ref[i] = x < win_w ? gr[off + x] : 0;
+    }
+    wave_lds_fence();
+    unsigned long long best = ~0ull;
+    const int ncand = search_w * search_h;
+    const uint32_t wq = spitch >> 2;
+    for (int cand = lane; cand < ncand; cand += 64) {
+        const int ys = cand / search_w, xs = cand - ys * search_w;
+        unsigned acc = 0;
+        for (uint32_t y = 0; y < height; y++) {
+            const uint32_t rr = plain ? (uint32_t)ys + y : (uint32_t)ys * height + y;
+            const uint32_t* rrow = reinterpret_cast<const uint32_t*>(s_ref + rr * wpitch) + (xs >> 2);
+            const uint32_t* srow = reinterpret_cast<const uint32_t*>(s_src + y * spitch);
+            const unsigned sh = (unsigned)(xs & 3);
+            uint32_t lo = rrow[0];
+            for (uint32_t q = 0; q < wq; q++) {
+                const uint32_t hi = rrow[q + 1];
+                const uint32_t rv = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                uint32_t sv = srow[q];
+                uint32_t rvm = rv;
+                const uint32_t rem = width - q * 4;      // < 4 only on a ragged last group
+                if (rem < 4) { const uint32_t m = (1u << (rem * 8)) - 1; rvm &= m; sv &= m; }
+                acc = __builtin_amdgcn_sad_u8(sv, rvm, acc);
+                lo = hi;
+            }
+        }
+        const unsigned long long key = ((unsigned long long)acc << 32) | (unsigned)cand;
+        best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long o = __shfl_xor(best, m, 64);
+        best = o < best ? o : best;
+    }
+    if (lane == 0) {
+        const unsigned sadv = (unsigned)(best >> 32);
+        const int cand = (int)(best & 0xffffffffu);
+        // reference initialises best_sad = 0xffffff and only updates on strict '<'
+        if (ncand > 0 && sadv < 0xffffffu) {
+            best_sad[blk] = sadv;
+            best_x[blk] = (int16_t)(cand % search_w);
+            best_y[blk] = (int16_t)(cand / search_w);
+        } else {
+            best_sad[blk] = 0xffffffu;   // x/y untouched, as in the reference
+        }
+    }
+}
+
+}  // namespace svtdev

@@ -1,0 +1,655 @@
+// svt_hip_dsp.hip — C-ABI shim (include/svt_hip_dsp.h) over the gfx950 kernels.
+// Host logic only: argument checks, launch geometry, per-thread staging for the
+// drop-in (one block per call) entry points.  NO CPU compute path exists here:
+// if HIP is unusable the batched API returns an error and the drop-ins abort.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+
+#include "../../include/svt_hip_dsp.h"
+#include "kernel_fused32.h"
+#include "kernel_pixel.h"
+#include "kernel_txfm.h"
+
+using namespace svtdev;
+
+namespace {
+
+thread_local char g_err[512] = "";
+std::atomic<int> g_inited{0};
+std::mutex g_init_mu;
+int g_device = -1;
+char g_devname[300] = "";
+int g_num_cu = 256;
+
+int set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return set_err(SVT_HIP_ERR_RUNTIME, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                                  \
+    } while (0)
+
+int require_init() {
+    if (g_inited.load(std::memory_order_acquire)) return SVT_HIP_OK;
+    return svt_hip_init(0);
+}
+int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(SVT_HIP_ERR_RUNTIME, "launch %s: %s", what, hipGetErrorString(e));
+    return SVT_HIP_OK;
+}
+
+const int kTxW[SVT_TX_SIZES_ALL] = {4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64};
+const int kTxH[SVT_TX_SIZES_ALL] = {4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16};
+
+// is_txfm_allowed (test/TxfmCommon.h:172-181; av1_estimate_transform's switch)
+bool txfm_allowed(int tx_size, int tx_type) {
+    if (tx_size < 0 || tx_size >= SVT_TX_SIZES_ALL || tx_type < 0 || tx_type >= SVT_TX_TYPES) return false;
+    const int m = kTxW[tx_size] > kTxH[tx_size] ? kTxW[tx_size] : kTxH[tx_size];
+    if (m == 64) return tx_type == SVT_DCT_DCT;
+    if (m == 32) return tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX;
+    return true;
+}
+
+int rpot(int v, int n) { return n == 0 ? v : ((v + (1 << (n - 1))) >> n); }
+
+QParams make_qparams(const int16_t* zbin, const int16_t* round, const int16_t* quant,
+                     const int16_t* quant_shift, const int16_t* dequant, int log_scale) {
+    QParams qp;
+    for (int i = 0; i < 2; i++) {
+        qp.zbin[i] = rpot(zbin[i], log_scale);       // EbFullLoop.c:248-249
+        qp.round[i] = rpot(round[i], log_scale);     // :277
+        qp.quant_m[i] = (uint32_t)((int)quant[i] + 65536);
+        qp.quant_shift[i] = quant_shift[i];
+        qp.dequant[i] = dequant[i];
+    }
+    qp.log_scale = log_scale;
+    return qp;
+}
+
+// ---------------------------------------------------------------------------
+// 64-pt packing kernel (HandleTransform64x64_c & friends)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack64_kernel(int32_t* __restrict__ coeff,
+                                                     unsigned long long* __restrict__ energy, int w, int h,
+                                                     uint32_t nblocks) {
+    // one workgroup per block; reads complete before any write (barrier)
+    const uint32_t blk = blockIdx.x;
+    if (blk >= nblocks) return;
+    const int kw = w > 32 ? 32 : w, kh = h > 32 ? 32 : h;
+    int32_t* c = coeff + (size_t)blk * w * h;
+    __shared__ int32_t keep[1024];
+    __shared__ unsigned long long part[4];
+    unsigned long long e = 0;
+    for (int i = threadIdx.x; i < w * h; i += 256) {
+        const int r = i / w, cc = i - r * w;
+        const long long v = c[i];
+        if (r < kh && cc < kw) keep[r * kw + cc] = (int32_t)v;
+        else e += (unsigned long long)(v * v);
+    }
+    e = group_sum64<64>(e);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+    __syncthreads();
+    for (int i = threadIdx.x; i < w * h; i += 256) c[i] = i < kw * kh ? keep[i] : 0;
+    if (threadIdx.x == 0 && energy) energy[blk] = part[0] + part[1] + part[2] + part[3];
+}
+
+template <int W, int H>
+int launch_fwd(const int16_t* in, uint32_t in_stride, size_t pitch, int32_t* out, size_t n, int tx_type,
+               hipStream_t s) {
+    constexpr int BPW = TxGeom<W, H>::BPW;
+    const uint32_t per_wg = TX_WAVES * BPW;
+    const uint32_t grid = (uint32_t)((n + per_wg - 1) / per_wg);
+    hipLaunchKernelGGL((fwd_txfm2d_kernel<W, H>), dim3(grid), dim3(TX_WAVES * 64), 0, s, in, out, in_stride,
+                       pitch, tx_type, (uint32_t)n);
+    return launch_status("fwd_txfm2d");
+}
+template <int W, int H>
+int launch_inv(const int32_t* in, void* dst, int is16, int32_t stride, size_t pitch, const uint32_t* offs,
+               size_t n, int tx_type, int bd, hipStream_t s) {
+    constexpr int BPW = TxGeom<W, H>::BPW;
+    const uint32_t per_wg = TX_WAVES * BPW;
+    const uint32_t grid = (uint32_t)((n + per_wg - 1) / per_wg);
+    if (is16)
+        hipLaunchKernelGGL((inv_txfm2d_add_kernel<W, H, uint16_t>), dim3(grid), dim3(TX_WAVES * 64), 0, s, in,
+                           (uint16_t*)dst, stride, pitch, offs, tx_type, bd, (uint32_t)n);
+    else
+        hipLaunchKernelGGL((inv_txfm2d_add_kernel<W, H, uint8_t>), dim3(grid), dim3(TX_WAVES * 64), 0, s, in,
+                           (uint8_t*)dst, stride, pitch, offs, tx_type, bd, (uint32_t)n);
+    return launch_status("inv_txfm2d_add");
+}
+
+#define TX_SWITCH(tx_size, CALL)                                                                  \
+    switch (tx_size) {                                                                            \
+    case SVT_TX_4X4: return CALL(4, 4); case SVT_TX_8X8: return CALL(8, 8);                        \
+    case SVT_TX_16X16: return CALL(16, 16); case SVT_TX_32X32: return CALL(32, 32);                \
+    case SVT_TX_64X64: return CALL(64, 64); case SVT_TX_4X8: return CALL(4, 8);                    \
+    case SVT_TX_8X4: return CALL(8, 4); case SVT_TX_8X16: return CALL(8, 16);                      \
+    case SVT_TX_16X8: return CALL(16, 8); case SVT_TX_16X32: return CALL(16, 32);                  \
+    case SVT_TX_32X16: return CALL(32, 16); case SVT_TX_32X64: return CALL(32, 64);                \
+    case SVT_TX_64X32: return CALL(64, 32); case SVT_TX_4X16: return CALL(4, 16);                  \
+    case SVT_TX_16X4: return CALL(16, 4); case SVT_TX_8X32: return CALL(8, 32);                    \
+    case SVT_TX_32X8: return CALL(32, 8); case SVT_TX_16X64: return CALL(16, 64);                  \
+    case SVT_TX_64X16: return CALL(64, 16);                                                       \
+    default: return set_err(SVT_HIP_ERR_INVALID, "bad tx_size %d", tx_size);                      \
+    }
+
+// ---------------------------------------------------------------------------
+// per-thread context for the drop-in entry points
+// ---------------------------------------------------------------------------
+struct ThreadCtx {
+    hipStream_t stream = nullptr;
+    char* dbuf = nullptr;
+    size_t cap = 0;
+    ~ThreadCtx() {
+        if (dbuf) (void)hipFree(dbuf);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    int ensure(size_t bytes) {
+        if (require_init() != SVT_HIP_OK) return SVT_HIP_ERR_NO_DEVICE;
+        if (!stream) {
+            HIP_TRY(hipSetDevice(g_device));
+            HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        }
+        if (bytes > cap) {
+            if (dbuf) HIP_TRY(hipFree(dbuf));
+            dbuf = nullptr;
+            cap = 0;
+            const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+            HIP_TRY(hipMalloc((void**)&dbuf, want));
+            cap = want;
+        }
+        return SVT_HIP_OK;
+    }
+};
+thread_local ThreadCtx t_ctx;
+
+[[noreturn]] void die(const char* fn) {
+    fprintf(stderr, "libsvt_hip_dsp: %s: %s — no CPU fallback exists; aborting\n", fn, g_err);
+    abort();
+}
+#define DROPIN_TRY(expr, fn) do { if ((expr) != SVT_HIP_OK) die(fn); } while (0)
+#define HIP_DIE(expr, fn)                                                          \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) { set_err(SVT_HIP_ERR_RUNTIME, "%s: %s", #expr, hipGetErrorString(e_)); die(fn); } \
+    } while (0)
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// ===========================================================================
+// init / misc
+// ===========================================================================
+extern "C" int svt_hip_init(int device) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (g_inited.load(std::memory_order_acquire)) return SVT_HIP_OK;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_err(SVT_HIP_ERR_NO_DEVICE, "no HIP device (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return set_err(SVT_HIP_ERR_INVALID, "device %d out of range (%d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(g_devname, sizeof(g_devname), "%s %s (%d CUs)", prop.gcnArchName, prop.name, prop.multiProcessorCount);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(SVT_HIP_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
+                       prop.gcnArchName);
+    g_num_cu = prop.multiProcessorCount;
+    g_device = device;
+    g_inited.store(1, std::memory_order_release);
+    return SVT_HIP_OK;
+}
+extern "C" void svt_hip_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    g_inited.store(0, std::memory_order_release);
+}
+extern "C" const char* svt_hip_last_error(void) { return g_err; }
+extern "C" const char* svt_hip_device_name(void) { return g_devname; }
+
+extern "C" void* svt_hip_malloc(size_t bytes) {
+    if (require_init() != SVT_HIP_OK) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { set_err(SVT_HIP_ERR_RUNTIME, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+extern "C" void svt_hip_free(void* p) { if (p) (void)hipFree(p); }
+extern "C" int svt_hip_memcpy_h2d(void* d, const void* h, size_t n, void* s) {
+    HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
+    return SVT_HIP_OK;
+}
+extern "C" int svt_hip_memcpy_d2h(void* h, const void* d, size_t n, void* s) {
+    HIP_TRY(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s));
+    return SVT_HIP_OK;
+}
+extern "C" int svt_hip_stream_sync(void* s) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+    return SVT_HIP_OK;
+}
+
+// ===========================================================================
+// (B) batched API
+// ===========================================================================
+extern "C" int svt_hip_fwd_txfm2d_batch(const int16_t* d_in, uint32_t in_stride, size_t in_block_pitch,
+                                        int32_t* d_out, size_t nblocks, int tx_size, int tx_type, int bd,
+                                        void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_in || !d_out) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (!txfm_allowed(tx_size, tx_type)) return set_err(SVT_HIP_ERR_INVALID, "tx_size %d / tx_type %d not defined by the reference", tx_size, tx_type);
+    if (bd != 8 && bd != 10) return set_err(SVT_HIP_ERR_INVALID, "bit depth %d", bd);
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (nblocks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "nblocks too large");
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(W, H) launch_fwd<W, H>(d_in, in_stride, in_block_pitch, d_out, nblocks, tx_type, s)
+    TX_SWITCH(tx_size, CALL)
+#undef CALL
+}
+
+extern "C" int svt_hip_pack64_batch(int32_t* d_coeff, uint64_t* d_energy, size_t nblocks, int tx_size,
+                                    void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (tx_size < 0 || tx_size >= SVT_TX_SIZES_ALL || !d_coeff) return set_err(SVT_HIP_ERR_INVALID, "bad argument");
+    const int w = kTxW[tx_size], h = kTxH[tx_size];
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (w != 64 && h != 64) {
+        if (d_energy) HIP_TRY(hipMemsetAsync(d_energy, 0, nblocks * sizeof(uint64_t), (hipStream_t)stream));
+        return SVT_HIP_OK;
+    }
+    hipLaunchKernelGGL(pack64_kernel, dim3((uint32_t)nblocks), dim3(256), 0, (hipStream_t)stream, d_coeff,
+                       (unsigned long long*)d_energy, w, h, (uint32_t)nblocks);
+    return launch_status("pack64");
+}
+
+extern "C" int svt_hip_inv_txfm2d_add_batch(const int32_t* d_coeff, void* d_dst, int dst_is_16bit,
+                                            int32_t dst_stride, size_t dst_block_pitch,
+                                            const uint32_t* d_dst_offsets, size_t nblocks, int tx_size,
+                                            int tx_type, int bd, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_coeff || !d_dst) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (!txfm_allowed(tx_size, tx_type)) return set_err(SVT_HIP_ERR_INVALID, "tx_size %d / tx_type %d not defined by the reference", tx_size, tx_type);
+    if (bd != 8 && bd != 10 && bd != 12) return set_err(SVT_HIP_ERR_INVALID, "bit depth %d", bd);
+    if (!dst_is_16bit && bd != 8) return set_err(SVT_HIP_ERR_INVALID, "8-bit destination needs bd = 8");
+    if (nblocks == 0) return SVT_HIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(W, H) launch_inv<W, H>(d_coeff, d_dst, dst_is_16bit, dst_stride, dst_block_pitch, d_dst_offsets, nblocks, tx_type, bd, s)
+    TX_SWITCH(tx_size, CALL)
+#undef CALL
+}
+
+extern "C" int svt_hip_quantize_b_batch(const int32_t* d_coeff, size_t n_coeffs, int skip_block,
+                                        const int16_t* zbin, const int16_t* round, const int16_t* quant,
+                                        const int16_t* quant_shift, int32_t* d_qcoeff, int32_t* d_dqcoeff,
+                                        const int16_t* dequant, uint16_t* d_eob, const int16_t* d_iscan,
+                                        int log_scale, size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_coeff || !d_qcoeff || !d_dqcoeff || !d_eob || !d_iscan || !zbin || !round || !quant || !quant_shift || !dequant)
+        return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    if (n_coeffs < 16 || n_coeffs > 4096 || (n_coeffs & 15)) return set_err(SVT_HIP_ERR_INVALID, "n_coeffs %zu", n_coeffs);
+    if (log_scale < 0 || log_scale > 2) return set_err(SVT_HIP_ERR_INVALID, "log_scale %d", log_scale);
+    if (nblocks == 0) return SVT_HIP_OK;
+    const QParams qp = make_qparams(zbin, round, quant, quant_shift, dequant, log_scale);
+    hipStream_t s = (hipStream_t)stream;
+    const int n = (int)n_coeffs;
+    const int lpb = n / 4 >= 64 ? 64 : n / 4;   // 4, 8, 16, 32 or 64 lanes per block
+#define QL(L)                                                                                          \
+    {                                                                                                  \
+        const uint32_t per_wg = 4 * (64 / L);                                                          \
+        hipLaunchKernelGGL((quantize_b_kernel<L>), dim3((uint32_t)((nblocks + per_wg - 1) / per_wg)), dim3(256), 0, \
+                           s, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_iscan, qp, n, skip_block, (uint32_t)nblocks); \
+    }
+    switch (lpb) {
+    case 4: QL(4) break; case 8: QL(8) break; case 16: QL(16) break; case 32: QL(32) break;
+    default: QL(64) break;
+    }
+#undef QL
+    return launch_status("quantize_b");
+}
+
+extern "C" int svt_hip_fwd_quant_sad_batch(const uint8_t* d_src, const uint8_t* d_pred, size_t nblocks,
+                                           int tx_size, int tx_type, const int16_t* zbin, const int16_t* round,
+                                           const int16_t* quant, const int16_t* quant_shift,
+                                           const int16_t* dequant, const int16_t* d_iscan, int32_t* d_coeff,
+                                           int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob,
+                                           uint32_t* d_sad, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_src || !d_pred || !d_coeff || !d_qcoeff || !d_dqcoeff || !d_eob || !d_iscan || !zbin || !round || !quant || !quant_shift || !dequant)
+        return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    if (tx_size != SVT_TX_32X32 || tx_type != SVT_DCT_DCT)
+        return set_err(SVT_HIP_ERR_UNSUPPORTED, "fused chain: only TX_32X32 / DCT_DCT is built (got %d/%d)", tx_size, tx_type);
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (nblocks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "nblocks too large");
+    const QParams qp = make_qparams(zbin, round, quant, quant_shift, dequant, 1);
+    // FAST24 precondition of the fused kernel (dev_common.h quant_one<true>)
+    for (int i = 0; i < 2; i++)
+        if (qp.quant_shift[i] < 0 || qp.dequant[i] < 0 || qp.round[i] < 0)
+            return set_err(SVT_HIP_ERR_INVALID, "negative quantizer table entry");
+    const uint32_t npairs = (uint32_t)((nblocks + 1) / 2);
+    uint32_t grid = (npairs + F32_WAVES - 1) / F32_WAVES;
+    const uint32_t max_grid = (uint32_t)g_num_cu * 5u * 4u;   // 5 resident WGs/CU (LDS-limited) x 4 rounds
+    if (grid > max_grid) grid = max_grid;
+    hipStream_t s = (hipStream_t)stream;
+    if (d_sad)
+        hipLaunchKernelGGL((fwd_quant_sad_32x32_kernel<true>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, d_pred,
+                           d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL((fwd_quant_sad_32x32_kernel<false>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, d_pred,
+                           d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks);
+    return launch_status("fwd_quant_sad_32x32");
+}
+
+static int sad_sse_common(bool sse, const uint8_t* a, uint32_t as, size_t ap, const uint8_t* b, uint32_t bs,
+                          size_t bp, uint32_t w, uint32_t h, void* out, size_t n, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (n == 0) return SVT_HIP_OK;
+    if (!a || !b || !out) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (w == 0 || h == 0 || w > 128 || h > 128) return set_err(SVT_HIP_ERR_INVALID, "block %ux%u", w, h);
+    if (n == 0) return SVT_HIP_OK;
+    const uint32_t grid = (uint32_t)((n + 15) / 16);
+    if (sse)
+        hipLaunchKernelGGL((sad_sse_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, as, ap, b, bs, bp, w, h, out, (uint32_t)n);
+    else
+        hipLaunchKernelGGL((sad_sse_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, as, ap, b, bs, bp, w, h, out, (uint32_t)n);
+    return launch_status(sse ? "sse" : "sad");
+}
+extern "C" int svt_hip_sad_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                 const uint8_t* d_ref, uint32_t ref_stride, size_t ref_block_pitch, uint32_t width,
+                                 uint32_t height, uint32_t* d_out, size_t nblocks, void* stream) {
+    return sad_sse_common(false, d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, width, height, d_out, nblocks, stream);
+}
+extern "C" int svt_hip_sse_batch(const uint8_t* d_a, uint32_t a_stride, size_t a_block_pitch, const uint8_t* d_b,
+                                 uint32_t b_stride, size_t b_block_pitch, uint32_t width, uint32_t height,
+                                 uint64_t* d_out, size_t nblocks, void* stream) {
+    return sad_sse_common(true, d_a, a_stride, a_block_pitch, d_b, b_stride, b_block_pitch, width, height, d_out, nblocks, stream);
+}
+extern "C" int svt_hip_residual_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                      const uint8_t* d_pred, uint32_t pred_stride, size_t pred_block_pitch,
+                                      int16_t* d_res, uint32_t res_stride, size_t res_block_pitch, uint32_t width,
+                                      uint32_t height, size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_src || !d_pred || !d_res) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (width == 0 || height == 0) return set_err(SVT_HIP_ERR_INVALID, "empty block");
+    if (nblocks == 0) return SVT_HIP_OK;
+    const size_t total = (size_t)width * height * nblocks;
+    size_t grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(residual_kernel, dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_src, src_stride,
+                       src_block_pitch, d_pred, pred_stride, pred_block_pitch, d_res, res_stride, res_block_pitch,
+                       width, height, (uint32_t)nblocks);
+    return launch_status("residual");
+}
+
+extern "C" int svt_hip_sad_search_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                        const uint8_t* d_ref, uint32_t ref_stride, uint32_t ref_stride_raw,
+                                        size_t ref_block_pitch, uint32_t width, uint32_t height,
+                                        int16_t search_area_width, int16_t search_area_height,
+                                        uint64_t* d_best_sad, int16_t* d_x, int16_t* d_y, size_t nblocks,
+                                        void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_src || !d_ref || !d_best_sad || !d_x || !d_y) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (width == 0 || height == 0 || width > 64 || height > 64) return set_err(SVT_HIP_ERR_INVALID, "block %ux%u", width, height);
+    if (search_area_width <= 0 || search_area_height <= 0) return set_err(SVT_HIP_ERR_INVALID, "empty search area");
+    if (nblocks == 0) return SVT_HIP_OK;
+    const uint32_t win_w = width + search_area_width - 1;
+    const uint32_t wpitch = (win_w + 3 + 8) & ~3u;
+    const uint32_t spitch = (width + 3) & ~3u;
+    const bool plain = ref_stride == ref_stride_raw;
+    const uint32_t nrows = plain ? (uint32_t)(search_area_height + height - 1) : (uint32_t)search_area_height * height;
+    const uint32_t src_bytes = (spitch * height + 15) & ~15u;
+    const uint32_t ref_bytes = (wpitch * nrows + 16 + 15) & ~15u;
+    const uint32_t per_wave = src_bytes + ref_bytes;
+    if (per_wave > 64 * 1024) return set_err(SVT_HIP_ERR_INVALID, "search window needs %u B of LDS per block (> 64 KiB)", per_wave);
+    uint32_t waves = (64 * 1024) / per_wave;
+    if (waves > 4) waves = 4;
+    const uint32_t grid = (uint32_t)((nblocks + waves - 1) / waves);
+    hipLaunchKernelGGL(sad_search_kernel, dim3(grid), dim3(waves * 64), waves * per_wave, (hipStream_t)stream, d_src,
+                       src_stride, src_block_pitch, d_ref, ref_stride, ref_stride_raw, ref_block_pitch, width, height,
+                       (int)search_area_width, (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y,
+                       src_bytes, ref_bytes, (uint32_t)nblocks);
+    return launch_status("sad_search");
+}
+
+// ===========================================================================
+// (A) drop-in entry points: host pointers, one block, synchronous
+// ===========================================================================
+static void dropin_fwd(int tx_size, int16_t* input, int32_t* output, uint32_t stride, uint8_t tx_type, uint8_t bd,
+                       const char* fn) {
+    const int w = kTxW[tx_size], h = kTxH[tx_size];
+    const size_t in_b = align256((size_t)w * h * 2), out_b = (size_t)w * h * 4;
+    DROPIN_TRY(t_ctx.ensure(in_b + out_b), fn);
+    int16_t* d_in = (int16_t*)t_ctx.dbuf;
+    int32_t* d_out = (int32_t*)(t_ctx.dbuf + in_b);
+    HIP_DIE(hipMemcpy2DAsync(d_in, (size_t)w * 2, input, (size_t)stride * 2, (size_t)w * 2, h, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_fwd_txfm2d_batch(d_in, (uint32_t)w, (size_t)w * h, d_out, 1, tx_size, tx_type, bd, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(output, d_out, out_b, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+#define DEF_FWD(W, H, TS)                                                                                          \
+    extern "C" void svt_hip_av1_fwd_txfm2d_##W##x##H(int16_t* input, int32_t* output, uint32_t input_stride,      \
+                                                     svt_tx_type_t transform_type, uint8_t bit_depth) {           \
+        dropin_fwd(TS, input, output, input_stride, transform_type, bit_depth, "svt_hip_av1_fwd_txfm2d_" #W "x" #H); \
+    }
+DEF_FWD(4, 4, SVT_TX_4X4) DEF_FWD(8, 8, SVT_TX_8X8) DEF_FWD(16, 16, SVT_TX_16X16) DEF_FWD(32, 32, SVT_TX_32X32)
+DEF_FWD(64, 64, SVT_TX_64X64) DEF_FWD(4, 8, SVT_TX_4X8) DEF_FWD(8, 4, SVT_TX_8X4) DEF_FWD(8, 16, SVT_TX_8X16)
+DEF_FWD(16, 8, SVT_TX_16X8) DEF_FWD(16, 32, SVT_TX_16X32) DEF_FWD(32, 16, SVT_TX_32X16) DEF_FWD(32, 64, SVT_TX_32X64)
+DEF_FWD(64, 32, SVT_TX_64X32) DEF_FWD(4, 16, SVT_TX_4X16) DEF_FWD(16, 4, SVT_TX_16X4) DEF_FWD(8, 32, SVT_TX_8X32)
+DEF_FWD(32, 8, SVT_TX_32X8) DEF_FWD(16, 64, SVT_TX_16X64) DEF_FWD(64, 16, SVT_TX_64X16)
+#undef DEF_FWD
+
+static void dropin_inv(int tx_size, const int32_t* input, void* output, int is16, int32_t stride, uint8_t tx_type,
+                       int32_t bd, const char* fn) {
+    const int w = kTxW[tx_size], h = kTxH[tx_size];
+    const int kw = w > 32 ? 32 : w, kh = h > 32 ? 32 : h;
+    const size_t es = is16 ? 2 : 1;
+    const size_t in_b = align256((size_t)kw * kh * 4), px_b = (size_t)w * h * es;
+    DROPIN_TRY(t_ctx.ensure(in_b + px_b), fn);
+    int32_t* d_in = (int32_t*)t_ctx.dbuf;
+    char* d_px = t_ctx.dbuf + in_b;
+    HIP_DIE(hipMemcpyAsync(d_in, input, (size_t)kw * kh * 4, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpy2DAsync(d_px, (size_t)w * es, output, (size_t)stride * es, (size_t)w * es, h, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_inv_txfm2d_add_batch(d_in, d_px, is16, w, (size_t)w * h, nullptr, 1, tx_size, tx_type, bd, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpy2DAsync(output, (size_t)stride * es, d_px, (size_t)w * es, (size_t)w * es, h, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+#define DEF_INV_SQ(W, H, TS)                                                                                       \
+    extern "C" void svt_hip_av1_inv_txfm2d_add_##W##x##H(const int32_t* input, uint16_t* output, int32_t stride,  \
+                                                         svt_tx_type_t tx_type, int32_t bd) {                     \
+        dropin_inv(TS, input, output, 1, stride, tx_type, bd, "svt_hip_av1_inv_txfm2d_add_" #W "x" #H);           \
+    }
+#define DEF_INV_R1(W, H, TS)                                                                                       \
+    extern "C" void svt_hip_av1_inv_txfm2d_add_##W##x##H(const int32_t* input, uint16_t* output, int32_t stride,  \
+                                                         svt_tx_type_t tx_type, svt_tx_size_t, int32_t, int32_t bd) { \
+        dropin_inv(TS, input, output, 1, stride, tx_type, bd, "svt_hip_av1_inv_txfm2d_add_" #W "x" #H);           \
+    }
+#define DEF_INV_R2(W, H, TS)                                                                                       \
+    extern "C" void svt_hip_av1_inv_txfm2d_add_##W##x##H(const int32_t* input, uint16_t* output, int32_t stride,  \
+                                                         svt_tx_type_t tx_type, svt_tx_size_t, int32_t bd) {      \
+        dropin_inv(TS, input, output, 1, stride, tx_type, bd, "svt_hip_av1_inv_txfm2d_add_" #W "x" #H);           \
+    }
+DEF_INV_SQ(4, 4, SVT_TX_4X4) DEF_INV_SQ(8, 8, SVT_TX_8X8) DEF_INV_SQ(16, 16, SVT_TX_16X16)
+DEF_INV_SQ(32, 32, SVT_TX_32X32) DEF_INV_SQ(64, 64, SVT_TX_64X64)
+DEF_INV_R1(8, 16, SVT_TX_8X16) DEF_INV_R1(16, 8, SVT_TX_16X8) DEF_INV_R1(16, 32, SVT_TX_16X32)
+DEF_INV_R1(32, 16, SVT_TX_32X16) DEF_INV_R1(32, 64, SVT_TX_32X64) DEF_INV_R1(64, 32, SVT_TX_64X32)
+DEF_INV_R1(8, 32, SVT_TX_8X32) DEF_INV_R1(32, 8, SVT_TX_32X8) DEF_INV_R1(16, 64, SVT_TX_16X64)
+DEF_INV_R1(64, 16, SVT_TX_64X16)
+DEF_INV_R2(4, 8, SVT_TX_4X8) DEF_INV_R2(8, 4, SVT_TX_8X4) DEF_INV_R2(4, 16, SVT_TX_4X16) DEF_INV_R2(16, 4, SVT_TX_16X4)
+#undef DEF_INV_SQ
+#undef DEF_INV_R1
+#undef DEF_INV_R2
+
+extern "C" void svt_hip_av1_inv_txfm_add(const svt_tran_low_t* dqcoeff, uint8_t* dst, int32_t stride,
+                                         const svt_txfm_param* p) {
+    dropin_inv(p->tx_size, dqcoeff, dst, 0, stride, p->tx_type, 8, "svt_hip_av1_inv_txfm_add");
+}
+
+static void dropin_quant(int log_scale, const int32_t* coeff, intptr_t n, int32_t skip, const int16_t* zbin,
+                         const int16_t* round, const int16_t* quant, const int16_t* qshift, int32_t* q, int32_t* dq,
+                         const int16_t* dequant, uint16_t* eob, const int16_t* iscan, const char* fn) {
+    const size_t cb = align256((size_t)n * 4), ib = align256((size_t)n * 2);
+    DROPIN_TRY(t_ctx.ensure(3 * cb + ib + 256), fn);
+    int32_t* d_c = (int32_t*)t_ctx.dbuf;
+    int32_t* d_q = (int32_t*)(t_ctx.dbuf + cb);
+    int32_t* d_dq = (int32_t*)(t_ctx.dbuf + 2 * cb);
+    int16_t* d_is = (int16_t*)(t_ctx.dbuf + 3 * cb);
+    uint16_t* d_eob = (uint16_t*)(t_ctx.dbuf + 3 * cb + ib);
+    HIP_DIE(hipMemcpyAsync(d_c, coeff, (size_t)n * 4, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(d_is, iscan, (size_t)n * 2, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_quantize_b_batch(d_c, (size_t)n, skip, zbin, round, quant, qshift, d_q, d_dq, dequant, d_eob, d_is, log_scale, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(q, d_q, (size_t)n * 4, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(dq, d_dq, (size_t)n * 4, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(eob, d_eob, 2, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+#define DEF_QUANT(name, LS)                                                                                        \
+    extern "C" void name(const svt_tran_low_t* coeff_ptr, intptr_t n_coeffs, int32_t skip_block,                  \
+                         const int16_t* zbin_ptr, const int16_t* round_ptr, const int16_t* quant_ptr,             \
+                         const int16_t* quant_shift_ptr, svt_tran_low_t* qcoeff_ptr, svt_tran_low_t* dqcoeff_ptr, \
+                         const int16_t* dequant_ptr, uint16_t* eob_ptr, const int16_t* scan, const int16_t* iscan) { \
+        (void)scan;                                                                                                \
+        dropin_quant(LS, coeff_ptr, n_coeffs, skip_block, zbin_ptr, round_ptr, quant_ptr, quant_shift_ptr,         \
+                     qcoeff_ptr, dqcoeff_ptr, dequant_ptr, eob_ptr, iscan, #name);                                 \
+    }
+DEF_QUANT(svt_hip_aom_highbd_quantize_b, 0)
+DEF_QUANT(svt_hip_aom_highbd_quantize_b_32x32, 1)
+DEF_QUANT(svt_hip_aom_highbd_quantize_b_64x64, 2)
+DEF_QUANT(svt_hip_aom_quantize_b, 0)
+DEF_QUANT(svt_hip_aom_quantize_b_32x32, 1)
+DEF_QUANT(svt_hip_aom_quantize_b_64x64, 2)
+#undef DEF_QUANT
+
+// copies a w x h u8 block with `stride` into dense device memory
+static void h2d_block(void* d, const uint8_t* h, uint32_t stride, uint32_t w, uint32_t ht, const char* fn) {
+    HIP_DIE(hipMemcpy2DAsync(d, w, h, stride, w, ht, hipMemcpyHostToDevice, t_ctx.stream), fn);
+}
+
+extern "C" uint32_t svt_hip_nxm_sad_kernel(const uint8_t* src, uint32_t src_stride, const uint8_t* ref,
+                                           uint32_t ref_stride, uint32_t height, uint32_t width) {
+    const char* fn = "svt_hip_nxm_sad_kernel";
+    const size_t bb = align256((size_t)width * height);
+    DROPIN_TRY(t_ctx.ensure(2 * bb + 256), fn);
+    uint8_t* d_a = (uint8_t*)t_ctx.dbuf;
+    uint8_t* d_b = d_a + bb;
+    uint32_t* d_o = (uint32_t*)(d_a + 2 * bb);
+    h2d_block(d_a, src, src_stride, width, height, fn);
+    h2d_block(d_b, ref, ref_stride, width, height, fn);
+    DROPIN_TRY(svt_hip_sad_batch(d_a, width, 0, d_b, width, 0, width, height, d_o, 1, t_ctx.stream), fn);
+    uint32_t out = 0;
+    HIP_DIE(hipMemcpyAsync(&out, d_o, 4, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+    return out;
+}
+extern "C" uint64_t svt_hip_spatial_full_distortion_kernel(uint8_t* input, uint32_t input_stride, uint8_t* recon,
+                                                           uint32_t recon_stride, uint32_t area_width,
+                                                           uint32_t area_height) {
+    const char* fn = "svt_hip_spatial_full_distortion_kernel";
+    const size_t bb = align256((size_t)area_width * area_height);
+    DROPIN_TRY(t_ctx.ensure(2 * bb + 256), fn);
+    uint8_t* d_a = (uint8_t*)t_ctx.dbuf;
+    uint8_t* d_b = d_a + bb;
+    uint64_t* d_o = (uint64_t*)(d_a + 2 * bb);
+    h2d_block(d_a, input, input_stride, area_width, area_height, fn);
+    h2d_block(d_b, recon, recon_stride, area_width, area_height, fn);
+    DROPIN_TRY(svt_hip_sse_batch(d_a, area_width, 0, d_b, area_width, 0, area_width, area_height, d_o, 1, t_ctx.stream), fn);
+    uint64_t out = 0;
+    HIP_DIE(hipMemcpyAsync(&out, d_o, 8, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+    return out;
+}
+extern "C" void svt_hip_residual_kernel(uint8_t* input, uint32_t input_stride, uint8_t* pred, uint32_t pred_stride,
+                                        int16_t* residual, uint32_t residual_stride, uint32_t area_width,
+                                        uint32_t area_height) {
+    const char* fn = "svt_hip_residual_kernel";
+    const size_t bb = align256((size_t)area_width * area_height);
+    DROPIN_TRY(t_ctx.ensure(4 * bb), fn);
+    uint8_t* d_a = (uint8_t*)t_ctx.dbuf;
+    uint8_t* d_b = d_a + bb;
+    int16_t* d_r = (int16_t*)(d_a + 2 * bb);
+    h2d_block(d_a, input, input_stride, area_width, area_height, fn);
+    h2d_block(d_b, pred, pred_stride, area_width, area_height, fn);
+    DROPIN_TRY(svt_hip_residual_batch(d_a, area_width, 0, d_b, area_width, 0, d_r, area_width, 0, area_width, area_height, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpy2DAsync(residual, (size_t)residual_stride * 2, d_r, (size_t)area_width * 2, (size_t)area_width * 2,
+                             area_height, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+extern "C" void svt_hip_sad_loop_kernel(uint8_t* src, uint32_t src_stride, uint8_t* ref, uint32_t ref_stride,
+                                        uint32_t height, uint32_t width, uint64_t* best_sad, int16_t* x_search_center,
+                                        int16_t* y_search_center, uint32_t src_stride_raw, int16_t search_area_width,
+                                        int16_t search_area_height) {
+    const char* fn = "svt_hip_sad_loop_kernel";
+    // stage the touched source rows and the touched reference span as-is (strides kept)
+    const size_t src_span = (size_t)(height - 1) * src_stride + width;
+    const size_t ref_span = (size_t)(search_area_height - 1) * src_stride_raw + (size_t)(height - 1) * ref_stride +
+                            width + search_area_width - 1;
+    const size_t sb = align256(src_span), rb = align256(ref_span);
+    DROPIN_TRY(t_ctx.ensure(sb + rb + 256), fn);
+    uint8_t* d_s = (uint8_t*)t_ctx.dbuf;
+    uint8_t* d_r = d_s + sb;
+    uint64_t* d_best = (uint64_t*)(d_r + rb);
+    int16_t* d_xy = (int16_t*)(d_best + 1);
+    int16_t xy[2] = {*x_search_center, *y_search_center};
+    HIP_DIE(hipMemcpyAsync(d_s, src, src_span, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(d_r, ref, ref_span, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(d_xy, xy, 4, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_sad_search_batch(d_s, src_stride, 0, d_r, ref_stride, src_stride_raw, 0, width, height,
+                                        search_area_width, search_area_height, d_best, d_xy, d_xy + 1, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(best_sad, d_best, 8, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(xy, d_xy, 4, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+    *x_search_center = xy[0];
+    *y_search_center = xy[1];
+}
+
+extern "C" int svt_hip_rtcd_override(const svt_hip_rtcd_table* t) {
+    if (!t) return set_err(SVT_HIP_ERR_INVALID, "NULL table");
+    if (int rc = require_init()) return rc;
+    void* fwd[SVT_TX_SIZES_ALL] = {
+        (void*)svt_hip_av1_fwd_txfm2d_4x4, (void*)svt_hip_av1_fwd_txfm2d_8x8, (void*)svt_hip_av1_fwd_txfm2d_16x16,
+        (void*)svt_hip_av1_fwd_txfm2d_32x32, (void*)svt_hip_av1_fwd_txfm2d_64x64, (void*)svt_hip_av1_fwd_txfm2d_4x8,
+        (void*)svt_hip_av1_fwd_txfm2d_8x4, (void*)svt_hip_av1_fwd_txfm2d_8x16, (void*)svt_hip_av1_fwd_txfm2d_16x8,
+        (void*)svt_hip_av1_fwd_txfm2d_16x32, (void*)svt_hip_av1_fwd_txfm2d_32x16, (void*)svt_hip_av1_fwd_txfm2d_32x64,
+        (void*)svt_hip_av1_fwd_txfm2d_64x32, (void*)svt_hip_av1_fwd_txfm2d_4x16, (void*)svt_hip_av1_fwd_txfm2d_16x4,
+        (void*)svt_hip_av1_fwd_txfm2d_8x32, (void*)svt_hip_av1_fwd_txfm2d_32x8, (void*)svt_hip_av1_fwd_txfm2d_16x64,
+        (void*)svt_hip_av1_fwd_txfm2d_64x16};
+    void* inv[SVT_TX_SIZES_ALL] = {
+        (void*)svt_hip_av1_inv_txfm2d_add_4x4, (void*)svt_hip_av1_inv_txfm2d_add_8x8, (void*)svt_hip_av1_inv_txfm2d_add_16x16,
+        (void*)svt_hip_av1_inv_txfm2d_add_32x32, (void*)svt_hip_av1_inv_txfm2d_add_64x64, (void*)svt_hip_av1_inv_txfm2d_add_4x8,
+        (void*)svt_hip_av1_inv_txfm2d_add_8x4, (void*)svt_hip_av1_inv_txfm2d_add_8x16, (void*)svt_hip_av1_inv_txfm2d_add_16x8,
+        (void*)svt_hip_av1_inv_txfm2d_add_16x32, (void*)svt_hip_av1_inv_txfm2d_add_32x16, (void*)svt_hip_av1_inv_txfm2d_add_32x64,
+        (void*)svt_hip_av1_inv_txfm2d_add_64x32, (void*)svt_hip_av1_inv_txfm2d_add_4x16, (void*)svt_hip_av1_inv_txfm2d_add_16x4,
+        (void*)svt_hip_av1_inv_txfm2d_add_8x32, (void*)svt_hip_av1_inv_txfm2d_add_32x8, (void*)svt_hip_av1_inv_txfm2d_add_16x64,
+        (void*)svt_hip_av1_inv_txfm2d_add_64x16};
+    for (int i = 0; i < SVT_TX_SIZES_ALL; i++) {
+        if (t->av1_fwd_txfm2d[i]) *t->av1_fwd_txfm2d[i] = fwd[i];
+        if (t->av1_inv_txfm2d_add[i]) *t->av1_inv_txfm2d_add[i] = inv[i];
+    }
+    if (t->av1_inv_txfm_add) *t->av1_inv_txfm_add = (void*)svt_hip_av1_inv_txfm_add;
+    if (t->aom_quantize_b) *t->aom_quantize_b = (void*)svt_hip_aom_quantize_b;
+    if (t->aom_quantize_b_32x32) *t->aom_quantize_b_32x32 = (void*)svt_hip_aom_quantize_b_32x32;
+    if (t->aom_quantize_b_64x64) *t->aom_quantize_b_64x64 = (void*)svt_hip_aom_quantize_b_64x64;
+    if (t->aom_highbd_quantize_b) *t->aom_highbd_quantize_b = (void*)svt_hip_aom_highbd_quantize_b;
+    if (t->aom_highbd_quantize_b_32x32) *t->aom_highbd_quantize_b_32x32 = (void*)svt_hip_aom_highbd_quantize_b_32x32;
+    if (t->aom_highbd_quantize_b_64x64) *t->aom_highbd_quantize_b_64x64 = (void*)svt_hip_aom_highbd_quantize_b_64x64;
+    if (t->ResidualKernel) *t->ResidualKernel = (void*)svt_hip_residual_kernel;
+    return SVT_HIP_OK;
+}

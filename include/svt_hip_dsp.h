@@ -1,0 +1,263 @@
+/*
+ * svt_hip_dsp.h — C ABI of libsvt_hip_dsp.so: the MI355X (gfx950) implementation
+ * of SVT-AV1's block-DSP hot path.  Plain C, plain pointers and sizes; no HIP or
+ * torch types appear in any signature (streams travel as void*).
+ *
+ * Two layers:
+ *
+ *  (A) DROP-IN entry points — the exact signatures of the reference's dispatch
+ *      slots (RTCD globals in Source/Lib/Common/Codec/aom_dsp_rtcd.h and the
+ *      *_funcPtrArray[asm_type] tables).  HOST pointers, synchronous, re-entrant
+ *      (per-thread stream + staging).  They exist so that the reference's own
+ *      call sites and unit tests can run unchanged against this library; one
+ *      block per call cannot be fast on a GPU.
+ *
+ *  (B) BATCHED entry points — arrays of blocks per launch on DEVICE-resident
+ *      buffers with an explicit stream; this is where the throughput is.
+ *
+ * There is no CPU fallback anywhere: when the HIP runtime / device is not
+ * usable, (B) returns SVT_HIP_ERR_* and (A), whose reference signatures have no
+ * error channel, print the error to stderr and abort().
+ *
+ * Numeric contract: every output is bit-exact with the reference's C / AVX2
+ * kernels (all arithmetic on this path is integer).  8-bit quantisation follows
+ * the reference's PRODUCTION slot, i.e. the high-bit-depth algorithm that
+ * setup_rtcd_internal installs under AVX2 (aom_dsp_rtcd.h:3330-3334), not the
+ * INT16-clamping aom_quantize_b_c_II.
+ */
+#ifndef SVT_HIP_DSP_H
+#define SVT_HIP_DSP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- reference types (Source/Lib/Common/Codec/EbDefinitions.h) ------------- */
+typedef uint8_t svt_tx_size_t;   /* TxSize, packed enum  (EbDefinitions.h:615-650) */
+typedef uint8_t svt_tx_type_t;   /* TxType, packed enum  (EbDefinitions.h:727-746) */
+typedef int32_t svt_tran_low_t;  /* tran_low_t           (EbDefinitions.h:662)     */
+
+enum { SVT_TX_4X4, SVT_TX_8X8, SVT_TX_16X16, SVT_TX_32X32, SVT_TX_64X64, SVT_TX_4X8, SVT_TX_8X4,
+       SVT_TX_8X16, SVT_TX_16X8, SVT_TX_16X32, SVT_TX_32X16, SVT_TX_32X64, SVT_TX_64X32,
+       SVT_TX_4X16, SVT_TX_16X4, SVT_TX_8X32, SVT_TX_32X8, SVT_TX_16X64, SVT_TX_64X16, SVT_TX_SIZES_ALL };
+enum { SVT_DCT_DCT, SVT_ADST_DCT, SVT_DCT_ADST, SVT_ADST_ADST, SVT_FLIPADST_DCT, SVT_DCT_FLIPADST,
+       SVT_FLIPADST_FLIPADST, SVT_ADST_FLIPADST, SVT_FLIPADST_ADST, SVT_IDTX, SVT_V_DCT, SVT_H_DCT,
+       SVT_V_ADST, SVT_H_ADST, SVT_V_FLIPADST, SVT_H_FLIPADST, SVT_TX_TYPES };
+
+/* TxfmParam (EbDefinitions.h:764-776), same layout */
+typedef struct svt_txfm_param {
+    svt_tx_type_t tx_type;
+    svt_tx_size_t tx_size;
+    int32_t lossless;
+    int32_t bd;
+    int32_t is_hbd;
+    uint8_t tx_set_type;
+    int32_t eob;
+} svt_txfm_param;
+
+/* ---- status ---------------------------------------------------------------- */
+enum {
+    SVT_HIP_OK = 0,
+    SVT_HIP_ERR_NO_DEVICE = -1,     /* HIP runtime or gfx950 device unavailable */
+    SVT_HIP_ERR_INVALID = -2,       /* bad argument (size/type not defined by AV1, NULL, ...) */
+    SVT_HIP_ERR_UNSUPPORTED = -3,   /* defined by the reference but not built yet */
+    SVT_HIP_ERR_RUNTIME = -4        /* a HIP call failed; see svt_hip_last_error() */
+};
+
+/* Initialise on HIP device `device` (call once per process, before any worker
+ * thread uses the library — mirrors eb_init_encoder's single-threaded RTCD fill,
+ * EbEncHandle.c:917).  Idempotent. */
+int svt_hip_init(int device);
+void svt_hip_shutdown(void);
+/* thread-local, NUL-terminated, never NULL */
+const char *svt_hip_last_error(void);
+/* "gfx950 ..." description of the device in use (empty string before init) */
+const char *svt_hip_device_name(void);
+
+/* device memory helpers for C hosts that do not link the HIP runtime */
+void *svt_hip_malloc(size_t bytes);
+void svt_hip_free(void *dptr);
+int svt_hip_memcpy_h2d(void *dptr, const void *hptr, size_t bytes, void *stream);
+int svt_hip_memcpy_d2h(void *hptr, const void *dptr, size_t bytes, void *stream);
+int svt_hip_stream_sync(void *stream);
+
+/* ============================================================================
+ * (B) batched API — device pointers, `stream` is a hipStream_t (NULL = default)
+ * Every call only enqueues work; it returns before the GPU finishes.
+ * ==========================================================================*/
+
+/* K1 forward 2-D transform.  Replaces av1_fwd_txfm2d_WxH
+ * (aom_dsp_rtcd.h:160-255; C: EbTransforms.c:4410-4910; AVX2:
+ * highbd_fwd_txfm_avx2.c:762-5814) over `nblocks` blocks.
+ * d_in: int16 residual, block b at d_in + b*in_block_pitch, row stride in_stride
+ * (elements).  d_out: dense W*H int32 per block, row-major, full size (64-pt
+ * outputs are NOT packed; see svt_hip_pack64_batch). */
+int svt_hip_fwd_txfm2d_batch(const int16_t *d_in, uint32_t in_stride, size_t in_block_pitch,
+                             int32_t *d_out, size_t nblocks, int tx_size, int tx_type, int bd,
+                             void *stream);
+
+/* 64-pt handling of av1_estimate_transform (EbTransforms.c:4377-4408,
+ * 4580-4731, 5157-5175): per block, energy of the discarded region -> d_energy
+ * (may be NULL), then re-pack the kept min(W,32) x min(H,32) region in place and
+ * zero the tail.  No-op (energy 0) for sizes without a 64 dimension. */
+int svt_hip_pack64_batch(int32_t *d_coeff, uint64_t *d_energy, size_t nblocks, int tx_size,
+                         void *stream);
+
+/* K2 inverse 2-D transform + add.  Replaces av1_inv_txfm2d_add_WxH
+ * (aom_dsp_rtcd.h:350-417; C: EbTransforms.c:8180-8458) and, with
+ * dst_is_16bit = 0, the 8-bit recon entry av1_inv_txfm_add (:8882-8903).
+ * d_coeff: dense packed min(W,32)*min(H,32) int32 per block.
+ * d_dst: uint16 (dst_is_16bit) or uint8 samples; block b lives at
+ * d_dst + (d_dst_offsets ? d_dst_offsets[b] : b*dst_block_pitch), row stride
+ * dst_stride (all in elements).  Blocks must not overlap. */
+int svt_hip_inv_txfm2d_add_batch(const int32_t *d_coeff, void *d_dst, int dst_is_16bit,
+                                 int32_t dst_stride, size_t dst_block_pitch,
+                                 const uint32_t *d_dst_offsets, size_t nblocks, int tx_size,
+                                 int tx_type, int bd, void *stream);
+
+/* K3 quantize + dequantize + eob.  Replaces aom_highbd_quantize_b{,_32x32,_64x64}
+ * (aom_dsp_rtcd.h:323-342; C: EbFullLoop.c:239-333; AVX2:
+ * highbd_quantize_intrin_avx2.c:127-484) over nblocks dense blocks of n_coeffs.
+ * zbin/round/quant/quant_shift/dequant: HOST pointers to the reference's
+ * int16[8] table rows ([0] = DC, [1] = AC).  d_iscan: DEVICE int16[n_coeffs].
+ * log_scale: 0 (aom_highbd_quantize_b), 1 (_32x32), 2 (_64x64). */
+int svt_hip_quantize_b_batch(const int32_t *d_coeff, size_t n_coeffs, int skip_block,
+                             const int16_t *zbin, const int16_t *round, const int16_t *quant,
+                             const int16_t *quant_shift, int32_t *d_qcoeff, int32_t *d_dqcoeff,
+                             const int16_t *dequant, uint16_t *d_eob, const int16_t *d_iscan,
+                             int log_scale, size_t nblocks, void *stream);
+
+/* Headline chain (BASELINE.json metric), fused in one kernel: per block
+ *   residual = src - pred            ResidualKernel   (EbCodingLoop.c:617)
+ *   coeff    = FwdTxfm2d(residual)   av1_estimate_transform (EbFullLoop.c:763)
+ *   q,dq,eob = quantize_b(coeff)     av1_quantize_inv_quantize (EbFullLoop.c:780)
+ *   sad      = SAD(src, pred)        NxMSadKernel     (EbProductCodingLoop.c:1259)
+ * d_src/d_pred: dense W*H uint8 per block.  Outputs dense per block; d_sad may be
+ * NULL.  Round 1: tx_size must be SVT_TX_32X32 and tx_type SVT_DCT_DCT. */
+int svt_hip_fwd_quant_sad_batch(const uint8_t *d_src, const uint8_t *d_pred, size_t nblocks,
+                                int tx_size, int tx_type, const int16_t *zbin,
+                                const int16_t *round, const int16_t *quant,
+                                const int16_t *quant_shift, const int16_t *dequant,
+                                const int16_t *d_iscan, int32_t *d_coeff, int32_t *d_qcoeff,
+                                int32_t *d_dqcoeff, uint16_t *d_eob, uint32_t *d_sad, void *stream);
+
+/* K4 NxM SAD (NxMSadKernel_funcPtrArray, EbComputeSAD.h:105-160; C:
+ * EbComputeSAD_C.c:48) and K7 SSE (spatial_full_distortion_kernel,
+ * EbPictureOperators_C.c:40) over nblocks block pairs; d_out: uint32 / uint64. */
+int svt_hip_sad_batch(const uint8_t *d_src, uint32_t src_stride, size_t src_block_pitch,
+                      const uint8_t *d_ref, uint32_t ref_stride, size_t ref_block_pitch,
+                      uint32_t width, uint32_t height, uint32_t *d_out, size_t nblocks, void *stream);
+int svt_hip_sse_batch(const uint8_t *d_a, uint32_t a_stride, size_t a_block_pitch,
+                      const uint8_t *d_b, uint32_t b_stride, size_t b_block_pitch, uint32_t width,
+                      uint32_t height, uint64_t *d_out, size_t nblocks, void *stream);
+/* K8 residual (ResidualKernel, aom_dsp_rtcd.h:2372; C: EbPictureOperators.c:166) */
+int svt_hip_residual_batch(const uint8_t *d_src, uint32_t src_stride, size_t src_block_pitch,
+                           const uint8_t *d_pred, uint32_t pred_stride, size_t pred_block_pitch,
+                           int16_t *d_res, uint32_t res_stride, size_t res_block_pitch,
+                           uint32_t width, uint32_t height, size_t nblocks, void *stream);
+
+/* K5 SAD search (NxMSadLoopKernel_funcPtrArray, EbComputeSAD.h:199; C:
+ * sad_loop_kernel, EbComputeSAD_C.c:72-120).  Per block b: source block at
+ * d_src + b*src_block_pitch, reference window origin at d_ref + b*ref_block_pitch.
+ * Outputs: best_sad (uint64), x/y search centre (int16), first minimum in raster
+ * order.  Limits: width, height <= 64; window must fit the LDS budget
+ * (else SVT_HIP_ERR_INVALID). */
+int svt_hip_sad_search_batch(const uint8_t *d_src, uint32_t src_stride, size_t src_block_pitch,
+                             const uint8_t *d_ref, uint32_t ref_stride, uint32_t ref_stride_raw,
+                             size_t ref_block_pitch, uint32_t width, uint32_t height,
+                             int16_t search_area_width, int16_t search_area_height,
+                             uint64_t *d_best_sad, int16_t *d_x, int16_t *d_y, size_t nblocks,
+                             void *stream);
+
+/* ============================================================================
+ * (A) drop-in entry points — reference signatures, HOST pointers, synchronous.
+ * ==========================================================================*/
+
+/* av1_fwd_txfm2d_WxH (aom_dsp_rtcd.h:160-255) */
+#define SVT_HIP_DECL_FWD(W, H) \
+    void svt_hip_av1_fwd_txfm2d_##W##x##H(int16_t *input, int32_t *output, uint32_t input_stride, \
+                                          svt_tx_type_t transform_type, uint8_t bit_depth);
+SVT_HIP_DECL_FWD(4, 4) SVT_HIP_DECL_FWD(8, 8) SVT_HIP_DECL_FWD(16, 16) SVT_HIP_DECL_FWD(32, 32)
+SVT_HIP_DECL_FWD(64, 64) SVT_HIP_DECL_FWD(4, 8) SVT_HIP_DECL_FWD(8, 4) SVT_HIP_DECL_FWD(8, 16)
+SVT_HIP_DECL_FWD(16, 8) SVT_HIP_DECL_FWD(16, 32) SVT_HIP_DECL_FWD(32, 16) SVT_HIP_DECL_FWD(32, 64)
+SVT_HIP_DECL_FWD(64, 32) SVT_HIP_DECL_FWD(4, 16) SVT_HIP_DECL_FWD(16, 4) SVT_HIP_DECL_FWD(8, 32)
+SVT_HIP_DECL_FWD(32, 8) SVT_HIP_DECL_FWD(16, 64) SVT_HIP_DECL_FWD(64, 16)
+#undef SVT_HIP_DECL_FWD
+
+/* av1_inv_txfm2d_add_WxH (aom_dsp_rtcd.h:350-417): the three signature classes */
+#define SVT_HIP_DECL_INV_SQ(W, H) \
+    void svt_hip_av1_inv_txfm2d_add_##W##x##H(const int32_t *input, uint16_t *output, int32_t stride, \
+                                              svt_tx_type_t tx_type, int32_t bd);
+#define SVT_HIP_DECL_INV_R1(W, H) \
+    void svt_hip_av1_inv_txfm2d_add_##W##x##H(const int32_t *input, uint16_t *output, int32_t stride, \
+                                              svt_tx_type_t tx_type, svt_tx_size_t tx_size, int32_t eob, int32_t bd);
+#define SVT_HIP_DECL_INV_R2(W, H) \
+    void svt_hip_av1_inv_txfm2d_add_##W##x##H(const int32_t *input, uint16_t *output, int32_t stride, \
+                                              svt_tx_type_t tx_type, svt_tx_size_t tx_size, int32_t bd);
+SVT_HIP_DECL_INV_SQ(4, 4) SVT_HIP_DECL_INV_SQ(8, 8) SVT_HIP_DECL_INV_SQ(16, 16) SVT_HIP_DECL_INV_SQ(32, 32)
+SVT_HIP_DECL_INV_SQ(64, 64)
+SVT_HIP_DECL_INV_R1(8, 16) SVT_HIP_DECL_INV_R1(16, 8) SVT_HIP_DECL_INV_R1(16, 32) SVT_HIP_DECL_INV_R1(32, 16)
+SVT_HIP_DECL_INV_R1(32, 64) SVT_HIP_DECL_INV_R1(64, 32) SVT_HIP_DECL_INV_R1(8, 32) SVT_HIP_DECL_INV_R1(32, 8)
+SVT_HIP_DECL_INV_R1(16, 64) SVT_HIP_DECL_INV_R1(64, 16)
+SVT_HIP_DECL_INV_R2(4, 8) SVT_HIP_DECL_INV_R2(8, 4) SVT_HIP_DECL_INV_R2(4, 16) SVT_HIP_DECL_INV_R2(16, 4)
+#undef SVT_HIP_DECL_INV_SQ
+#undef SVT_HIP_DECL_INV_R1
+#undef SVT_HIP_DECL_INV_R2
+/* av1_inv_txfm_add (aom_dsp_rtcd.h:421-423): 8-bit recon */
+void svt_hip_av1_inv_txfm_add(const svt_tran_low_t *dqcoeff, uint8_t *dst, int32_t stride,
+                              const svt_txfm_param *txfm_param);
+
+/* aom_highbd_quantize_b{,_32x32,_64x64} and the 8-bit aom_quantize_b* slots
+ * (aom_dsp_rtcd.h:323-342) */
+#define SVT_HIP_DECL_QUANT(name) \
+    void name(const svt_tran_low_t *coeff_ptr, intptr_t n_coeffs, int32_t skip_block, \
+              const int16_t *zbin_ptr, const int16_t *round_ptr, const int16_t *quant_ptr, \
+              const int16_t *quant_shift_ptr, svt_tran_low_t *qcoeff_ptr, svt_tran_low_t *dqcoeff_ptr, \
+              const int16_t *dequant_ptr, uint16_t *eob_ptr, const int16_t *scan, const int16_t *iscan);
+SVT_HIP_DECL_QUANT(svt_hip_aom_highbd_quantize_b)
+SVT_HIP_DECL_QUANT(svt_hip_aom_highbd_quantize_b_32x32)
+SVT_HIP_DECL_QUANT(svt_hip_aom_highbd_quantize_b_64x64)
+SVT_HIP_DECL_QUANT(svt_hip_aom_quantize_b)
+SVT_HIP_DECL_QUANT(svt_hip_aom_quantize_b_32x32)
+SVT_HIP_DECL_QUANT(svt_hip_aom_quantize_b_64x64)
+#undef SVT_HIP_DECL_QUANT
+
+/* EB_SADKERNELNxM_TYPE (EbComputeSAD.h:25-31): one row of NxMSadKernel_funcPtrArray */
+uint32_t svt_hip_nxm_sad_kernel(const uint8_t *src, uint32_t src_stride, const uint8_t *ref,
+                                uint32_t ref_stride, uint32_t height, uint32_t width);
+/* EB_SADLOOPKERNELNxM_TYPE (EbComputeSAD.h:35-47) */
+void svt_hip_sad_loop_kernel(uint8_t *src, uint32_t src_stride, uint8_t *ref, uint32_t ref_stride,
+                             uint32_t height, uint32_t width, uint64_t *best_sad,
+                             int16_t *x_search_center, int16_t *y_search_center,
+                             uint32_t src_stride_raw, int16_t search_area_width,
+                             int16_t search_area_height);
+/* spatial_full_distortion_kernel_func_ptr_array entry (EbPictureOperators.h:470) */
+uint64_t svt_hip_spatial_full_distortion_kernel(uint8_t *input, uint32_t input_stride, uint8_t *recon,
+                                                uint32_t recon_stride, uint32_t area_width,
+                                                uint32_t area_height);
+/* ResidualKernel (aom_dsp_rtcd.h:2372) */
+void svt_hip_residual_kernel(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride,
+                             int16_t *residual, uint32_t residual_stride, uint32_t area_width,
+                             uint32_t area_height);
+
+/* Pointer table the host fills after the stock setup_rtcd_internal(asm_type)
+ * (EbEncHandle.c:917) and BEFORE init_intra_predictors_internal(): each member is
+ * the address of the reference's RTCD global of the same name (or NULL to leave
+ * that slot alone).  svt_hip_rtcd_override stores the svt_hip_* drop-ins in them. */
+typedef struct svt_hip_rtcd_table {
+    void **av1_fwd_txfm2d[SVT_TX_SIZES_ALL];      /* &av1_fwd_txfm2d_4x4 ... by TxSize */
+    void **av1_inv_txfm2d_add[SVT_TX_SIZES_ALL];  /* &av1_inv_txfm2d_add_4x4 ... */
+    void **av1_inv_txfm_add;
+    void **aom_quantize_b, **aom_quantize_b_32x32, **aom_quantize_b_64x64;
+    void **aom_highbd_quantize_b, **aom_highbd_quantize_b_32x32, **aom_highbd_quantize_b_64x64;
+    void **ResidualKernel;
+} svt_hip_rtcd_table;
+int svt_hip_rtcd_override(const svt_hip_rtcd_table *table);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVT_HIP_DSP_H */

@@ -64,9 +64,9 @@ static void *chain_worker(void *arg) {
     if (posix_memalign((void **)&sc, 32, 3 * 1024 * sizeof(int32_t))) return NULL;
     for (size_t b = j->begin; b < j->end; b++) {
         uint8_t *s = (uint8_t *)j->src + b * 1024, *p = (uint8_t *)j->pred + b * 1024;
-        int32_t *co = j->coeff ? j->coeff + b * 1024 : sc;
-        int32_t *qc = j->qcoeff ? j->qcoeff + b * 1024 : sc + 1024;
-        int32_t *dq = j->dqcoeff ? j->dqcoeff + b * 1024 : sc + 2048;
+        /* always compute into 32-B aligned scratch (the AVX2 kernels use aligned
+         * stores, as the encoder's own buffers are aligned); copy out if asked */
+        int32_t *co = sc, *qc = sc + 1024, *dq = sc + 2048;
         uint16_t eob;
         if (j->avx2) {
             ResidualKernel_avx2(s, 32, p, 32, res, 32, 32, 32);
@@ -82,6 +82,9 @@ static void *chain_worker(void *arg) {
             j->sad[b] = fast_loop_nx_m_sad_kernel(s, 32, p, 32, 32, 32);
         }
         j->eob[b] = eob;
+        if (j->coeff) memcpy(j->coeff + b * 1024, co, 4096);
+        if (j->qcoeff) memcpy(j->qcoeff + b * 1024, qc, 4096);
+        if (j->dqcoeff) memcpy(j->dqcoeff + b * 1024, dq, 4096);
     }
     free(res); free(sc);
     return NULL;

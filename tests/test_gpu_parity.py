@@ -1,0 +1,240 @@
+"""GPU parity tests: the HIP path, called through the C ABI
+(include/svt_hip_dsp.h), against the CPU oracle on the same seeded inputs.
+Bit-exact everywhere (all outputs on this path are integers).  Mirrors the
+reference's own unit tests: FwdTxfm2dAsmTest.cc:74-166 (all sizes x allowed types
+x bd{8,10}, uniform +-(2^bd-1) inputs), InvTxfm2dAsmTest.cc:166-510 (coefficients
+from the forward transform), QuantAsmTest.cc:84-308 (q sweep, +-2^(7+bd))."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import svtlibs
+from svtlibs import TX_H, TX_SIZES, TX_TYPES, TX_W, ptr, txfm_allowed
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def oracle_chain(src, pred, tx_size, tx_type, qrow):
+    O = svtlibs.oracle()
+    n = src.shape[0]
+    h, w = src.shape[1:]
+    nc = min(w, 32) * min(h, 32)
+    co = np.zeros((n, w * h), np.int32); q = np.zeros((n, w * h), np.int32); dq = np.zeros((n, w * h), np.int32)
+    eob = np.zeros(n, np.uint16); sad = np.zeros(n, np.uint32)
+    for i in range(n):
+        O.svt_oracle_fwd_quant_sad(ptr(src[i]), w, ptr(pred[i]), w, tx_size, tx_type, ptr(qrow["zbin"]),
+                                   ptr(qrow["round"]), ptr(qrow["quant"]), ptr(qrow["quant_shift"]),
+                                   ptr(qrow["dequant"]), ptr(co[i]), ptr(q[i]), ptr(dq[i]),
+                                   ptr(eob[i:i + 1]), ptr(sad[i:i + 1]))
+    return co[:, :nc], q[:, :nc], dq[:, :nc], eob, sad
+
+
+def make_pixels(rng, n, h, w, kind):
+    src = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+    pred = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+    if kind == "extreme":      # residual +-255 everywhere / checker / flat
+        src[0] = 255; pred[0] = 0
+        src[1] = 0; pred[1] = 255
+        src[2] = pred[2]                      # zero residual -> eob 0
+        yy, xx = np.mgrid[0:h, 0:w]
+        src[3] = np.where((yy + xx) & 1, 255, 0); pred[3] = 255 - src[3]
+        src[4] = 128; pred[4] = 127          # DC only
+    if kind == "smooth":
+        pred = np.clip(src.astype(int) + rng.integers(-3, 4, size=src.shape), 0, 255).astype(np.uint8)
+    return src, pred
+
+
+@pytest.mark.parametrize("qindex", [0, 1, 25, 100, 180, 255])
+@pytest.mark.parametrize("kind", ["random", "extreme", "smooth"])
+def test_fused_fwd_quant_sad_32x32(dsp, pkg, qindex, kind):
+    rng = np.random.default_rng(13596 + qindex)
+    n = 37                                   # odd: exercises the half-empty last wave
+    src, pred = make_pixels(rng, n, 32, 32, kind)
+    qt = svtlibs.quant_tables(8)
+    qrow = {k: v[qindex].copy() for k, v in qt.items()}
+    _, iscan = svtlibs.scan_tables(3, 0)
+    co, q, dq, eob, sad = dsp.fwd_quant_sad(dev(src), dev(pred), 3, 0, qrow, dev(iscan))
+    torch.cuda.synchronize()
+    rco, rq, rdq, reob, rsad = oracle_chain(src, pred, 3, 0, qrow)
+    assert np.array_equal(co.cpu().numpy(), rco)
+    assert np.array_equal(q.cpu().numpy(), rq)
+    assert np.array_equal(dq.cpu().numpy(), rdq)
+    assert np.array_equal(eob.cpu().numpy().view(np.uint16), reob)
+    assert np.array_equal(sad.cpu().numpy().view(np.uint32), rsad)
+
+
+def test_fused_empty_and_single(dsp, pkg):
+    qt = svtlibs.quant_tables(8)
+    qrow = {k: v[100].copy() for k, v in qt.items()}
+    _, iscan = svtlibs.scan_tables(3, 0)
+    e = torch.empty((0, 32, 32), dtype=torch.uint8, device=DEV)
+    dsp.fwd_quant_sad(e, e, 3, 0, qrow, dev(iscan))          # n = 0 is a no-op
+    rng = np.random.default_rng(1)
+    src, pred = make_pixels(rng, 1, 32, 32, "random")
+    co, q, dq, eob, sad = dsp.fwd_quant_sad(dev(src), dev(pred), 3, 0, qrow, dev(iscan))
+    rco, rq, rdq, reob, rsad = oracle_chain(src, pred, 3, 0, qrow)
+    assert np.array_equal(co.cpu().numpy(), rco) and np.array_equal(q.cpu().numpy(), rq)
+    assert int(eob.cpu().numpy().view(np.uint16)[0]) == int(reob[0])
+
+
+def test_fused_unsupported_size_is_loud(dsp, pkg):
+    qt = svtlibs.quant_tables(8)
+    qrow = {k: v[100].copy() for k, v in qt.items()}
+    _, iscan = svtlibs.scan_tables(2, 0)
+    x = torch.zeros((4, 16, 16), dtype=torch.uint8, device=DEV)
+    with pytest.raises(pkg.SvtHipError):
+        dsp.fwd_quant_sad(x, x, 2, 0, qrow, dev(iscan))
+
+
+@pytest.mark.parametrize("tx_size", range(19))
+@pytest.mark.parametrize("bd", [8, 10])
+def test_fwd_txfm2d_all_types(dsp, tx_size, bd):
+    O = svtlibs.oracle()
+    w, h = TX_W[tx_size], TX_H[tx_size]
+    rng = np.random.default_rng(100 * tx_size + bd)
+    n = 21
+    for tx_type in range(16):
+        if not txfm_allowed(tx_size, tx_type):
+            continue
+        x = rng.integers(-(1 << bd) + 1, 1 << bd, size=(n, h, w)).astype(np.int16)
+        x[0] = (1 << bd) - 1; x[1] = -((1 << bd) - 1); x[2] = 0
+        x[3] = 0; x[3, 0, 0] = (1 << bd) - 1
+        out = dsp.fwd_txfm2d(dev(x), tx_size, tx_type, bd).cpu().numpy()
+        ref = np.zeros((n, w * h), np.int32)
+        for i in range(n):
+            O.svt_oracle_fwd_txfm2d(ptr(x[i]), ptr(ref[i]), ctypes.c_uint32(w), tx_type, tx_size, bd)
+        assert np.array_equal(out, ref), f"{TX_SIZES[tx_size]} {TX_TYPES[tx_type]} bd{bd}"
+
+
+@pytest.mark.parametrize("tx_size", [4, 11, 12, 17, 18])
+def test_pack64(dsp, tx_size):
+    O = svtlibs.oracle()
+    w, h = TX_W[tx_size], TX_H[tx_size]
+    rng = np.random.default_rng(tx_size)
+    n = 5
+    c = rng.integers(-(1 << 17), 1 << 17, size=(n, w * h)).astype(np.int32)
+    d = dev(c)
+    energy = dsp.pack64(d, tx_size).cpu().numpy()
+    ref = c.copy()
+    for i in range(n):
+        e = O.svt_oracle_fwd_txfm2d_pack64(ptr(ref[i]), tx_size)
+        assert int(energy[i]) == int(e)
+    assert np.array_equal(d.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("tx_size", range(19))
+@pytest.mark.parametrize("bd", [8, 10])
+def test_inv_txfm2d_add_all_types(dsp, tx_size, bd):
+    O = svtlibs.oracle()
+    w, h = TX_W[tx_size], TX_H[tx_size]
+    kw, kh = min(w, 32), min(h, 32)
+    rng = np.random.default_rng(7 * tx_size + bd)
+    n = 13
+    for tx_type in range(16):
+        if not txfm_allowed(tx_size, tx_type):
+            continue
+        co = np.zeros((n, kw * kh), np.int32)
+        for i in range(n):
+            if i < 9:    # coefficients of a forward transform (InvTxfm2dAsmTest.cc:398-462)
+                x = rng.integers(-(1 << bd) + 1, 1 << bd, size=(h, w)).astype(np.int16)
+                full = np.zeros(w * h, np.int32)
+                O.svt_oracle_fwd_txfm2d(ptr(x), ptr(full), ctypes.c_uint32(w), tx_type, tx_size, bd)
+                O.svt_oracle_fwd_txfm2d_pack64(ptr(full), tx_size)
+                co[i] = full[:kw * kh]
+                if i >= 5:   # eob truncation: clear the tail in raster order
+                    co[i, rng.integers(1, kw * kh):] = 0
+            else:        # out-of-range garbage exercises every clamp
+                co[i] = rng.integers(-(1 << 20), 1 << 20, size=kw * kh)
+        dst = rng.integers(0, 1 << bd, size=(n, h, w)).astype(np.uint16)
+        ref = dst.copy()
+        for i in range(n):
+            O.svt_oracle_inv_txfm2d_add(ptr(co[i]), ptr(ref[i]), w, tx_type, tx_size, bd)
+        d = dev(dst.view(np.int16))
+        dsp.inv_txfm2d_add(dev(co), d, tx_size, tx_type, bd)
+        assert np.array_equal(d.cpu().numpy().view(np.uint16), ref), f"{TX_SIZES[tx_size]} {TX_TYPES[tx_type]} bd{bd}"
+        if bd == 8:      # the 8-bit recon entry (av1_inv_txfm_add)
+            dst8 = dst.astype(np.uint8)
+            ref8 = dst8.copy()
+            for i in range(n):
+                O.svt_oracle_inv_txfm2d_add_u8(ptr(co[i]), ptr(ref8[i]), w, tx_type, tx_size)
+            d8 = dev(dst8)
+            dsp.inv_txfm2d_add(dev(co), d8, tx_size, tx_type, 8)
+            assert np.array_equal(d8.cpu().numpy(), ref8)
+
+
+@pytest.mark.parametrize("tx_size,log_scale", [(0, 0), (1, 0), (2, 0), (3, 1), (4, 2), (9, 1), (7, 0), (5, 0)])
+@pytest.mark.parametrize("bd", [8, 10])
+def test_quantize_b(dsp, tx_size, log_scale, bd):
+    O = svtlibs.oracle()
+    qt = svtlibs.quant_tables(bd)
+    scan, iscan = svtlibs.scan_tables(tx_size, 0)
+    nc = len(scan)
+    rng = np.random.default_rng(tx_size * 31 + bd)
+    n = 11
+    for qindex in (0, 1, 25, 100, 200, 255):
+        qrow = {k: v[qindex].copy() for k, v in qt.items()}
+        co = rng.integers(-(1 << (7 + bd)), (1 << (7 + bd)) + 1, size=(n, nc)).astype(np.int32)
+        co[0] = 0
+        co[1] = 0; co[1, 0] = 30000
+        co[2, rng.random(nc) < 0.95] = 0
+        co[3] = rng.integers(-40, 41, size=nc)
+        q, dq, eob = dsp.quantize_b(dev(co), qrow, dev(iscan), log_scale)
+        rq = np.zeros_like(co); rdq = np.zeros_like(co); reob = np.zeros(n, np.uint16)
+        for i in range(n):
+            O.svt_oracle_quantize_b(ptr(co[i]), ctypes.c_ssize_t(nc), 0, ptr(qrow["zbin"]), ptr(qrow["round"]),
+                                    ptr(qrow["quant"]), ptr(qrow["quant_shift"]), ptr(rq[i]), ptr(rdq[i]),
+                                    ptr(qrow["dequant"]), ptr(reob[i:i + 1]), ptr(scan), ptr(iscan), log_scale, 0)
+        assert np.array_equal(q.cpu().numpy(), rq)
+        assert np.array_equal(dq.cpu().numpy(), rdq)
+        assert np.array_equal(eob.cpu().numpy().view(np.uint16), reob)
+    # skip_block: everything zero, eob 0
+    q, dq, eob = dsp.quantize_b(dev(co), qrow, dev(iscan), log_scale, skip_block=1)
+    assert not q.any() and not dq.any() and not eob.any()
+
+
+@pytest.mark.parametrize("w,h", [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (24, 16), (48, 32), (8, 32), (64, 16)])
+def test_sad_sse_residual(dsp, w, h):
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(w * 100 + h)
+    n = 19
+    a = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+    b = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+    a[0] = 255; b[0] = 0
+    b[1] = a[1]
+    sad = dsp.sad(dev(a), dev(b)).cpu().numpy().view(np.uint32)
+    sse = dsp.sse(dev(a), dev(b)).cpu().numpy().view(np.uint64)
+    res = dsp.residual(dev(a), dev(b)).cpu().numpy()
+    for i in range(n):
+        assert int(sad[i]) == O.svt_oracle_sad(ptr(a[i]), w, ptr(b[i]), w, h, w)
+        assert int(sse[i]) == O.svt_oracle_sse(ptr(a[i]), w, ptr(b[i]), w, w, h)
+    assert np.array_equal(res, a.astype(np.int16) - b.astype(np.int16))
+
+
+@pytest.mark.parametrize("w,h,sw,sh", [(16, 16, 8, 8), (16, 16, 1, 1), (8, 8, 16, 7), (32, 32, 13, 5), (64, 64, 9, 9),
+                                       (4, 4, 8, 8), (24, 24, 8, 4), (48, 48, 5, 3), (16, 8, 32, 20)])
+def test_sad_search(dsp, w, h, sw, sh):
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(w + 7 * sw)
+    n = 23
+    rw, rh = w + sw - 1, h + sh - 1
+    src = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+    ref = rng.integers(0, 256, size=(n, rh, rw), dtype=np.uint8)
+    # ties: constant planes (every candidate equal -> (0,0)), exact duplicates at two places
+    ref[0] = 7; src[0] = 9
+    if sw > 3 and sh > 2:
+        ref[1, 2:2 + h, 3:3 + w] = src[1]
+        ref[2, 0:h, 1:1 + w] = src[2]; ref[2, 1:1 + h, 0:w] = src[2]
+    best, x, y = dsp.sad_search(dev(src), dev(ref), sw, sh)
+    best = best.cpu().numpy(); x = x.cpu().numpy(); y = y.cpu().numpy()
+    for i in range(n):
+        rb = np.zeros(1, np.uint64); rx = np.zeros(1, np.int16); ry = np.zeros(1, np.int16)
+        O.svt_oracle_sad_loop(ptr(src[i]), w, ptr(ref[i]), rw, h, w, ptr(rb), ptr(rx), ptr(ry), rw,
+                              ctypes.c_int16(sw), ctypes.c_int16(sh))
+        assert (int(best[i]), int(x[i]), int(y[i])) == (int(rb[0]), int(rx[0]), int(ry[0])), f"block {i}"
