@@ -1,12 +1,10 @@
-"""Build everything native, in-tree:
+"""Build the product in-tree:
 
-  cidana-svt-av1_amd/libsvt_hip_dsp.so   the product: HIP kernels + C ABI (gfx950)
-  oracle/libsvt_oracle.so                CPU checker (test infrastructure)
-  oracle/_ref/libsvtref.so               reference sources compiled as-is, only
-                                         when /root/reference is present
+  cidana-svt-av1_amd/libsvt_hip_dsp.so   HIP kernels + C ABI, gfx950 only
 
 hipcc cross-compiles gfx950 without a GPU.  Nothing is installed outside the
-repo; the .so files are git-ignored but travel with the gpurun snapshot.
+repo; the .so is git-ignored but travels with the gpurun snapshot.  (The CPU
+checkers are test infrastructure and are built by __graft_entry__.build().)
 """
 import os
 import subprocess
@@ -44,17 +42,8 @@ def build_product(force=False, verbose=True):
     return LIB
 
 
-def build_oracle(verbose=True):
-    odir = os.path.join(ROOT, "oracle")
-    out = None if verbose else subprocess.DEVNULL
-    subprocess.check_call(["make", "-C", odir, "oracle"], stdout=out)
-    if os.path.exists("/root/reference/Source/Lib/Common/Codec/EbTransforms.c"):
-        subprocess.check_call(["make", "-C", odir, "-j8", "ref"], stdout=out)
-
-
 def build_all(force=False, verbose=True):
-    build_product(force=force, verbose=verbose)
-    build_oracle(verbose=verbose)
+    return build_product(force=force, verbose=verbose)
 
 
 if __name__ == "__main__":

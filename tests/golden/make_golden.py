@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE:
+the reference's own C (and, where it exists, AVX2) kernels compiled from
+/root/reference into oracle/_ref/libsvtref.so (oracle/Makefile) are called through
+ctypes on seeded inputs; inputs and the reference's outputs are stored as
+compressed .npz files.  The fixtures are data only (no reference source text).
+
+The reference holds no stored vectors for this path: its pins are
+the procedures of FwdTxfm2dAsmTest / InvTxfm2dAsmTest / QuantizeTest, which is
+what the input recipes below follow (uniform +-(2^bd - 1) residuals, coefficients
+from the forward transform, coefficients in +-2^(7+bd), q sweep).  SAD / SSE /
+residual / intra have no reference unit test at all; their fixtures are the
+outputs of the reference's scalar C functions.
+
+Run here (needs /root/reference):   python tests/golden/make_golden.py
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from svtlibs import TX_H, TX_SIZES, TX_TYPES, TX_W, ptr, ref, txfm_allowed  # noqa: E402
+
+c_int = ctypes.c_int
+R = ref()
+assert R is not None, "oracle/_ref/libsvtref.so missing: run `make -C oracle ref`"
+
+
+def fwd_name(s):
+    w, h = TX_W[s], TX_H[s]
+    return f"Av1TransformTwoD_{w}x{h}_c" if w == h else f"av1_fwd_txfm2d_{w}x{h}_c"
+
+
+def ref_fwd(s, t, bd, x):
+    w, h = TX_W[s], TX_H[s]
+    o = np.zeros(w * h, np.int32)
+    getattr(R, fwd_name(s))(ptr(x), ptr(o), ctypes.c_uint32(x.shape[1]), c_int(t), ctypes.c_uint8(bd))
+    return o
+
+
+SQ = {0, 1, 2, 3, 4}
+NO_EOB = {5, 6, 13, 14}
+
+
+def ref_inv(s, t, bd, co, dst):
+    w, h = TX_W[s], TX_H[s]
+    f = getattr(R, f"av1_inv_txfm2d_add_{w}x{h}_c")
+    stride = dst.shape[1]
+    if s in SQ:
+        f(ptr(co), ptr(dst), c_int(stride), c_int(t), c_int(bd))
+    elif s in NO_EOB:
+        f(ptr(co), ptr(dst), c_int(stride), c_int(t), c_int(s), c_int(bd))
+    else:
+        f(ptr(co), ptr(dst), c_int(stride), c_int(t), c_int(s), c_int(len(co)), c_int(bd))
+
+
+def pack64(co, s):
+    w, h = TX_W[s], TX_H[s]
+    kw, kh = min(w, 32), min(h, 32)
+    return np.ascontiguousarray(co.reshape(h, w)[:kh, :kw]).reshape(-1)
+
+
+def gen_txfm():
+    rng = np.random.default_rng(13596)
+    fw = {}
+    iv = {}
+    for s in range(19):
+        w, h = TX_W[s], TX_H[s]
+        kw, kh = min(w, 32), min(h, 32)
+        for t in range(16):
+            if not txfm_allowed(s, t):
+                continue
+            for bd in (8, 10):
+                m = (1 << bd) - 1
+                xs = [rng.integers(-m, m + 1, size=(h, w)).astype(np.int16),
+                      np.full((h, w), m, np.int16),
+                      (np.indices((h, w)).sum(0) % 2 * 2 * m - m).astype(np.int16)]
+                xin = np.stack(xs)
+                out = np.stack([ref_fwd(s, t, bd, x) for x in xs])
+                key = f"{s}_{t}_{bd}"
+                fw[key + "_in"] = xin
+                fw[key + "_out"] = out
+                # inverse: coefficients of the forward transform (packed), eob-truncated variant, random dst
+                cos = [pack64(out[0], s), pack64(out[2], s)]
+                tr = cos[0].copy(); tr[max(1, len(tr) // 5):] = 0
+                cos.append(tr)
+                cos = np.stack(cos).astype(np.int32)
+                dst0 = rng.integers(0, 1 << bd, size=(3, h, w)).astype(np.uint16)
+                dst1 = dst0.copy()
+                for i in range(3):
+                    ref_inv(s, t, bd, cos[i], dst1[i])
+                iv[key + "_coeff"] = cos
+                iv[key + "_dst_in"] = dst0
+                iv[key + "_dst_out"] = dst1
+    np.savez_compressed(os.path.join(HERE, "fwd_txfm2d.npz"), **fw)
+    np.savez_compressed(os.path.join(HERE, "inv_txfm2d_add.npz"), **iv)
+
+
+def gen_tables():
+    d = {}
+    for s in range(19):
+        n = min(TX_W[s], 32) * min(TX_H[s], 32)
+        for t in range(16):
+            d[f"scan_{s}_{t}"] = np.ctypeslib.as_array(R.ref_get_scan(s, t, 0), shape=(n,)).copy()
+            d[f"iscan_{s}_{t}"] = np.ctypeslib.as_array(R.ref_get_scan(s, t, 1), shape=(n,)).copy()
+    for bd in (8, 10, 12):
+        q = np.zeros((18, 256, 8), np.int16)
+        dq = np.zeros((6, 256, 8), np.int16)
+        R.av1_build_quantizer(c_int(bd), 0, 0, 0, 0, 0, ptr(q), ptr(dq))   # y tables: Quants fields 0..3, Dequants 0
+        d[f"quant_{bd}"] = q[0]; d[f"quant_shift_{bd}"] = q[1]; d[f"zbin_{bd}"] = q[2]; d[f"round_{bd}"] = q[3]
+        d[f"dequant_{bd}"] = dq[0]
+    cos = (ctypes.c_int32 * (7 * 64)).in_dll(R, "av1_cospi_arr_data")
+    d["cospi"] = np.array(cos[:], np.int32).reshape(7, 64)
+    sin = (ctypes.c_int32 * (7 * 5)).in_dll(R, "av1_sinpi_arr_data")
+    d["sinpi"] = np.array(sin[:], np.int32).reshape(7, 5)
+    np.savez_compressed(os.path.join(HERE, "tables.npz"), **d)
+    return d
+
+
+QNAMES = {0: ("aom_highbd_quantize_b_c", "aom_quantize_b_c_II", "aom_highbd_quantize_b_avx2"),
+          1: ("aom_highbd_quantize_b_32x32_c", "aom_quantize_b_32x32_c_II", "aom_highbd_quantize_b_32x32_avx2"),
+          2: ("aom_highbd_quantize_b_64x64_c", "aom_quantize_b_64x64_c_II", "aom_highbd_quantize_b_64x64_avx2")}
+
+
+def gen_quant(tabs):
+    rng = np.random.default_rng(13597)
+    d = {}
+    for s, ls in ((0, 0), (2, 0), (3, 1), (4, 2)):
+        n = min(TX_W[s], 32) * min(TX_H[s], 32)
+        sc, isc = tabs[f"scan_{s}_0"], tabs[f"iscan_{s}_0"]
+        for bd in (8, 10):
+            for q in (0, 1, 100, 255):
+                kinds = {"uniform": rng.integers(-(1 << (7 + bd)), (1 << (7 + bd)) + 1, size=n),
+                         "sparse": np.where(rng.random(n) < 0.9, 0, rng.integers(-3000, 3001, size=n)),
+                         "small": rng.integers(-30, 31, size=n),
+                         "dc": np.r_[rng.integers(-30000, 30001), np.zeros(n - 1, int)],
+                         "zero": np.zeros(n, int)}
+                for kname, co in kinds.items():
+                    co = np.ascontiguousarray(co.astype(np.int32))
+                    rows = [np.ascontiguousarray(tabs[f"{k}_{bd}"][q]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
+                    key = f"{s}_{bd}_{q}_{kname}"
+                    d[key + "_coeff"] = co
+                    for vi, fn in enumerate(QNAMES[ls]):
+                        qc = np.zeros(n, np.int32); dqc = np.zeros(n, np.int32); eob = np.zeros(1, np.uint16)
+                        getattr(R, fn)(ptr(co), ctypes.c_ssize_t(n), c_int(0), ptr(rows[0]), ptr(rows[1]), ptr(rows[2]),
+                                       ptr(rows[3]), ptr(qc), ptr(dqc), ptr(rows[4]), ptr(eob), ptr(sc), ptr(isc))
+                        tag = ("hbd", "cII", "avx2")[vi]
+                        if tag == "avx2":   # production path must equal the highbd C path
+                            assert np.array_equal(qc, d[key + "_q_hbd"]) and np.array_equal(dqc, d[key + "_dq_hbd"]) and eob[0] == d[key + "_eob_hbd"][0], key
+                            continue
+                        d[key + "_q_" + tag] = qc; d[key + "_dq_" + tag] = dqc; d[key + "_eob_" + tag] = eob
+    np.savez_compressed(os.path.join(HERE, "quantize_b.npz"), **d)
+
+
+def gen_pixel():
+    rng = np.random.default_rng(13598)
+    d = {}
+    R.fast_loop_nx_m_sad_kernel.restype = ctypes.c_uint32
+    R.spatial_full_distortion_kernel.restype = ctypes.c_uint64
+    for (w, h) in ((4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (24, 16), (48, 64), (8, 32), (64, 16)):
+        a = rng.integers(0, 256, size=(4, h, w), dtype=np.uint8)
+        b = rng.integers(0, 256, size=(4, h, w), dtype=np.uint8)
+        a[0] = 255; b[0] = 0; b[1] = a[1]
+        sad = np.array([R.fast_loop_nx_m_sad_kernel(ptr(a[i]), w, ptr(b[i]), w, h, w) for i in range(4)], np.uint32)
+        sse = np.array([R.spatial_full_distortion_kernel(ptr(a[i]), w, ptr(b[i]), w, w, h) for i in range(4)], np.uint64)
+        res = np.zeros((4, h, w), np.int16)
+        for i in range(4):
+            R.residual_kernel_c(ptr(a[i]), w, ptr(b[i]), w, ptr(res[i]), w, w, h)
+        k = f"{w}x{h}"
+        d[k + "_a"] = a; d[k + "_b"] = b; d[k + "_sad"] = sad; d[k + "_sse"] = sse; d[k + "_res"] = res
+    # sad_loop_kernel: incl. ties, constant planes, 1x1 search, leftover widths
+    for (w, h, sw, sh) in ((16, 16, 8, 8), (16, 16, 1, 1), (8, 8, 16, 7), (32, 32, 13, 5), (64, 64, 9, 9), (4, 4, 8, 8)):
+        n = 6
+        rw, rh = w + sw - 1, h + sh - 1
+        src = rng.integers(0, 256, size=(n, h, w), dtype=np.uint8)
+        rf = rng.integers(0, 256, size=(n, rh, rw), dtype=np.uint8)
+        rf[0] = 7; src[0] = 9
+        if sw > 3 and sh > 2:
+            rf[1, 2:2 + h, 3:3 + w] = src[1]
+            rf[2, 0:h, 1:1 + w] = src[2]; rf[2, 1:1 + h, 0:w] = src[2]
+        best = np.zeros(n, np.uint64); xs = np.zeros(n, np.int16); ys = np.zeros(n, np.int16)
+        for i in range(n):
+            R.sad_loop_kernel(ptr(src[i]), w, ptr(rf[i]), rw, h, w, ptr(best[i:i + 1]), ptr(xs[i:i + 1]), ptr(ys[i:i + 1]),
+                              rw, ctypes.c_int16(sw), ctypes.c_int16(sh))
+            # the production AVX2 kernel must agree wherever it is defined (w in {8,16,24,32,48,64}).
+            # Its 4-wide path returns different SADs from the scalar C kernel on the same
+            # inputs (probed here: 200/200 trials differ, an exact copy scores 360 not 0), so
+            # w = 4 is pinned by the scalar C function alone - recorded in DESIGN.md.
+            if w == 4:
+                continue
+            b2 = np.zeros(1, np.uint64); x2 = np.zeros(1, np.int16); y2 = np.zeros(1, np.int16)
+            R.sad_loop_kernel_avx2_intrin(ptr(src[i]), w, ptr(rf[i]), rw, h, w, ptr(b2), ptr(x2), ptr(y2), rw,
+                                          ctypes.c_int16(sw), ctypes.c_int16(sh))
+            assert (best[i], xs[i], ys[i]) == (b2[0], x2[0], y2[0]), (w, h, sw, sh, i)
+        k = f"loop_{w}x{h}_{sw}x{sh}"
+        d[k + "_src"] = src; d[k + "_ref"] = rf; d[k + "_best"] = best; d[k + "_x"] = xs; d[k + "_y"] = ys
+    np.savez_compressed(os.path.join(HERE, "pixel.npz"), **d)
+
+
+if __name__ == "__main__":
+    gen_txfm()
+    tabs = gen_tables()
+    gen_quant(tabs)
+    gen_pixel()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,117 @@
+"""CPU: the oracle (oracle/libsvt_oracle.so) against the committed golden
+fixtures, which are outputs of the reference's own kernels (tests/golden/
+make_golden.py).  This is what pins the oracle when /root/reference is absent."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import svtlibs
+from svtlibs import TX_H, TX_SIZES, TX_TYPES, TX_W, ptr, txfm_allowed
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def tabs():
+    return np.load(os.path.join(G, "tables.npz"))
+
+
+def test_scan_tables(tabs):
+    for s in range(19):
+        for t in range(16):
+            sc, isc = svtlibs.scan_tables(s, t)
+            assert np.array_equal(sc, tabs[f"scan_{s}_{t}"]), (TX_SIZES[s], TX_TYPES[t])
+            assert np.array_equal(isc, tabs[f"iscan_{s}_{t}"]), (TX_SIZES[s], TX_TYPES[t])
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_quantizer_tables(tabs, bd):
+    t = svtlibs.quant_tables(bd)
+    for k in ("zbin", "round", "quant", "quant_shift", "dequant"):
+        assert np.array_equal(t[k], tabs[f"{k}_{bd}"]), k
+
+
+def test_fwd_txfm2d_golden():
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "fwd_txfm2d.npz"))
+    n = 0
+    for s in range(19):
+        w, h = TX_W[s], TX_H[s]
+        for t in range(16):
+            if not txfm_allowed(s, t):
+                continue
+            for bd in (8, 10):
+                xin, out = g[f"{s}_{t}_{bd}_in"], g[f"{s}_{t}_{bd}_out"]
+                for i in range(xin.shape[0]):
+                    x = np.ascontiguousarray(xin[i]); o = np.zeros(w * h, np.int32)
+                    O.svt_oracle_fwd_txfm2d(ptr(x), ptr(o), ctypes.c_uint32(w), t, s, bd)
+                    assert np.array_equal(o, out[i]), (TX_SIZES[s], TX_TYPES[t], bd, i)
+                    n += 1
+    assert n == 954
+
+
+def test_inv_txfm2d_add_golden():
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "inv_txfm2d_add.npz"))
+    for s in range(19):
+        w = TX_W[s]
+        for t in range(16):
+            if not txfm_allowed(s, t):
+                continue
+            for bd in (8, 10):
+                co, d0, d1 = (g[f"{s}_{t}_{bd}_{k}"] for k in ("coeff", "dst_in", "dst_out"))
+                for i in range(co.shape[0]):
+                    d = np.ascontiguousarray(d0[i])
+                    O.svt_oracle_inv_txfm2d_add(ptr(np.ascontiguousarray(co[i])), ptr(d), w, t, s, bd)
+                    assert np.array_equal(d, d1[i]), (TX_SIZES[s], TX_TYPES[t], bd, i)
+
+
+def test_quantize_b_golden(tabs):
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "quantize_b.npz"))
+    cases = 0
+    for s, ls in ((0, 0), (2, 0), (3, 1), (4, 2)):
+        sc, isc = tabs[f"scan_{s}_0"], tabs[f"iscan_{s}_0"]
+        n = len(sc)
+        for bd in (8, 10):
+            for q in (0, 1, 100, 255):
+                rows = [np.ascontiguousarray(tabs[f"{k}_{bd}"][q]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
+                for kind in ("uniform", "sparse", "small", "dc", "zero"):
+                    key = f"{s}_{bd}_{q}_{kind}"
+                    co = np.ascontiguousarray(g[key + "_coeff"])
+                    for variant, tag in ((0, "hbd"), (1, "cII")):
+                        qc = np.zeros(n, np.int32); dqc = np.zeros(n, np.int32); eob = np.zeros(1, np.uint16)
+                        O.svt_oracle_quantize_b(ptr(co), ctypes.c_ssize_t(n), 0, ptr(rows[0]), ptr(rows[1]), ptr(rows[2]),
+                                                ptr(rows[3]), ptr(qc), ptr(dqc), ptr(rows[4]), ptr(eob),
+                                                ptr(np.ascontiguousarray(sc)), ptr(np.ascontiguousarray(isc)), ls, variant)
+                        assert np.array_equal(qc, g[f"{key}_q_{tag}"]), (key, tag)
+                        assert np.array_equal(dqc, g[f"{key}_dq_{tag}"]), (key, tag)
+                        assert eob[0] == g[f"{key}_eob_{tag}"][0], (key, tag)
+                        cases += 1
+    assert cases == 4 * 2 * 4 * 5 * 2
+
+
+def test_pixel_golden():
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "pixel.npz"))
+    for (w, h) in ((4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (24, 16), (48, 64), (8, 32), (64, 16)):
+        k = f"{w}x{h}"
+        a, b = g[k + "_a"], g[k + "_b"]
+        for i in range(a.shape[0]):
+            ai, bi = np.ascontiguousarray(a[i]), np.ascontiguousarray(b[i])
+            assert O.svt_oracle_sad(ptr(ai), w, ptr(bi), w, h, w) == int(g[k + "_sad"][i])
+            assert O.svt_oracle_sse(ptr(ai), w, ptr(bi), w, w, h) == int(g[k + "_sse"][i])
+            r = np.zeros((h, w), np.int16)
+            O.svt_oracle_residual(ptr(ai), w, ptr(bi), w, ptr(r), w, w, h)
+            assert np.array_equal(r, g[k + "_res"][i])
+    for (w, h, sw, sh) in ((16, 16, 8, 8), (16, 16, 1, 1), (8, 8, 16, 7), (32, 32, 13, 5), (64, 64, 9, 9), (4, 4, 8, 8)):
+        k = f"loop_{w}x{h}_{sw}x{sh}"
+        src, rf = g[k + "_src"], g[k + "_ref"]
+        rw = w + sw - 1
+        for i in range(src.shape[0]):
+            b = np.zeros(1, np.uint64); x = np.zeros(1, np.int16); y = np.zeros(1, np.int16)
+            O.svt_oracle_sad_loop(ptr(np.ascontiguousarray(src[i])), w, ptr(np.ascontiguousarray(rf[i])), rw, h, w,
+                                  ptr(b), ptr(x), ptr(y), rw, ctypes.c_int16(sw), ctypes.c_int16(sh))
+            assert (int(b[0]), int(x[0]), int(y[0])) == (int(g[k + "_best"][i]), int(g[k + "_x"][i]), int(g[k + "_y"][i])), (k, i)
