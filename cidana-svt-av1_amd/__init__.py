@@ -70,9 +70,12 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_sad_search_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_uint32, c_size_t,
                                            c_uint32, c_uint32, c_int16, c_int16, c_void_p, c_void_p, c_void_p, c_size_t,
                                            c_void_p]
-    if hasattr(L, "svt_hip_intra_pred_batch"):
-        L.svt_hip_intra_pred_batch.argtypes = [c_void_p, c_int32, c_size_t, c_void_p, c_void_p, c_int32, c_int, c_int,
-                                               c_int, c_int, c_int, c_size_t, c_void_p]
+    L.svt_hip_intra_pred_batch.argtypes = [c_void_p, c_int32, c_size_t, c_void_p, c_void_p, c_void_p, c_int32, c_int,
+                                           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_size_t, c_void_p]
+    L.svt_hip_filter_intra_edge_batch.argtypes = [c_void_p, c_int32, c_int, c_int, c_int, c_size_t, c_void_p]
+    L.svt_hip_upsample_intra_edge_batch.argtypes = [c_void_p, c_int32, c_int, c_int, c_int, c_size_t, c_void_p]
+    L.svt_hip_full_distortion32_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t, c_uint32,
+                                                  c_uint32, c_int, c_void_p, c_size_t, c_void_p]
     return L
 
 
@@ -226,3 +229,48 @@ class SvtHipDsp:
                                                        search_w, search_h, self._p(best), self._p(x), self._p(y), n,
                                                        self._stream()), "svt_hip_sad_search_batch")
         return best, x, y
+
+    # -- K7 coefficient domain ---------------------------------------------------------
+    def full_distortion32(self, coeff, recon, width, height, cbf_zero=False):
+        """coeff, recon: int32 [n, height, width] dense -> int64 [n, 2] (uint64 values)"""
+        t = self.torch
+        n = coeff.shape[0]
+        out = t.zeros((n, 2), dtype=t.int64, device=coeff.device)
+        self._check(self.lib.svt_hip_full_distortion32_batch(self._p(coeff), width, width * height,
+                                                              self._p(recon) if recon is not None else None, width,
+                                                              width * height, width, height, 1 if cbf_zero else 0,
+                                                              self._p(out), n, self._stream()),
+                    "svt_hip_full_distortion32_batch")
+        return out
+
+    # -- K9 / K10 ------------------------------------------------------------------------
+    NB_ORIGIN = 16
+
+    def intra_pred(self, above, left, mode, bw, bh, bd=8, up_above=0, up_left=0, dx=1, dy=1, out=None):
+        """above, left: [n, nb_pitch] uint8 or int16(as uint16) neighbour rows (position p at NB_ORIGIN + p).
+        -> [n, bh, bw] prediction"""
+        t = self.torch
+        n, pitch = above.shape
+        is16 = 0 if above.dtype == t.uint8 else 1
+        if out is None:
+            out = t.empty((n, bh, bw), dtype=above.dtype, device=above.device)
+        self._check(self.lib.svt_hip_intra_pred_batch(self._p(out), bw, bw * bh, None, self._p(above), self._p(left), pitch,
+                                                       mode, bw, bh, up_above, up_left, dx, dy, is16, bd, n,
+                                                       self._stream()), "svt_hip_intra_pred_batch")
+        return out
+
+    def filter_intra_edge(self, edges, sz, strength):
+        t = self.torch
+        n, pitch = edges.shape
+        self._check(self.lib.svt_hip_filter_intra_edge_batch(self._p(edges), pitch, sz, strength,
+                                                              0 if edges.dtype == t.uint8 else 1, n, self._stream()),
+                    "svt_hip_filter_intra_edge_batch")
+        return edges
+
+    def upsample_intra_edge(self, edges, sz, bd=8):
+        t = self.torch
+        n, pitch = edges.shape
+        self._check(self.lib.svt_hip_upsample_intra_edge_batch(self._p(edges), pitch, sz,
+                                                                0 if edges.dtype == t.uint8 else 1, bd, n,
+                                                                self._stream()), "svt_hip_upsample_intra_edge_batch")
+        return edges

@@ -13,6 +13,7 @@
 
 #include "../../include/svt_hip_dsp.h"
 #include "kernel_fused32.h"
+#include "kernel_intra.h"
 #include "kernel_pixel.h"
 #include "kernel_txfm.h"
 
@@ -430,6 +431,91 @@ extern "C" int svt_hip_sad_search_batch(const uint8_t* d_src, uint32_t src_strid
     return launch_status("sad_search");
 }
 
+extern "C" int svt_hip_full_distortion32_batch(const int32_t* d_coeff, uint32_t coeff_stride, size_t coeff_block_pitch,
+                                               const int32_t* d_recon, uint32_t recon_stride, size_t recon_block_pitch,
+                                               uint32_t width, uint32_t height, int cbf_zero, uint64_t* d_out,
+                                               size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_coeff || !d_out || (!cbf_zero && !d_recon)) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (width == 0 || height == 0 || width > 128 || height > 128) return set_err(SVT_HIP_ERR_INVALID, "area %ux%u", width, height);
+    hipLaunchKernelGGL(full_distortion32_kernel, dim3((uint32_t)((nblocks + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                       d_coeff, coeff_stride, coeff_block_pitch, d_recon, recon_stride, recon_block_pitch, width, height,
+                       cbf_zero, (unsigned long long*)d_out, (uint32_t)nblocks);
+    return launch_status("full_distortion32");
+}
+
+static bool intra_size_ok(int bw, int bh) {
+    auto ok1 = [](int v) { return v == 4 || v == 8 || v == 16 || v == 32 || v == 64; };
+    if (!ok1(bw) || !ok1(bh)) return false;
+    const int m = bw > bh ? bw : bh, mn = bw < bh ? bw : bh;
+    return m <= 4 * mn;     // the 19 TX sizes
+}
+
+extern "C" int svt_hip_intra_pred_batch(void* d_dst, int32_t dst_stride, size_t dst_block_pitch,
+                                        const uint32_t* d_dst_offsets, const void* d_above, const void* d_left,
+                                        int32_t nb_pitch, int mode, int bw, int bh, int upsample_above,
+                                        int upsample_left, int dx, int dy, int is_16bit, int bd, size_t nblocks,
+                                        void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_dst || !d_above || !d_left) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (mode < 0 || mode >= SVT_INTRA_MODES) return set_err(SVT_HIP_ERR_INVALID, "intra mode %d", mode);
+    if (!intra_size_ok(bw, bh)) return set_err(SVT_HIP_ERR_INVALID, "block %dx%d is not an AV1 transform size", bw, bh);
+    if ((is_16bit && bd != 10 && bd != 12 && bd != 8) || (!is_16bit && bd != 8)) return set_err(SVT_HIP_ERR_INVALID, "bit depth %d", bd);
+    if ((upsample_above | upsample_left) & ~1) return set_err(SVT_HIP_ERR_INVALID, "upsample flags");
+    if (mode >= SVT_INTRA_Z1) {
+        if (dx <= 0 || dy <= 0) return set_err(SVT_HIP_ERR_INVALID, "dx/dy must be positive");
+        const int need = NB_ORIGIN + (((bw + bh) << 1) + 2);
+        if (nb_pitch < need) return set_err(SVT_HIP_ERR_INVALID, "nb_pitch %d < %d", nb_pitch, need);
+    } else if (nb_pitch < NB_ORIGIN + (bw > bh ? bw : bh)) {
+        return set_err(SVT_HIP_ERR_INVALID, "nb_pitch %d too small", nb_pitch);
+    }
+    const int es = is_16bit ? 2 : 1;
+    const int pxl = 16 / es, ppl = bw < pxl ? bw : pxl;
+    const size_t items = (size_t)(bw / ppl) * bh * nblocks;
+    size_t grid = (items + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    hipStream_t s = (hipStream_t)stream;
+    if (is_16bit)
+        hipLaunchKernelGGL((intra_pred_kernel<uint16_t>), dim3((uint32_t)grid), dim3(256), 0, s, (uint16_t*)d_dst, dst_stride,
+                           dst_block_pitch, d_dst_offsets, (const uint16_t*)d_above, (const uint16_t*)d_left, nb_pitch, mode,
+                           bw, bh, upsample_above, upsample_left, dx, dy, bd, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL((intra_pred_kernel<uint8_t>), dim3((uint32_t)grid), dim3(256), 0, s, (uint8_t*)d_dst, dst_stride,
+                           dst_block_pitch, d_dst_offsets, (const uint8_t*)d_above, (const uint8_t*)d_left, nb_pitch, mode,
+                           bw, bh, upsample_above, upsample_left, dx, dy, bd, (uint32_t)nblocks);
+    return launch_status("intra_pred");
+}
+
+extern "C" int svt_hip_filter_intra_edge_batch(void* d_edges, int32_t nb_pitch, int sz, int strength, int is_16bit,
+                                               size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0 || strength == 0) return SVT_HIP_OK;
+    if (!d_edges) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (sz < 1 || sz > 129 || strength < 0 || strength > 3 || nb_pitch < NB_ORIGIN + sz)
+        return set_err(SVT_HIP_ERR_INVALID, "edge sz %d strength %d pitch %d", sz, strength, nb_pitch);
+    hipStream_t s = (hipStream_t)stream;
+    if (is_16bit)
+        hipLaunchKernelGGL((filter_edge_kernel<uint16_t>), dim3((uint32_t)nblocks), dim3(256), 0, s, (uint16_t*)d_edges, nb_pitch, NB_ORIGIN, sz, strength, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL((filter_edge_kernel<uint8_t>), dim3((uint32_t)nblocks), dim3(256), 0, s, (uint8_t*)d_edges, nb_pitch, NB_ORIGIN, sz, strength, (uint32_t)nblocks);
+    return launch_status("filter_intra_edge");
+}
+extern "C" int svt_hip_upsample_intra_edge_batch(void* d_edges, int32_t nb_pitch, int sz, int is_16bit, int bd,
+                                                 size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_edges) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (sz < 1 || sz > 16 || nb_pitch < NB_ORIGIN + 2 * sz) return set_err(SVT_HIP_ERR_INVALID, "upsample sz %d pitch %d", sz, nb_pitch);
+    hipStream_t s = (hipStream_t)stream;
+    if (is_16bit)
+        hipLaunchKernelGGL((upsample_edge_kernel<uint16_t>), dim3((uint32_t)nblocks), dim3(64), 0, s, (uint16_t*)d_edges, nb_pitch, NB_ORIGIN, sz, bd, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL((upsample_edge_kernel<uint8_t>), dim3((uint32_t)nblocks), dim3(64), 0, s, (uint8_t*)d_edges, nb_pitch, NB_ORIGIN, sz, 8, (uint32_t)nblocks);
+    return launch_status("upsample_intra_edge");
+}
+
 // ===========================================================================
 // (A) drop-in entry points: host pointers, one block, synchronous
 // ===========================================================================
@@ -618,6 +704,96 @@ extern "C" void svt_hip_sad_loop_kernel(uint8_t* src, uint32_t src_stride, uint8
     HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
     *x_search_center = xy[0];
     *y_search_center = xy[1];
+}
+
+static void dropin_dist32(int cbf_zero, int32_t* coeff, uint32_t cs, int32_t* recon, uint32_t rs, uint64_t out[2],
+                          uint32_t w, uint32_t h, const char* fn) {
+    const size_t bb = align256((size_t)w * h * 4);
+    DROPIN_TRY(t_ctx.ensure(2 * bb + 256), fn);
+    int32_t* d_c = (int32_t*)t_ctx.dbuf;
+    int32_t* d_r = (int32_t*)(t_ctx.dbuf + bb);
+    uint64_t* d_o = (uint64_t*)(t_ctx.dbuf + 2 * bb);
+    HIP_DIE(hipMemcpy2DAsync(d_c, (size_t)w * 4, coeff, (size_t)cs * 4, (size_t)w * 4, h, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    if (!cbf_zero)
+        HIP_DIE(hipMemcpy2DAsync(d_r, (size_t)w * 4, recon, (size_t)rs * 4, (size_t)w * 4, h, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_full_distortion32_batch(d_c, w, 0, d_r, w, 0, w, h, cbf_zero, d_o, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(out, d_o, 16, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+extern "C" void svt_hip_full_distortion_kernel32_bits(int32_t* coeff, uint32_t coeff_stride, int32_t* recon_coeff,
+                                                      uint32_t recon_coeff_stride, uint64_t distortion_result[2],
+                                                      uint32_t area_width, uint32_t area_height) {
+    dropin_dist32(0, coeff, coeff_stride, recon_coeff, recon_coeff_stride, distortion_result, area_width, area_height,
+                  "svt_hip_full_distortion_kernel32_bits");
+}
+extern "C" void svt_hip_full_distortion_kernel_cbf_zero32_bits(int32_t* coeff, uint32_t coeff_stride, int32_t* recon_coeff,
+                                                               uint32_t recon_coeff_stride, uint64_t distortion_result[2],
+                                                               uint32_t area_width, uint32_t area_height) {
+    dropin_dist32(1, coeff, coeff_stride, recon_coeff, recon_coeff_stride, distortion_result, area_width, area_height,
+                  "svt_hip_full_distortion_kernel_cbf_zero32_bits");
+}
+
+// one intra block: stage [lo, hi) of above / left around the origin, predict, copy the block back
+static void dropin_intra(int mode, int bw, int bh, void* dst, ptrdiff_t stride, const void* above, const void* left,
+                         int a_lo, int a_hi, int l_lo, int l_hi, int ua, int ul, int dx, int dy, int is16, int bd,
+                         const char* fn) {
+    const size_t es = is16 ? 2 : 1;
+    const int pitch = NB_ORIGIN + 2 * (bw + bh) + 16;
+    const size_t nb_b = align256((size_t)pitch * es), px_b = (size_t)bw * bh * es;
+    DROPIN_TRY(t_ctx.ensure(2 * nb_b + px_b), fn);
+    char* d_a = t_ctx.dbuf;
+    char* d_l = t_ctx.dbuf + nb_b;
+    char* d_px = t_ctx.dbuf + 2 * nb_b;
+    HIP_DIE(hipMemsetAsync(d_a, 0, 2 * nb_b, t_ctx.stream), fn);
+    if (a_hi > a_lo)
+        HIP_DIE(hipMemcpyAsync(d_a + (size_t)(NB_ORIGIN + a_lo) * es, (const char*)above + (ptrdiff_t)a_lo * (ptrdiff_t)es,
+                               (size_t)(a_hi - a_lo) * es, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    if (l_hi > l_lo)
+        HIP_DIE(hipMemcpyAsync(d_l + (size_t)(NB_ORIGIN + l_lo) * es, (const char*)left + (ptrdiff_t)l_lo * (ptrdiff_t)es,
+                               (size_t)(l_hi - l_lo) * es, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_intra_pred_batch(d_px, bw, (size_t)bw * bh, nullptr, d_a, d_l, pitch, mode, bw, bh, ua, ul, dx, dy,
+                                        is16, bd, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpy2DAsync(dst, (size_t)stride * es, d_px, (size_t)bw * es, (size_t)bw * es, bh, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+extern "C" void svt_hip_intra_predictor(int mode, int bw, int bh, uint8_t* dst, ptrdiff_t stride, const uint8_t* above,
+                                        const uint8_t* left) {
+    dropin_intra(mode, bw, bh, dst, stride, above, left, -1, bw, 0, bh, 0, 0, 1, 1, 0, 8, "svt_hip_intra_predictor");
+}
+extern "C" void svt_hip_highbd_intra_predictor(int mode, int bw, int bh, uint16_t* dst, ptrdiff_t stride,
+                                               const uint16_t* above, const uint16_t* left, int32_t bd) {
+    dropin_intra(mode, bw, bh, dst, stride, above, left, -1, bw, 0, bh, 0, 0, 1, 1, 1, bd, "svt_hip_highbd_intra_predictor");
+}
+#define DR_RANGES_Z1 0, (((bw + bh - 1) << upsample_above) + 2), 0, 0
+#define DR_RANGES_Z3 0, 0, 0, (((bw + bh - 1) << upsample_left) + 2)
+#define DR_RANGES_Z2 -(1 << upsample_above), (((bw - 1) << upsample_above) + 2), -(1 << upsample_left), (((bh - 1) << upsample_left) + 2)
+extern "C" void svt_hip_av1_dr_prediction_z1(uint8_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t* above,
+                                             const uint8_t* left, int32_t upsample_above, int32_t dx, int32_t dy) {
+    dropin_intra(SVT_INTRA_Z1, bw, bh, dst, stride, above, left, DR_RANGES_Z1, upsample_above, 0, dx, dy, 0, 8, "svt_hip_av1_dr_prediction_z1");
+}
+extern "C" void svt_hip_av1_dr_prediction_z2(uint8_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t* above,
+                                             const uint8_t* left, int32_t upsample_above, int32_t upsample_left,
+                                             int32_t dx, int32_t dy) {
+    dropin_intra(SVT_INTRA_Z2, bw, bh, dst, stride, above, left, DR_RANGES_Z2, upsample_above, upsample_left, dx, dy, 0, 8, "svt_hip_av1_dr_prediction_z2");
+}
+extern "C" void svt_hip_av1_dr_prediction_z3(uint8_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t* above,
+                                             const uint8_t* left, int32_t upsample_left, int32_t dx, int32_t dy) {
+    dropin_intra(SVT_INTRA_Z3, bw, bh, dst, stride, above, left, DR_RANGES_Z3, 0, upsample_left, dx, dy, 0, 8, "svt_hip_av1_dr_prediction_z3");
+}
+extern "C" void svt_hip_av1_highbd_dr_prediction_z1(uint16_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh,
+                                                    const uint16_t* above, const uint16_t* left, int32_t upsample_above,
+                                                    int32_t dx, int32_t dy, int32_t bd) {
+    dropin_intra(SVT_INTRA_Z1, bw, bh, dst, stride, above, left, DR_RANGES_Z1, upsample_above, 0, dx, dy, 1, bd, "svt_hip_av1_highbd_dr_prediction_z1");
+}
+extern "C" void svt_hip_av1_highbd_dr_prediction_z2(uint16_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh,
+                                                    const uint16_t* above, const uint16_t* left, int32_t upsample_above,
+                                                    int32_t upsample_left, int32_t dx, int32_t dy, int32_t bd) {
+    dropin_intra(SVT_INTRA_Z2, bw, bh, dst, stride, above, left, DR_RANGES_Z2, upsample_above, upsample_left, dx, dy, 1, bd, "svt_hip_av1_highbd_dr_prediction_z2");
+}
+extern "C" void svt_hip_av1_highbd_dr_prediction_z3(uint16_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh,
+                                                    const uint16_t* above, const uint16_t* left, int32_t upsample_left,
+                                                    int32_t dx, int32_t dy, int32_t bd) {
+    dropin_intra(SVT_INTRA_Z3, bw, bh, dst, stride, above, left, DR_RANGES_Z3, 0, upsample_left, dx, dy, 1, bd, "svt_hip_av1_highbd_dr_prediction_z3");
 }
 
 extern "C" int svt_hip_rtcd_override(const svt_hip_rtcd_table* t) {

@@ -172,6 +172,42 @@ int svt_hip_sad_search_batch(const uint8_t *d_src, uint32_t src_stride, size_t s
                              uint64_t *d_best_sad, int16_t *d_x, int16_t *d_y, size_t nblocks,
                              void *stream);
 
+/* K7 coefficient-domain distortion (full_distortion_kernel32_bits_func_ptr_array /
+ * full_distortion_kernel_cbf_zero32_bits_func_ptr_array, EbPictureOperators.h:268-280;
+ * C: EbPictureOperators.c:283-346).  d_out: uint64[nblocks][2] =
+ * {DIST_CALC_RESIDUAL, DIST_CALC_PREDICTION}.  cbf_zero: d_recon is ignored. */
+int svt_hip_full_distortion32_batch(const int32_t *d_coeff, uint32_t coeff_stride,
+                                    size_t coeff_block_pitch, const int32_t *d_recon,
+                                    uint32_t recon_stride, size_t recon_block_pitch,
+                                    uint32_t width, uint32_t height, int cbf_zero,
+                                    uint64_t *d_out, size_t nblocks, void *stream);
+
+/* K9/K10 intra prediction.  Replaces the aom_{dc,...,paeth}_predictor_WxH /
+ * aom_highbd_* slots (aom_dsp_rtcd.h:442-1262, 1626-2330; C: EbIntraPrediction.c:
+ * 1838-2260) and av1_dr_prediction_z{1,2,3} / av1_highbd_dr_prediction_z*
+ * (aom_dsp_rtcd.h:2340; C: EbIntraPrediction.c:370-477, 3394-3506).
+ * Neighbours: d_above / d_left hold one row of `nb_pitch` samples per block; the
+ * reference's above_row[p] / left_col[p] (p >= -2) is element SVT_HIP_NB_ORIGIN + p.
+ * Samples are uint8 (is_16bit = 0, bd = 8) or uint16.  mode: SVT_INTRA_*; for the
+ * directional modes dx, dy, upsample_above, upsample_left are the reference's
+ * arguments (dr_intra_derivative based).  Destination addressing as in
+ * svt_hip_inv_txfm2d_add_batch. */
+enum { SVT_INTRA_DC, SVT_INTRA_V, SVT_INTRA_H, SVT_INTRA_SMOOTH, SVT_INTRA_SMOOTH_V, SVT_INTRA_SMOOTH_H,
+       SVT_INTRA_PAETH, SVT_INTRA_DC_TOP, SVT_INTRA_DC_LEFT, SVT_INTRA_DC_128, SVT_INTRA_Z1, SVT_INTRA_Z2,
+       SVT_INTRA_Z3, SVT_INTRA_MODES };
+#define SVT_HIP_NB_ORIGIN 16
+int svt_hip_intra_pred_batch(void *d_dst, int32_t dst_stride, size_t dst_block_pitch,
+                             const uint32_t *d_dst_offsets, const void *d_above, const void *d_left,
+                             int32_t nb_pitch, int mode, int bw, int bh, int upsample_above,
+                             int upsample_left, int dx, int dy, int is_16bit, int bd,
+                             size_t nblocks, void *stream);
+/* av1_filter_intra_edge{,_high} / av1_upsample_intra_edge{,_high} (aom_dsp_rtcd.h:152,
+ * 431; C: EbIntraPrediction.c:3539-3660) on nblocks edges laid out like d_above. */
+int svt_hip_filter_intra_edge_batch(void *d_edges, int32_t nb_pitch, int sz, int strength,
+                                    int is_16bit, size_t nblocks, void *stream);
+int svt_hip_upsample_intra_edge_batch(void *d_edges, int32_t nb_pitch, int sz, int is_16bit,
+                                      int bd, size_t nblocks, void *stream);
+
 /* ============================================================================
  * (A) drop-in entry points — reference signatures, HOST pointers, synchronous.
  * ==========================================================================*/
@@ -242,6 +278,40 @@ uint64_t svt_hip_spatial_full_distortion_kernel(uint8_t *input, uint32_t input_s
 void svt_hip_residual_kernel(uint8_t *input, uint32_t input_stride, uint8_t *pred, uint32_t pred_stride,
                              int16_t *residual, uint32_t residual_stride, uint32_t area_width,
                              uint32_t area_height);
+
+/* full_distortion_kernel32_bits / _cbf_zero32_bits (EbPictureOperators.h:268-280) */
+void svt_hip_full_distortion_kernel32_bits(int32_t *coeff, uint32_t coeff_stride, int32_t *recon_coeff,
+                                           uint32_t recon_coeff_stride, uint64_t distortion_result[2],
+                                           uint32_t area_width, uint32_t area_height);
+void svt_hip_full_distortion_kernel_cbf_zero32_bits(int32_t *coeff, uint32_t coeff_stride,
+                                                    int32_t *recon_coeff, uint32_t recon_coeff_stride,
+                                                    uint64_t distortion_result[2], uint32_t area_width,
+                                                    uint32_t area_height);
+
+/* intra_pred_fn / intra_high_pred_fn (EbIntraPrediction.h:36-41): one entry per mode;
+ * the per-size RTCD slots aom_<mode>_predictor_WxH bind to these with W, H fixed
+ * (INTEGRATION.md).  mode = SVT_INTRA_DC .. SVT_INTRA_DC_128. */
+void svt_hip_intra_predictor(int mode, int bw, int bh, uint8_t *dst, ptrdiff_t stride,
+                             const uint8_t *above, const uint8_t *left);
+void svt_hip_highbd_intra_predictor(int mode, int bw, int bh, uint16_t *dst, ptrdiff_t stride,
+                                    const uint16_t *above, const uint16_t *left, int32_t bd);
+/* av1_dr_prediction_z1/z2/z3 and highbd twins (aom_dsp_rtcd.h:2340-2362) */
+void svt_hip_av1_dr_prediction_z1(uint8_t *dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t *above,
+                                  const uint8_t *left, int32_t upsample_above, int32_t dx, int32_t dy);
+void svt_hip_av1_dr_prediction_z2(uint8_t *dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t *above,
+                                  const uint8_t *left, int32_t upsample_above, int32_t upsample_left,
+                                  int32_t dx, int32_t dy);
+void svt_hip_av1_dr_prediction_z3(uint8_t *dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t *above,
+                                  const uint8_t *left, int32_t upsample_left, int32_t dx, int32_t dy);
+void svt_hip_av1_highbd_dr_prediction_z1(uint16_t *dst, ptrdiff_t stride, int32_t bw, int32_t bh,
+                                         const uint16_t *above, const uint16_t *left, int32_t upsample_above,
+                                         int32_t dx, int32_t dy, int32_t bd);
+void svt_hip_av1_highbd_dr_prediction_z2(uint16_t *dst, ptrdiff_t stride, int32_t bw, int32_t bh,
+                                         const uint16_t *above, const uint16_t *left, int32_t upsample_above,
+                                         int32_t upsample_left, int32_t dx, int32_t dy, int32_t bd);
+void svt_hip_av1_highbd_dr_prediction_z3(uint16_t *dst, ptrdiff_t stride, int32_t bw, int32_t bh,
+                                         const uint16_t *above, const uint16_t *left, int32_t upsample_left,
+                                         int32_t dx, int32_t dy, int32_t bd);
 
 /* Pointer table the host fills after the stock setup_rtcd_internal(asm_type)
  * (EbEncHandle.c:917) and BEFORE init_intra_predictors_internal(): each member is

@@ -200,11 +200,58 @@ def gen_pixel():
     np.savez_compressed(os.path.join(HERE, "pixel.npz"), **d)
 
 
+INTRA_NAMES = ["dc", "v", "h", "smooth", "smooth_v", "smooth_h", "paeth", "dc_top", "dc_left", "dc_128"]
+DR_DERIV = {3: 1023, 6: 547, 9: 372, 14: 273, 17: 215, 20: 178, 23: 151, 26: 132, 29: 116, 32: 102, 36: 90, 39: 80,
+            42: 71, 45: 64, 48: 57, 51: 51, 54: 45, 58: 40, 61: 35, 64: 31, 67: 27, 70: 23, 73: 19, 76: 15, 81: 11,
+            84: 7, 87: 3}
+
+
+def gen_intra():
+    """No reference unit test covers intra prediction: the fixtures are the outputs of the
+    reference's scalar C predictors aom_*_predictor_WxH_c / av1_*dr_prediction_z*_c."""
+    rng = np.random.default_rng(13599)
+    d = {}
+    S = ctypes.c_ssize_t
+    for s in range(19):
+        bw, bh = TX_W[s], TX_H[s]
+        for bd in (8, 10):
+            dt = np.uint8 if bd == 8 else np.uint16
+            es = 1 if bd == 8 else 2
+            a = rng.integers(0, 1 << bd, size=304).astype(dt)
+            l = rng.integers(0, 1 << bd, size=304).astype(dt)
+            pa = ctypes.c_void_p(a.ctypes.data + 16 * es); pl = ctypes.c_void_p(l.ctypes.data + 16 * es)
+            key = f"{s}_{bd}"
+            d[key + "_above"] = a; d[key + "_left"] = l
+            for m, name in enumerate(INTRA_NAMES):
+                o = np.zeros((bh, bw), dt)
+                if bd == 8:
+                    getattr(R, f"aom_{name}_predictor_{bw}x{bh}_c")(ptr(o), S(bw), pa, pl)
+                else:
+                    getattr(R, f"aom_highbd_{name}_predictor_{bw}x{bh}_c")(ptr(o), S(bw), pa, pl, c_int(bd))
+                d[f"{key}_m{m}"] = o
+            if s in (0, 1, 2, 3, 5, 8, 9, 16):
+                for zone in (1, 2, 3):
+                    for ang in (3, 23, 45, 67, 87):
+                        for up in ((0, 0), (1, 1)) if bw + bh <= 16 else ((0, 0),):
+                            dx = DR_DERIV[ang] if zone in (1, 2) else 1
+                            dy = DR_DERIV[90 - ang] if zone == 2 else (DR_DERIV[ang] if zone == 3 else 1)
+                            o = np.zeros((bh, bw), dt)
+                            pre = "av1_" if bd == 8 else "av1_highbd_"
+                            f = getattr(R, f"{pre}dr_prediction_z{zone}_c")
+                            args = [ptr(o), S(bw), bw, bh, pa, pl] + ([up[0]] if zone == 1 else [up[1]] if zone == 3 else [up[0], up[1]]) + [dx, dy]
+                            if bd != 8:
+                                args.append(bd)
+                            f(*args)
+                            d[f"{key}_z{zone}_{ang}_{up[0]}{up[1]}"] = o
+    np.savez_compressed(os.path.join(HERE, "intra.npz"), **d)
+
+
 if __name__ == "__main__":
     gen_txfm()
     tabs = gen_tables()
     gen_quant(tabs)
     gen_pixel()
+    gen_intra()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

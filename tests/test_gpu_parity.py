@@ -238,3 +238,123 @@ def test_sad_search(dsp, w, h, sw, sh):
         O.svt_oracle_sad_loop(ptr(src[i]), w, ptr(ref[i]), rw, h, w, ptr(rb), ptr(rx), ptr(ry), rw,
                               ctypes.c_int16(sw), ctypes.c_int16(sh))
         assert (int(best[i]), int(x[i]), int(y[i])) == (int(rb[0]), int(rx[0]), int(ry[0])), f"block {i}"
+
+
+# ---------------------------------------------------------------------------------------
+# intra prediction (no reference unit test exists: SURVEY F5 — oracle is pinned by the
+# reference's scalar C functions, tests/test_oracle_vs_ref.py + tests/golden/intra.npz)
+# ---------------------------------------------------------------------------------------
+NB = 16
+DR_DERIV = {3: 1023, 6: 547, 9: 372, 14: 273, 17: 215, 20: 178, 23: 151, 26: 132, 29: 116, 32: 102, 36: 90, 39: 80,
+            42: 71, 45: 64, 48: 57, 51: 51, 54: 45, 58: 40, 61: 35, 64: 31, 67: 27, 70: 23, 73: 19, 76: 15, 81: 11,
+            84: 7, 87: 3}
+
+
+def _neighbours(rng, n, bd, pitch=304):
+    dt = np.uint8 if bd == 8 else np.uint16
+    a = rng.integers(0, 1 << bd, size=(n, pitch)).astype(dt)
+    l = rng.integers(0, 1 << bd, size=(n, pitch)).astype(dt)
+    a[0] = (1 << bd) - 1; l[0] = 0
+    a[1] = 0; l[1] = (1 << bd) - 1
+    return a, l
+
+
+def _as_dev(a):
+    return dev(a if a.dtype == np.uint8 else a.view(np.int16))
+
+
+@pytest.mark.parametrize("tx_size", range(19))
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_nondirectional(dsp, tx_size, bd):
+    O = svtlibs.oracle()
+    bw, bh = TX_W[tx_size], TX_H[tx_size]
+    rng = np.random.default_rng(tx_size * 13 + bd)
+    n = 9
+    a, l = _neighbours(rng, n, bd)
+    es = a.itemsize
+    for mode in range(10):
+        out = dsp.intra_pred(_as_dev(a), _as_dev(l), mode, bw, bh, bd).cpu().numpy()
+        out = out if bd == 8 else out.view(np.uint16)
+        ref = np.zeros((n, bh, bw), a.dtype)
+        for i in range(n):
+            pa = ctypes.c_void_p(a[i].ctypes.data + NB * es); pl = ctypes.c_void_p(l[i].ctypes.data + NB * es)
+            if bd == 8:
+                O.svt_oracle_intra_pred(mode, ptr(ref[i]), ctypes.c_ssize_t(bw), bw, bh, pa, pl)
+            else:
+                O.svt_oracle_intra_pred_hbd(mode, ptr(ref[i]), ctypes.c_ssize_t(bw), bw, bh, pa, pl, bd)
+        assert np.array_equal(out, ref), (TX_SIZES[tx_size], mode, bd)
+
+
+@pytest.mark.parametrize("tx_size", [0, 1, 2, 3, 4, 5, 6, 8, 9, 13, 14, 16, 17, 18])
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_directional(dsp, tx_size, bd):
+    O = svtlibs.oracle()
+    bw, bh = TX_W[tx_size], TX_H[tx_size]
+    rng = np.random.default_rng(tx_size * 17 + bd)
+    n = 7
+    a, l = _neighbours(rng, n, bd)
+    es = a.itemsize
+    angles = sorted(DR_DERIV)
+    for zone in (1, 2, 3):
+        for ang in angles[::2] + [87]:
+            ups = ((0, 0), (1, 1), (1, 0), (0, 1)) if bw + bh <= 16 else ((0, 0),)
+            for ua, ul in ups:
+                dx = DR_DERIV[ang] if zone in (1, 2) else 1
+                dy = DR_DERIV[90 - ang] if zone == 2 else (DR_DERIV[ang] if zone == 3 else 1)
+                out = dsp.intra_pred(_as_dev(a), _as_dev(l), 9 + zone, bw, bh, bd, ua, ul, dx, dy).cpu().numpy()
+                out = out if bd == 8 else out.view(np.uint16)
+                ref = np.zeros((n, bh, bw), a.dtype)
+                for i in range(n):
+                    pa = ctypes.c_void_p(a[i].ctypes.data + NB * es); pl = ctypes.c_void_p(l[i].ctypes.data + NB * es)
+                    if bd == 8:
+                        O.svt_oracle_dr_prediction(zone, ptr(ref[i]), ctypes.c_ssize_t(bw), bw, bh, pa, pl, ua, ul, dx, dy)
+                    else:
+                        O.svt_oracle_dr_prediction_hbd(zone, ptr(ref[i]), ctypes.c_ssize_t(bw), bw, bh, pa, pl, ua, ul, dx, dy, bd)
+                assert np.array_equal(out, ref), (TX_SIZES[tx_size], zone, ang, ua, ul, bd)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_edge_filter_and_upsample(dsp, bd):
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(bd)
+    n = 11
+    dt = np.uint8 if bd == 8 else np.uint16
+    for sz in (5, 9, 17, 33, 65, 129):
+        for strength in (0, 1, 2, 3):
+            e = rng.integers(0, 1 << bd, size=(n, 160)).astype(dt)
+            ref = e.copy()
+            for i in range(n):
+                p = ctypes.c_void_p(ref[i].ctypes.data + NB * e.itemsize)
+                (O.svt_oracle_filter_intra_edge if bd == 8 else O.svt_oracle_filter_intra_edge_hbd)(p, sz, strength)
+            d = _as_dev(e)
+            dsp.filter_intra_edge(d, sz, strength)
+            got = d.cpu().numpy(); got = got if bd == 8 else got.view(np.uint16)
+            assert np.array_equal(got, ref), (sz, strength)
+    for sz in (4, 8, 16):
+        e = rng.integers(0, 1 << bd, size=(n, 64)).astype(dt)
+        ref = e.copy()
+        for i in range(n):
+            p = ctypes.c_void_p(ref[i].ctypes.data + NB * e.itemsize)
+            if bd == 8: O.svt_oracle_upsample_intra_edge(p, sz)
+            else: O.svt_oracle_upsample_intra_edge_hbd(p, sz, bd)
+        d = _as_dev(e)
+        dsp.upsample_intra_edge(d, sz, bd)
+        got = d.cpu().numpy(); got = got if bd == 8 else got.view(np.uint16)
+        assert np.array_equal(got, ref), sz
+
+
+@pytest.mark.parametrize("w,h", [(4, 4), (8, 8), (16, 16), (32, 32), (32, 16), (8, 32)])
+def test_full_distortion32(dsp, w, h):
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(w + h)
+    n = 21
+    c = rng.integers(-(1 << 18), 1 << 18, size=(n, h, w)).astype(np.int32)
+    r = rng.integers(-(1 << 18), 1 << 18, size=(n, h, w)).astype(np.int32)
+    r[0] = c[0]
+    got = dsp.full_distortion32(dev(c), dev(r), w, h).cpu().numpy().view(np.uint64)
+    got0 = dsp.full_distortion32(dev(c), None, w, h, cbf_zero=True).cpu().numpy().view(np.uint64)
+    for i in range(n):
+        out = np.zeros(2, np.uint64)
+        O.svt_oracle_full_distortion32(ptr(c[i]), w, ptr(r[i]), w, ptr(out), w, h)
+        assert (int(got[i, 0]), int(got[i, 1])) == (int(out[0]), int(out[1]))
+        assert (int(got0[i, 0]), int(got0[i, 1])) == (int(out[1]), int(out[1]))

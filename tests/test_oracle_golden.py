@@ -115,3 +115,34 @@ def test_pixel_golden():
             O.svt_oracle_sad_loop(ptr(np.ascontiguousarray(src[i])), w, ptr(np.ascontiguousarray(rf[i])), rw, h, w,
                                   ptr(b), ptr(x), ptr(y), rw, ctypes.c_int16(sw), ctypes.c_int16(sh))
             assert (int(b[0]), int(x[0]), int(y[0])) == (int(g[k + "_best"][i]), int(g[k + "_x"][i]), int(g[k + "_y"][i])), (k, i)
+
+
+def test_intra_golden():
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "intra.npz"))
+    S = ctypes.c_ssize_t
+    checked = 0
+    for key in g.files:
+        parts = key.split("_")
+        if len(parts) < 3 or parts[2] in ("above", "left"):
+            continue
+        s, bd = int(parts[0]), int(parts[1])
+        bw, bh = TX_W[s], TX_H[s]
+        a = np.ascontiguousarray(g[f"{s}_{bd}_above"]); l = np.ascontiguousarray(g[f"{s}_{bd}_left"])
+        es = a.itemsize
+        pa = ctypes.c_void_p(a.ctypes.data + 16 * es); pl = ctypes.c_void_p(l.ctypes.data + 16 * es)
+        o = np.zeros((bh, bw), a.dtype)
+        if parts[2].startswith("m"):
+            m = int(parts[2][1:])
+            if bd == 8: O.svt_oracle_intra_pred(m, ptr(o), S(bw), bw, bh, pa, pl)
+            else: O.svt_oracle_intra_pred_hbd(m, ptr(o), S(bw), bw, bh, pa, pl, bd)
+        else:
+            zone, ang, ua, ul = int(parts[2][1:]), int(parts[3]), int(parts[4][0]), int(parts[4][1])
+            from test_oracle_vs_ref_tables import DR_DERIV
+            dx = DR_DERIV[ang] if zone in (1, 2) else 1
+            dy = DR_DERIV[90 - ang] if zone == 2 else (DR_DERIV[ang] if zone == 3 else 1)
+            if bd == 8: O.svt_oracle_dr_prediction(zone, ptr(o), S(bw), bw, bh, pa, pl, ua, ul, dx, dy)
+            else: O.svt_oracle_dr_prediction_hbd(zone, ptr(o), S(bw), bw, bh, pa, pl, ua, ul, dx, dy, bd)
+        assert np.array_equal(o, g[key]), key
+        checked += 1
+    assert checked > 500

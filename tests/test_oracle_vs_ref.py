@@ -118,3 +118,106 @@ def test_headline_chain_vs_reference_avx2_threads():
                                        ptr(tabs[3]), ptr(tabs[4]), ptr(r[0]), ptr(r[1]), ptr(r[2]), ptr(r[3]), ptr(r[4]))
             assert np.array_equal(co[i], r[0]) and np.array_equal(q[i], r[1]) and np.array_equal(dq[i], r[2])
             assert eob[i] == r[3][0] and sad[i] == r[4][0]
+
+
+# ---- intra prediction: no reference unit test exists; pinned by the scalar C functions ----
+INTRA_NAMES = ["dc", "v", "h", "smooth", "smooth_v", "smooth_h", "paeth", "dc_top", "dc_left", "dc_128"]
+
+
+@pytest.mark.parametrize("tx_size", range(19))
+def test_intra_nondirectional_vs_reference(tx_size):
+    O = svtlibs.oracle()
+    bw, bh = TX_W[tx_size], TX_H[tx_size]
+    rng = np.random.default_rng(900 + tx_size)
+    for mode, name in enumerate(INTRA_NAMES):
+        for bd in (8, 10):
+            for trial in range(3):
+                if bd == 8:
+                    nb_a = rng.integers(0, 256, size=16 + 2 * 64 + 16, dtype=np.uint8)
+                    nb_l = rng.integers(0, 256, size=16 + 2 * 64 + 16, dtype=np.uint8)
+                    d1 = np.zeros((bh, 80), np.uint8); d2 = d1.copy()
+                    f = getattr(R, f"aom_{name}_predictor_{bw}x{bh}_c")
+                    f(ptr(d1), ctypes.c_ssize_t(80), ctypes.c_void_p(nb_a.ctypes.data + 16), ctypes.c_void_p(nb_l.ctypes.data + 16))
+                    O.svt_oracle_intra_pred(mode, ptr(d2), ctypes.c_ssize_t(80), bw, bh, ctypes.c_void_p(nb_a.ctypes.data + 16),
+                                            ctypes.c_void_p(nb_l.ctypes.data + 16))
+                else:
+                    nb_a = rng.integers(0, 1 << bd, size=16 + 2 * 64 + 16).astype(np.uint16)
+                    nb_l = rng.integers(0, 1 << bd, size=16 + 2 * 64 + 16).astype(np.uint16)
+                    if trial == 1:
+                        nb_a[:] = (1 << bd) - 1; nb_l[:] = (1 << bd) - 1
+                    d1 = np.zeros((bh, 80), np.uint16); d2 = d1.copy()
+                    f = getattr(R, f"aom_highbd_{name}_predictor_{bw}x{bh}_c")
+                    f(ptr(d1), ctypes.c_ssize_t(80), ctypes.c_void_p(nb_a.ctypes.data + 32), ctypes.c_void_p(nb_l.ctypes.data + 32), c_int(bd))
+                    O.svt_oracle_intra_pred_hbd(mode, ptr(d2), ctypes.c_ssize_t(80), bw, bh, ctypes.c_void_p(nb_a.ctypes.data + 32),
+                                                ctypes.c_void_p(nb_l.ctypes.data + 32), bd)
+                assert np.array_equal(d1, d2), (TX_SIZES[tx_size], name, bd)
+
+
+DR_DERIV = {3: 1023, 6: 547, 9: 372, 14: 273, 17: 215, 20: 178, 23: 151, 26: 132, 29: 116, 32: 102, 36: 90, 39: 80,
+            42: 71, 45: 64, 48: 57, 51: 51, 54: 45, 58: 40, 61: 35, 64: 31, 67: 27, 70: 23, 73: 19, 76: 15, 81: 11,
+            84: 7, 87: 3}
+
+
+def test_dr_intra_derivative_table():
+    t = (ctypes.c_uint16 * 90).in_dll(R, "dr_intra_derivative")
+    for k, v in DR_DERIV.items():
+        assert t[k] == v
+
+
+@pytest.mark.parametrize("tx_size", [0, 1, 2, 3, 4, 5, 8, 9, 13, 16, 17])
+def test_directional_vs_reference(tx_size):
+    O = svtlibs.oracle()
+    bw, bh = TX_W[tx_size], TX_H[tx_size]
+    rng = np.random.default_rng(1700 + tx_size)
+    angles = sorted(DR_DERIV)
+    for bd in (8, 10):
+        dt = np.uint8 if bd == 8 else np.uint16
+        es = 1 if bd == 8 else 2
+        for zone in (1, 2, 3):
+            for a in angles[::3] + [87]:
+                for up in ((0, 0), (1, 1)) if bw + bh <= 16 else ((0, 0),):
+                    nb_a = rng.integers(0, 1 << bd, size=16 + 300).astype(dt)
+                    nb_l = rng.integers(0, 1 << bd, size=16 + 300).astype(dt)
+                    dx = DR_DERIV[a] if zone in (1, 2) else 1
+                    dy = DR_DERIV[a] if zone in (2, 3) else 1
+                    if zone == 2:      # angle p in (90,180): dx = deriv[180-p], dy = deriv[p-90]
+                        dy = DR_DERIV[90 - a]
+                    ua, ul = up
+                    pa = ctypes.c_void_p(nb_a.ctypes.data + 16 * es); pl = ctypes.c_void_p(nb_l.ctypes.data + 16 * es)
+                    d1 = np.zeros((bh, 72), dt); d2 = d1.copy()
+                    S = ctypes.c_ssize_t(72)
+                    if bd == 8:
+                        if zone == 1: R.av1_dr_prediction_z1_c(ptr(d1), S, bw, bh, pa, pl, ua, dx, dy)
+                        elif zone == 2: R.av1_dr_prediction_z2_c(ptr(d1), S, bw, bh, pa, pl, ua, ul, dx, dy)
+                        else: R.av1_dr_prediction_z3_c(ptr(d1), S, bw, bh, pa, pl, ul, dx, dy)
+                        O.svt_oracle_dr_prediction(zone, ptr(d2), S, bw, bh, pa, pl, ua, ul, dx, dy)
+                    else:
+                        if zone == 1: R.av1_highbd_dr_prediction_z1_c(ptr(d1), S, bw, bh, pa, pl, ua, dx, dy, bd)
+                        elif zone == 2: R.av1_highbd_dr_prediction_z2_c(ptr(d1), S, bw, bh, pa, pl, ua, ul, dx, dy, bd)
+                        else: R.av1_highbd_dr_prediction_z3_c(ptr(d1), S, bw, bh, pa, pl, ul, dx, dy, bd)
+                        O.svt_oracle_dr_prediction_hbd(zone, ptr(d2), S, bw, bh, pa, pl, ua, ul, dx, dy, bd)
+                    assert np.array_equal(d1, d2), (TX_SIZES[tx_size], bd, zone, a, up)
+
+
+def test_edge_filter_and_upsample_vs_reference():
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(4242)
+    for sz in (5, 9, 17, 33, 65, 129):
+        for strength in (0, 1, 2, 3):
+            e = rng.integers(0, 1024, size=sz).astype(np.uint16); e2 = e.copy()
+            R.av1_filter_intra_edge_high_c(ptr(e), sz, strength)
+            O.svt_oracle_filter_intra_edge_hbd(ptr(e2), sz, strength)
+            assert np.array_equal(e, e2)
+            e8 = rng.integers(0, 256, size=sz).astype(np.uint8); e82 = e8.copy()
+            R.av1_filter_intra_edge_high_c_old(ptr(e8), sz, strength)   # the uint8 body (EbIntraPrediction.c:177)
+            O.svt_oracle_filter_intra_edge(ptr(e82), sz, strength)
+            assert np.array_equal(e8, e82)
+    for sz in (4, 8, 16):
+        b = rng.integers(0, 256, size=64).astype(np.uint8); b2 = b.copy()
+        R.av1_upsample_intra_edge_c(ctypes.c_void_p(b.ctypes.data + 16), sz)
+        O.svt_oracle_upsample_intra_edge(ctypes.c_void_p(b2.ctypes.data + 16), sz)
+        assert np.array_equal(b, b2)
+        h = rng.integers(0, 1024, size=64).astype(np.uint16); h2 = h.copy()
+        R.av1_upsample_intra_edge_high_c(ctypes.c_void_p(h.ctypes.data + 32), sz, 10)
+        O.svt_oracle_upsample_intra_edge_hbd(ctypes.c_void_p(h2.ctypes.data + 32), sz, 10)
+        assert np.array_equal(h, h2)
