@@ -76,6 +76,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_upsample_intra_edge_batch.argtypes = [c_void_p, c_int32, c_int, c_int, c_int, c_size_t, c_void_p]
     L.svt_hip_full_distortion32_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t, c_uint32,
                                                   c_uint32, c_int, c_void_p, c_size_t, c_void_p]
+    L.svt_hip_me_sb_search_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t, c_int, c_int,
+                                             c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     return L
 
 
@@ -274,3 +276,21 @@ class SvtHipDsp:
                                                                 0 if edges.dtype == t.uint8 else 1, bd, n,
                                                                 self._stream()), "svt_hip_upsample_intra_edge_batch")
         return edges
+
+    # -- K6 ---------------------------------------------------------------------------------
+    MAX_SAD_VALUE = 128 * 128 * 255     # EbMotionEstimation.h:79
+
+    def me_sb_search(self, src, ref, search_w, search_h, x_origin=0, y_origin=0, origins=None, best_sad=None, best_mv=None):
+        """src uint8 [n,64,64]; ref uint8 [n, 64+sh-1 (or more), RW] private windows.
+        -> (best_sad, best_mv) int32 [n,85] (uint32 values), updated in place when given."""
+        t = self.torch
+        n = src.shape[0]
+        _, rh, rw = ref.shape
+        if best_sad is None:
+            best_sad = t.full((n, 85), self.MAX_SAD_VALUE, dtype=t.int32, device=src.device)
+            best_mv = t.zeros((n, 85), dtype=t.int32, device=src.device)
+        self._check(self.lib.svt_hip_me_sb_search_batch(self._p(src), 64, 64 * 64, self._p(ref), rw, rw * rh, search_w,
+                                                         search_h, self._p(origins) if origins is not None else None,
+                                                         x_origin, y_origin, self._p(best_sad), self._p(best_mv), n,
+                                                         self._stream()), "svt_hip_me_sb_search_batch")
+        return best_sad, best_mv

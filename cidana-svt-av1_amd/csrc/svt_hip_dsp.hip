@@ -14,6 +14,7 @@
 #include "../../include/svt_hip_dsp.h"
 #include "kernel_fused32.h"
 #include "kernel_intra.h"
+#include "kernel_me.h"
 #include "kernel_pixel.h"
 #include "kernel_txfm.h"
 
@@ -429,6 +430,26 @@ extern "C" int svt_hip_sad_search_batch(const uint8_t* d_src, uint32_t src_strid
                        (int)search_area_width, (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y,
                        src_bytes, ref_bytes, (uint32_t)nblocks);
     return launch_status("sad_search");
+}
+
+extern "C" int svt_hip_me_sb_search_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                          const uint8_t* d_ref, uint32_t ref_stride, size_t ref_block_pitch,
+                                          int search_w, int search_h, const int16_t* d_origins, int x_origin,
+                                          int y_origin, uint32_t* d_best_sad, uint32_t* d_best_mv, size_t nblocks,
+                                          void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_src || !d_ref || !d_best_sad || !d_best_mv) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (search_w <= 0 || search_h <= 0 || search_w * search_h > 4096)
+        return set_err(SVT_HIP_ERR_INVALID, "search area %dx%d (1..4096 points)", search_w, search_h);
+    const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
+    const uint32_t wpitch = (win_w + 3 + 8) & ~3u;
+    const size_t lds = 32 * 64 + (size_t)wpitch * win_h;
+    if (lds > 60 * 1024) return set_err(SVT_HIP_ERR_INVALID, "search window needs %zu B of LDS (> 60 KiB)", lds);
+    hipLaunchKernelGGL(me_sb_search_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
+                       src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
+                       x_origin, y_origin, d_best_sad, d_best_mv, wpitch, (uint32_t)nblocks);
+    return launch_status("me_sb_search");
 }
 
 extern "C" int svt_hip_full_distortion32_batch(const int32_t* d_coeff, uint32_t coeff_stride, size_t coeff_block_pitch,

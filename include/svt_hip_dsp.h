@@ -172,6 +172,23 @@ int svt_hip_sad_search_batch(const uint8_t *d_src, uint32_t src_stride, size_t s
                              uint64_t *d_best_sad, int16_t *d_x, int16_t *d_y, size_t nblocks,
                              void *stream);
 
+/* K6 ME multi-size SAD: full-pel search of 64x64 superblocks for all 85 PUs.
+ * Replaces FullPelSearch_LCU's inner calls (EbMotionEstimation.c:3199-3247 ->
+ * GetSearchPointResults :2932 -> SadCalculation_8x8_16x16 / _32x32_64x64 tables :145-199;
+ * C: :208-311).  Per SB b: source d_src + b*src_block_pitch (64x64, src_stride),
+ * reference window origin d_ref + b*ref_block_pitch (ref_stride), search area
+ * search_w x search_h (<= 4096 points), area origin (x, y) from d_origins[b][2] or,
+ * when NULL, the uniform x_origin / y_origin.  d_best_sad / d_best_mv: uint32[n][85],
+ * IN/OUT running bests exactly like the reference's p_best_sad8x8[64] | 16x16[16] |
+ * 32x32[4] | 64x64[1] (and p_best_mv*) arrays back to back; the caller initialises
+ * them (reference: MAX_SAD_VALUE, EbMotionEstimation.h:79). */
+#define SVT_HIP_ME_PUS 85
+int svt_hip_me_sb_search_batch(const uint8_t *d_src, uint32_t src_stride, size_t src_block_pitch,
+                               const uint8_t *d_ref, uint32_t ref_stride, size_t ref_block_pitch,
+                               int search_w, int search_h, const int16_t *d_origins, int x_origin,
+                               int y_origin, uint32_t *d_best_sad, uint32_t *d_best_mv,
+                               size_t nblocks, void *stream);
+
 /* K7 coefficient-domain distortion (full_distortion_kernel32_bits_func_ptr_array /
  * full_distortion_kernel_cbf_zero32_bits_func_ptr_array, EbPictureOperators.h:268-280;
  * C: EbPictureOperators.c:283-346).  d_out: uint64[nblocks][2] =

@@ -84,3 +84,49 @@ void svt_oracle_fwd_quant_sad(const uint8_t *src, uint32_t src_stride, const uin
     *sad = svt_oracle_sad(src, src_stride, pred, pred_stride, (uint32_t)h, (uint32_t)w);
     free(res); free(scan);
 }
+
+/* ---- ME multi-size SAD of one 64x64 SB over a full-pel search area (K6) -------
+ * Restates FullPelSearch_LCU (EbMotionEstimation.c:3199-3247) -> GetSearchPointResults
+ * (:2932-3057) -> ext_sad_calculation_8x8_16x16 (:208-262) + ext_sad_calculation_32x32_64x64
+ * (:267-311): per search point (raster order, y outer), the 64 8x8 SADs are taken on
+ * EVERY OTHER ROW and doubled (Compute8x4SAD_Kernel with 2x strides, :121-143), summed to
+ * 16x16 / 32x32 / 64x64; each of the 85 PUs keeps its running best with strict '<' and
+ * the packed quarter-pel MV ((uint16)y << 18) | (uint16)(x << 2)  (:2958-2960).
+ * Layout of best_sad / best_mv[85]: [0..63] 8x8 at 4*z + k (z = z-order index of the
+ * parent 16x16, k = raster index inside it), [64..79] 16x16 in z-order, [80..83] 32x32,
+ * [84] 64x64 — the reference's p_best_sad8x8/16x16/32x32/64x64 arrays back to back. */
+void svt_oracle_me_sb_search(const uint8_t *src, uint32_t src_stride, const uint8_t *ref,
+                             uint32_t ref_stride, int search_w, int search_h, int x_origin,
+                             int y_origin, uint32_t *best_sad, uint32_t *best_mv) {
+    for (int ys = 0; ys < search_h; ys++)
+        for (int xs = 0; xs < search_w; xs++) {
+            const uint32_t mv = (uint32_t)(((uint32_t)(uint16_t)(ys + y_origin)) << 18) |
+                                (uint32_t)(uint16_t)((xs + x_origin) << 2);
+            const uint8_t *r0 = ref + xs + (size_t)ys * ref_stride;
+            uint32_t s16[16], s32[4] = {0, 0, 0, 0}, s64 = 0;
+            for (int by16 = 0; by16 < 4; by16++)
+                for (int bx16 = 0; bx16 < 4; bx16++) {
+                    const int z = ((by16 >> 1) * 2 + (bx16 >> 1)) * 4 + (by16 & 1) * 2 + (bx16 & 1);
+                    uint32_t sum = 0;
+                    for (int k = 0; k < 4; k++) {
+                        const int x0 = bx16 * 16 + (k & 1) * 8, y0 = by16 * 16 + (k >> 1) * 8;
+                        uint32_t s = 0;
+                        for (int rr = 0; rr < 4; rr++)
+                            for (int c = 0; c < 8; c++)
+                                s += (uint32_t)abs((int)src[(size_t)(y0 + 2 * rr) * src_stride + x0 + c] -
+                                                   (int)r0[(size_t)(y0 + 2 * rr) * ref_stride + x0 + c]);
+                        s <<= 1;
+                        if (s < best_sad[4 * z + k]) { best_sad[4 * z + k] = s; best_mv[4 * z + k] = mv; }
+                        sum += s;
+                    }
+                    s16[z] = sum;
+                    if (sum < best_sad[64 + z]) { best_sad[64 + z] = sum; best_mv[64 + z] = mv; }
+                }
+            for (int q = 0; q < 4; q++) {
+                s32[q] = s16[4 * q] + s16[4 * q + 1] + s16[4 * q + 2] + s16[4 * q + 3];
+                if (s32[q] < best_sad[80 + q]) { best_sad[80 + q] = s32[q]; best_mv[80 + q] = mv; }
+                s64 += s32[q];
+            }
+            if (s64 < best_sad[84]) { best_sad[84] = s64; best_mv[84] = mv; }
+        }
+}

@@ -358,3 +358,30 @@ def test_full_distortion32(dsp, w, h):
         O.svt_oracle_full_distortion32(ptr(c[i]), w, ptr(r[i]), w, ptr(out), w, h)
         assert (int(got[i, 0]), int(got[i, 1])) == (int(out[0]), int(out[1]))
         assert (int(got0[i, 0]), int(got0[i, 1])) == (int(out[1]), int(out[1]))
+
+
+@pytest.mark.parametrize("sw,sh", [(1, 1), (8, 8), (13, 7), (64, 64), (48, 16), (5, 33)])
+def test_me_sb_search_85_pus(dsp, sw, sh):
+    """K6: all 85 PU bests + packed MVs of FullPelSearch_LCU, incl. ties (first in raster order)."""
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(sw * 100 + sh)
+    n = 5
+    rw, rh = 64 + sw - 1 + 3, 64 + sh - 1
+    src = rng.integers(0, 256, size=(n, 64, 64), dtype=np.uint8)
+    ref = rng.integers(0, 256, size=(n, rh, rw), dtype=np.uint8)
+    ref[0] = 100; src[0] = 101                      # every point ties -> first point wins everywhere
+    if sw > 4 and sh > 3:
+        ref[1, 2:66, 3:67] = src[1]                 # exact match at (3, 2)
+        ref[2, 0:64, 1:65] = src[2]; ref[2, 1:65, 0:64] = src[2]   # two exact matches: (1,0) before (0,1)
+    org = np.array([[-32, -16], [0, 0], [-7, 5], [100, -100], [-64, -64]], np.int16)
+    bs, bm = dsp.me_sb_search(dev(src), dev(ref), sw, sh, origins=dev(org))
+    bs = bs.cpu().numpy().view(np.uint32); bm = bm.cpu().numpy().view(np.uint32)
+    for i in range(n):
+        rs = np.full(85, 128 * 128 * 255, np.uint32); rm = np.zeros(85, np.uint32)
+        O.svt_oracle_me_sb_search(ptr(src[i]), 64, ptr(ref[i]), rw, sw, sh, int(org[i, 0]), int(org[i, 1]), ptr(rs), ptr(rm))
+        assert np.array_equal(bs[i], rs), f"sad block {i}"
+        assert np.array_equal(bm[i], rm), f"mv block {i}"
+    # running-best semantics: a second call with a worse window must not change anything
+    bs2, bm2 = dsp.me_sb_search(dev(src), dev((255 - ref)), sw, sh, origins=dev(org), best_sad=dev(bs.view(np.int32)), best_mv=dev(bm.view(np.int32)))
+    b2 = bs2.cpu().numpy().view(np.uint32)
+    assert (b2 <= bs).all()
