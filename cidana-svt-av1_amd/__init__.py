@@ -76,6 +76,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_upsample_intra_edge_batch.argtypes = [c_void_p, c_int32, c_int, c_int, c_int, c_size_t, c_void_p]
     L.svt_hip_full_distortion32_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t, c_uint32,
                                                   c_uint32, c_int, c_void_p, c_size_t, c_void_p]
+    L.svt_hip_fwd_quant_planes_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_size_t, c_int, c_int,
+                                                 c_int, c_int] + [c_void_p] * 5 + [c_void_p] * 7 + [c_void_p]
     L.svt_hip_me_sb_search_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t, c_int, c_int,
                                              c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     return L
@@ -294,3 +296,28 @@ class SvtHipDsp:
                                                          x_origin, y_origin, self._p(best_sad), self._p(best_mv), n,
                                                          self._stream()), "svt_hip_me_sb_search_batch")
         return best_sad, best_mv
+
+    # -- general fused chain on planes ------------------------------------------------------
+    def fwd_quant_planes(self, src, src_stride, pred, pred_stride, xy, tx_size, tx_type, qrow, iscan, bd=8,
+                         want_sad=False, want_energy=False):
+        """src, pred: uint8 / int16(as uint16) planes (any shape, row strides given in elements);
+        xy: int32 tensor of (y << 16) | x block origins.  -> coeff, q, dq [n, KW*KH], eob, sad|None, energy|None"""
+        t = self.torch
+        n = xy.shape[0]
+        nc = min(TX_W[tx_size], 32) * min(TX_H[tx_size], 32)
+        is16 = 0 if src.dtype == t.uint8 else 1
+        co = t.empty((n, nc), dtype=t.int32, device=src.device)
+        q = t.empty_like(co); dq = t.empty_like(co)
+        eob = t.zeros(n, dtype=t.int16, device=src.device)
+        sad = t.zeros(n, dtype=t.int32, device=src.device) if want_sad else None
+        en = t.zeros(n, dtype=t.int64, device=src.device) if want_energy else None
+        tabs = [_np16(qrow[k]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
+        self._check(self.lib.svt_hip_fwd_quant_planes_batch(self._p(src), src_stride, self._p(pred), pred_stride,
+                                                             self._p(xy), n, is16, bd, tx_size, tx_type,
+                                                             tabs[0].ctypes.data, tabs[1].ctypes.data, tabs[2].ctypes.data,
+                                                             tabs[3].ctypes.data, tabs[4].ctypes.data, self._p(iscan),
+                                                             self._p(co), self._p(q), self._p(dq), self._p(eob),
+                                                             self._p(sad) if want_sad else None,
+                                                             self._p(en) if want_energy else None, self._stream()),
+                    "svt_hip_fwd_quant_planes_batch")
+        return co, q, dq, eob, sad, en

@@ -158,6 +158,112 @@ __global__ __launch_bounds__(TX_WAVES * 64) void fwd_txfm2d_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// generic fused chain, every size / type / bit depth:
+//   residual(src, pred) -> fwd 2-D -> [64-pt: energy + pack] -> quantize_b -> eob (+ SAD)
+// (Av1EncodeLoop, EbCodingLoop.c:617 -> :655 -> :673; av1_estimate_transform's
+// 64-pt handling EbTransforms.c:4377-4408; 16-bit twin Av1EncodeLoop16bit :1020).
+// src / pred are PLANES: block b starts at (xy[b] >> 16) * stride + (xy[b] & 0xffff)
+// when xy != NULL, else at b * block_pitch.  Outputs are dense, packed
+// KW*KH = min(W,32)*min(H,32) coefficients per block.  The tuned 32x32 8-bit
+// kernel (kernel_fused32.h) serves the headline case; this one is the general path.
+// ---------------------------------------------------------------------------
+template <int W, int H, typename PixT>
+__global__ __launch_bounds__(TX_WAVES * 64) void fwd_quant_generic_kernel(
+    const PixT* __restrict__ src, uint32_t src_stride, size_t src_block_pitch, const PixT* __restrict__ pred,
+    uint32_t pred_stride, size_t pred_block_pitch, const uint32_t* __restrict__ xy, int tx_type, QParams qp,
+    const int16_t* __restrict__ iscan, int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff,
+    int32_t* __restrict__ dqcoeff, uint16_t* __restrict__ eob, uint32_t* __restrict__ sad,
+    unsigned long long* __restrict__ energy, uint32_t nblocks) {
+    using G = TxGeom<W, H>;
+    constexpr int KW = W > 32 ? 32 : W, KH = H > 32 ? 32 : H;
+    constexpr bool FAST = sizeof(PixT) == 1;      // 24-bit quantiser arithmetic is proven for 8-bit only
+    __shared__ int32_t lds[TX_WAVES * G::BPW * G::TILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / G::LPB, l = lane % G::LPB;
+    const uint32_t blk = (blockIdx.x * TX_WAVES + wave) * G::BPW + sub;
+    const bool valid = blk < nblocks;
+    int32_t* tile = lds + (wave * G::BPW + sub) * G::TILE;
+    const int vk = kVKind[tx_type], hk = kHKind[tx_type];
+    const bool ud = vk == K1D_FLIPADST, lr = hk == K1D_FLIPADST;
+    constexpr int CBC = fwd_cos_col(W, H), CBR = fwd_cos_row(W, H);
+    constexpr int S0 = fwd_shift(W, H, 0), S1 = fwd_shift(W, H, 1), S2 = fwd_shift(W, H, 2);
+
+    unsigned sad_acc = 0;
+    if (l < W) {
+        int x[H];
+        size_t so = 0, po = 0;
+        if (valid) {
+            if (xy) {
+                const uint32_t v = xy[blk];
+                so = (size_t)(v >> 16) * src_stride + (v & 0xffffu);
+                po = (size_t)(v >> 16) * pred_stride + (v & 0xffffu);
+            } else {
+                so = (size_t)blk * src_block_pitch;
+                po = (size_t)blk * pred_block_pitch;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < H; r++) {
+            const int rr = ud ? H - 1 - r : r;
+            const int d = valid ? (int)src[so + (size_t)rr * src_stride + l] - (int)pred[po + (size_t)rr * pred_stride + l] : 0;
+            sad_acc += (unsigned)(d < 0 ? -d : d);
+            x[r] = round_shift_c<-S0>(d);
+        }
+        fwd1d<H, CBC>(vk, x);
+        const int cdst = lr ? W - 1 - l : l;
+#pragma unroll
+        for (int r = 0; r < H; r++) tile[r * G::PITCH + cdst] = round_shift_c<-S1>(x[r]);
+    }
+    wave_lds_fence();
+    int eob_acc = 0;
+    unsigned long long en = 0;
+    if (l < H) {
+        int y[W];
+#pragma unroll
+        for (int c = 0; c < W; c++) y[c] = tile[l * G::PITCH + c];
+        fwd1d<W, CBR>(hk, y);
+#pragma unroll
+        for (int c = 0; c < W; c++) {
+            int t = round_shift_c<-S2>(y[c]);
+            if (G::RECT2) t = mul_q12(t, 5793);
+            y[c] = t;
+        }
+        if (W > 32 || H > 32) {                  // three_quad_energy of the discarded region
+#pragma unroll
+            for (int c = 0; c < W; c++)
+                if (l >= KH || c >= KW) { const long long v = y[c]; en += (unsigned long long)(v * v); }
+        }
+        if (l < KH && valid) {
+            const size_t o = (size_t)blk * (KW * KH) + (size_t)l * KW;
+#pragma unroll
+            for (int c = 0; c < KW; c += 4) {
+                int4 cv, qv, dv;
+                int* cp = &cv.x; int* qp4 = &qv.x; int* dp = &dv.x;
+                const uint2 is = *reinterpret_cast<const uint2*>(iscan + l * KW + c);
+                const unsigned isv[4] = {is.x & 0xffffu, is.x >> 16, is.y & 0xffffu, is.y >> 16};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    cp[j] = y[c + j];
+                    quant_one<FAST>(y[c + j], (l == 0 && c + j == 0) ? 0 : 1, qp, qp4[j], dp[j]);
+                    eob_acc = max(eob_acc, qp4[j] ? (int)isv[j] + 1 : 0);
+                }
+                *reinterpret_cast<int4*>(coeff + o + c) = cv;
+                *reinterpret_cast<int4*>(qcoeff + o + c) = qv;
+                *reinterpret_cast<int4*>(dqcoeff + o + c) = dv;
+            }
+        }
+    }
+    eob_acc = group_max<G::LPB>(eob_acc);
+    sad_acc = group_sum<G::LPB>(sad_acc);
+    if (W > 32 || H > 32) en = group_sum64<G::LPB>(en);
+    if (valid && l == 0) {
+        eob[blk] = (uint16_t)eob_acc;
+        if (sad) sad[blk] = sad_acc;
+        if (energy) energy[blk] = en;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // inverse + add: in = packed min(W,32) x min(H,32) int32 coefficients per block
 // (dense), dst = PixT samples; block b at dst + (dst_offsets ? dst_offsets[b]
 // : b * dst_block_pitch), row stride dst_stride (elements).

@@ -337,7 +337,9 @@ extern "C" int svt_hip_fwd_quant_sad_batch(const uint8_t* d_src, const uint8_t* 
     if (!d_src || !d_pred || !d_coeff || !d_qcoeff || !d_dqcoeff || !d_eob || !d_iscan || !zbin || !round || !quant || !quant_shift || !dequant)
         return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
     if (tx_size != SVT_TX_32X32 || tx_type != SVT_DCT_DCT)
-        return set_err(SVT_HIP_ERR_UNSUPPORTED, "fused chain: only TX_32X32 / DCT_DCT is built (got %d/%d)", tx_size, tx_type);
+        return svt_hip_fwd_quant_planes_batch(d_src, 0, d_pred, 0, nullptr, nblocks, 0, 8, tx_size, tx_type, zbin, round, quant,
+                                              quant_shift, dequant, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad,
+                                              nullptr, stream);
     if (nblocks == 0) return SVT_HIP_OK;
     if (nblocks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "nblocks too large");
     const QParams qp = make_qparams(zbin, round, quant, quant_shift, dequant, 1);
@@ -357,6 +359,50 @@ extern "C" int svt_hip_fwd_quant_sad_batch(const uint8_t* d_src, const uint8_t* 
         hipLaunchKernelGGL((fwd_quant_sad_32x32_kernel<false>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, d_pred,
                            d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks);
     return launch_status("fwd_quant_sad_32x32");
+}
+
+template <int W, int H>
+int launch_fq(const void* src, uint32_t ss, const void* pred, uint32_t ps, const uint32_t* xy, size_t n, int is16, int tx_type,
+              const QParams& qp, const int16_t* iscan, int32_t* co, int32_t* q, int32_t* dq, uint16_t* eob, uint32_t* sad,
+              uint64_t* energy, hipStream_t s) {
+    constexpr int BPW = TxGeom<W, H>::BPW;
+    const uint32_t per_wg = TX_WAVES * BPW;
+    const uint32_t grid = (uint32_t)((n + per_wg - 1) / per_wg);
+    const uint32_t sstr = xy ? ss : (uint32_t)W, pstr = xy ? ps : (uint32_t)W;
+    if (is16)
+        hipLaunchKernelGGL((fwd_quant_generic_kernel<W, H, uint16_t>), dim3(grid), dim3(TX_WAVES * 64), 0, s, (const uint16_t*)src,
+                           sstr, (size_t)W * H, (const uint16_t*)pred, pstr, (size_t)W * H, xy, tx_type, qp, iscan, co, q, dq,
+                           eob, sad, (unsigned long long*)energy, (uint32_t)n);
+    else
+        hipLaunchKernelGGL((fwd_quant_generic_kernel<W, H, uint8_t>), dim3(grid), dim3(TX_WAVES * 64), 0, s, (const uint8_t*)src,
+                           sstr, (size_t)W * H, (const uint8_t*)pred, pstr, (size_t)W * H, xy, tx_type, qp, iscan, co, q, dq,
+                           eob, sad, (unsigned long long*)energy, (uint32_t)n);
+    return launch_status("fwd_quant_generic");
+}
+
+extern "C" int svt_hip_fwd_quant_planes_batch(const void* d_src, uint32_t src_stride, const void* d_pred,
+                                              uint32_t pred_stride, const uint32_t* d_xy, size_t nblocks, int is_16bit,
+                                              int bd, int tx_size, int tx_type, const int16_t* zbin, const int16_t* round,
+                                              const int16_t* quant, const int16_t* quant_shift, const int16_t* dequant,
+                                              const int16_t* d_iscan, int32_t* d_coeff, int32_t* d_qcoeff,
+                                              int32_t* d_dqcoeff, uint16_t* d_eob, uint32_t* d_sad, uint64_t* d_energy,
+                                              void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_src || !d_pred || !d_coeff || !d_qcoeff || !d_dqcoeff || !d_eob || !d_iscan || !zbin || !round || !quant || !quant_shift || !dequant)
+        return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    if (!txfm_allowed(tx_size, tx_type)) return set_err(SVT_HIP_ERR_INVALID, "tx_size %d / tx_type %d not defined by the reference", tx_size, tx_type);
+    if ((is_16bit && bd != 10) || (!is_16bit && bd != 8)) return set_err(SVT_HIP_ERR_INVALID, "bit depth %d (%d-bit planes)", bd, is_16bit ? 16 : 8);
+    if (is_16bit && d_sad) return set_err(SVT_HIP_ERR_INVALID, "SAD is defined for 8-bit planes only (the reference searches on the 8-bit MSB plane)");
+    if (nblocks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "nblocks too large");
+    const int pels = kTxW[tx_size] * kTxH[tx_size];
+    const QParams qp = make_qparams(zbin, round, quant, quant_shift, dequant, pels > 1024 ? 2 : (pels > 256 ? 1 : 0));
+    for (int i = 0; i < 2; i++)
+        if (qp.quant_shift[i] < 0 || qp.dequant[i] < 0 || qp.round[i] < 0) return set_err(SVT_HIP_ERR_INVALID, "negative quantizer table entry");
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(W, H) launch_fq<W, H>(d_src, src_stride, d_pred, pred_stride, d_xy, nblocks, is_16bit, tx_type, qp, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_energy, s)
+    TX_SWITCH(tx_size, CALL)
+#undef CALL
 }
 
 static int sad_sse_common(bool sse, const uint8_t* a, uint32_t as, size_t ap, const uint8_t* b, uint32_t bs,

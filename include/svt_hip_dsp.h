@@ -135,14 +135,31 @@ int svt_hip_quantize_b_batch(const int32_t *d_coeff, size_t n_coeffs, int skip_b
  *   coeff    = FwdTxfm2d(residual)   av1_estimate_transform (EbFullLoop.c:763)
  *   q,dq,eob = quantize_b(coeff)     av1_quantize_inv_quantize (EbFullLoop.c:780)
  *   sad      = SAD(src, pred)        NxMSadKernel     (EbProductCodingLoop.c:1259)
- * d_src/d_pred: dense W*H uint8 per block.  Outputs dense per block; d_sad may be
- * NULL.  Round 1: tx_size must be SVT_TX_32X32 and tx_type SVT_DCT_DCT. */
+ * d_src/d_pred: dense W*H uint8 per block.  Outputs dense per block (packed
+ * min(W,32)*min(H,32) for 64-pt sizes); d_sad may be NULL.  TX_32X32/DCT_DCT runs the
+ * tuned fused kernel, every other size/type the generic fused kernel. */
 int svt_hip_fwd_quant_sad_batch(const uint8_t *d_src, const uint8_t *d_pred, size_t nblocks,
                                 int tx_size, int tx_type, const int16_t *zbin,
                                 const int16_t *round, const int16_t *quant,
                                 const int16_t *quant_shift, const int16_t *dequant,
                                 const int16_t *d_iscan, int32_t *d_coeff, int32_t *d_qcoeff,
                                 int32_t *d_dqcoeff, uint16_t *d_eob, uint32_t *d_sad, void *stream);
+
+/* The same chain for EVERY transform size / type and for 8- or 16-bit sample planes
+ * (Av1EncodeLoop EbCodingLoop.c:545-950, Av1EncodeLoop16bit :1020-1351): blocks are
+ * addressed inside planes by d_xy[b] = (y << 16) | x (or, when d_xy == NULL, block b
+ * starts at b * W*H elements with row stride W: the dense layout above).  Outputs are
+ * dense, PACKED min(W,32)*min(H,32) coefficients per block; for 64-pt sizes d_energy
+ * (may be NULL) receives av1_estimate_transform's three_quad_energy.  d_sad (may be
+ * NULL) is defined for 8-bit planes only. */
+int svt_hip_fwd_quant_planes_batch(const void *d_src, uint32_t src_stride, const void *d_pred,
+                                   uint32_t pred_stride, const uint32_t *d_xy, size_t nblocks,
+                                   int is_16bit, int bd, int tx_size, int tx_type,
+                                   const int16_t *zbin, const int16_t *round, const int16_t *quant,
+                                   const int16_t *quant_shift, const int16_t *dequant,
+                                   const int16_t *d_iscan, int32_t *d_coeff, int32_t *d_qcoeff,
+                                   int32_t *d_dqcoeff, uint16_t *d_eob, uint32_t *d_sad,
+                                   uint64_t *d_energy, void *stream);
 
 /* K4 NxM SAD (NxMSadKernel_funcPtrArray, EbComputeSAD.h:105-160; C:
  * EbComputeSAD_C.c:48) and K7 SSE (spatial_full_distortion_kernel,

@@ -130,3 +130,39 @@ void svt_oracle_me_sb_search(const uint8_t *src, uint32_t src_stride, const uint
             if (s64 < best_sad[84]) { best_sad[84] = s64; best_mv[84] = mv; }
         }
 }
+
+/* General form of the chain for any size / type / bit depth, planes of 8- or 16-bit
+ * samples (Av1EncodeLoop EbCodingLoop.c:545 and Av1EncodeLoop16bit :1020: residual
+ * (residual_kernel16bit EbPictureOperators.c:134) -> av1_estimate_transform (incl.
+ * three_quad_energy for 64-pt) -> av1_quantize_inv_quantize with the high-bit-depth
+ * quantizer).  sad is only defined for 8-bit input (may be NULL). */
+void svt_oracle_fwd_quant_planes(const void *src, uint32_t src_stride, const void *pred,
+                                 uint32_t pred_stride, int is_16bit, int bd, int tx_size, int tx_type,
+                                 const int16_t *zbin, const int16_t *round, const int16_t *quant,
+                                 const int16_t *quant_shift, const int16_t *dequant, int32_t *coeff,
+                                 int32_t *qcoeff, int32_t *dqcoeff, uint16_t *eob, uint32_t *sad,
+                                 uint64_t *energy) {
+    const int w = svt_oracle_tx_wide(tx_size), h = svt_oracle_tx_high(tx_size);
+    int16_t *res = (int16_t *)malloc(sizeof(int16_t) * w * h);
+    int32_t *full = (int32_t *)malloc(sizeof(int32_t) * w * h);
+    int16_t *scan = (int16_t *)malloc(sizeof(int16_t) * 1024 * 2), *iscan = scan + 1024;
+    uint32_t acc = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int s = is_16bit ? ((const uint16_t *)src)[(size_t)y * src_stride + x] : ((const uint8_t *)src)[(size_t)y * src_stride + x];
+            const int p = is_16bit ? ((const uint16_t *)pred)[(size_t)y * pred_stride + x] : ((const uint8_t *)pred)[(size_t)y * pred_stride + x];
+            res[y * w + x] = (int16_t)(s - p);
+            acc += (uint32_t)abs(s - p);
+        }
+    svt_oracle_fwd_txfm2d(res, full, (uint32_t)w, tx_type, tx_size, bd);
+    const uint64_t e = svt_oracle_fwd_txfm2d_pack64(full, tx_size);
+    const int n = svt_oracle_get_scan(tx_size, tx_type, scan, iscan);
+    memcpy(coeff, full, sizeof(int32_t) * n);
+    const int pels = w * h;
+    const int log_scale = pels > 1024 ? 2 : (pels > 256 ? 1 : 0);
+    svt_oracle_quantize_b(coeff, n, 0, zbin, round, quant, quant_shift, qcoeff, dqcoeff, dequant, eob,
+                          scan, iscan, log_scale, 0);
+    if (sad) *sad = acc;
+    if (energy) *energy = e;
+    free(res); free(full); free(scan);
+}

@@ -84,13 +84,88 @@ def test_fused_empty_and_single(dsp, pkg):
     assert int(eob.cpu().numpy().view(np.uint16)[0]) == int(reob[0])
 
 
-def test_fused_unsupported_size_is_loud(dsp, pkg):
+def test_fused_invalid_combination_is_loud(dsp, pkg):
+    """TX_64X64 only exists with DCT_DCT (is_txfm_allowed): anything else is an error, never a guess"""
     qt = svtlibs.quant_tables(8)
     qrow = {k: v[100].copy() for k, v in qt.items()}
-    _, iscan = svtlibs.scan_tables(2, 0)
-    x = torch.zeros((4, 16, 16), dtype=torch.uint8, device=DEV)
+    _, iscan = svtlibs.scan_tables(4, 0)
+    x = torch.zeros((4, 64, 64), dtype=torch.uint8, device=DEV)
     with pytest.raises(pkg.SvtHipError):
-        dsp.fwd_quant_sad(x, x, 2, 0, qrow, dev(iscan))
+        dsp.fwd_quant_sad(x, x, 4, 1, qrow, dev(iscan))
+
+
+@pytest.mark.parametrize("tx_size", range(19))
+def test_fused_chain_every_size_and_type(dsp, tx_size):
+    """the generic fused kernel behind svt_hip_fwd_quant_sad_batch (dense 8-bit blocks)"""
+    w, h = TX_W[tx_size], TX_H[tx_size]
+    rng = np.random.default_rng(4000 + tx_size)
+    qt = svtlibs.quant_tables(8)
+    n = 11
+    for tx_type in range(16):
+        if not txfm_allowed(tx_size, tx_type):
+            continue
+        for qindex in (0, 60, 255):
+            qrow = {k: v[qindex].copy() for k, v in qt.items()}
+            _, iscan = svtlibs.scan_tables(tx_size, tx_type)
+            src, pred = make_pixels(rng, n, h, w, "extreme" if qindex == 60 else "random")
+            co, q, dq, eob, sad = dsp.fwd_quant_sad(dev(src), dev(pred), tx_size, tx_type, qrow, dev(iscan))
+            rco, rq, rdq, reob, rsad = oracle_chain(src, pred, tx_size, tx_type, qrow)
+            tag = (TX_SIZES[tx_size], TX_TYPES[tx_type], qindex)
+            assert np.array_equal(co.cpu().numpy(), rco), tag
+            assert np.array_equal(q.cpu().numpy(), rq), tag
+            assert np.array_equal(dq.cpu().numpy(), rdq), tag
+            assert np.array_equal(eob.cpu().numpy().view(np.uint16), reob), tag
+            assert np.array_equal(sad.cpu().numpy().view(np.uint32), rsad), tag
+
+
+def _plane_case(dsp, rng, bd, tx_size, tx_type, pw, ph, qindex):
+    O = svtlibs.oracle()
+    w, h = TX_W[tx_size], TX_H[tx_size]
+    dt = np.uint8 if bd == 8 else np.uint16
+    src = rng.integers(0, 1 << bd, size=(ph, pw)).astype(dt)
+    pred = rng.integers(0, 1 << bd, size=(ph, pw + 16)).astype(dt)        # different stride on purpose
+    xs = np.arange(0, pw - w + 1, w); ys = np.arange(0, ph - h + 1, h)
+    xy = np.array([(y << 16) | x for y in ys for x in xs], np.uint32)
+    qt = svtlibs.quant_tables(bd)
+    qrow = {k: v[qindex].copy() for k, v in qt.items()}
+    _, iscan = svtlibs.scan_tables(tx_size, tx_type)
+    as_dev = (lambda a: dev(a)) if bd == 8 else (lambda a: dev(a.view(np.int16)))
+    co, q, dq, eob, sad, en = dsp.fwd_quant_planes(as_dev(src), pw, as_dev(pred), pw + 16, dev(xy.view(np.int32)), tx_size,
+                                                   tx_type, qrow, dev(iscan), bd=bd, want_sad=(bd == 8), want_energy=True)
+    co = co.cpu().numpy(); q = q.cpu().numpy(); dq = dq.cpu().numpy()
+    eob = eob.cpu().numpy().view(np.uint16); en = en.cpu().numpy().view(np.uint64)
+    nc = co.shape[1]
+    for i, v in enumerate(xy):
+        y, x = int(v >> 16), int(v & 0xffff)
+        rc = np.zeros(1024, np.int32); rq = np.zeros(1024, np.int32); rdq = np.zeros(1024, np.int32)
+        reob = np.zeros(1, np.uint16); rsad = np.zeros(1, np.uint32); ren = np.zeros(1, np.uint64)
+        sp = ctypes.c_void_p(src.ctypes.data + (y * pw + x) * src.itemsize)
+        pp = ctypes.c_void_p(pred.ctypes.data + (y * (pw + 16) + x) * pred.itemsize)
+        O.svt_oracle_fwd_quant_planes(sp, pw, pp, pw + 16, int(bd != 8), bd, tx_size, tx_type, ptr(qrow["zbin"]), ptr(qrow["round"]),
+                                      ptr(qrow["quant"]), ptr(qrow["quant_shift"]), ptr(qrow["dequant"]), ptr(rc), ptr(rq), ptr(rdq),
+                                      ptr(reob), ptr(rsad), ptr(ren))
+        assert np.array_equal(co[i], rc[:nc]) and np.array_equal(q[i], rq[:nc]) and np.array_equal(dq[i], rdq[:nc]), (i, bd)
+        assert eob[i] == reob[0] and en[i] == ren[0]
+        if bd == 8:
+            assert int(sad[i].item()) & 0xffffffff == int(rsad[0])
+    return src, pred, xy, qrow, dq
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("tx_size,tx_type", [(0, 0), (1, 3), (2, 9), (3, 0), (4, 0), (5, 6), (10, 0), (11, 0), (17, 0), (14, 12)])
+def test_fwd_quant_planes_xy_addressing(dsp, bd, tx_size, tx_type):
+    rng = np.random.default_rng(tx_size * 3 + bd)
+    _plane_case(dsp, rng, bd, tx_size, tx_type, 192, 128, 80)
+
+
+def test_planes_sad_is_refused_for_16bit(dsp, pkg):
+    qt = svtlibs.quant_tables(10)
+    qrow = {k: v[100].copy() for k, v in qt.items()}
+    _, iscan = svtlibs.scan_tables(1, 0)
+    p = torch.zeros((64, 64), dtype=torch.int16, device=DEV)
+    xy = torch.zeros(4, dtype=torch.int32, device=DEV)
+    with pytest.raises(pkg.SvtHipError):
+        dsp.fwd_quant_planes(p, 64, p, 64, xy, 1, 0, qrow, dev(iscan), bd=10, want_sad=True)
 
 
 @pytest.mark.parametrize("tx_size", range(19))
