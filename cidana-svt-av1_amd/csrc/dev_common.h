@@ -16,6 +16,10 @@ struct QParams {
     int32_t quant_shift[2];
     int32_t dequant[2];
     int32_t log_scale;
+    // POW2 fast path (host-checked): quant_shift = 2^k, so the two-step reference
+    // formula collapses to  aq = (t1 * quant_m) >> fast_sh  with fast_sh = 32 - log_scale - k
+    int32_t fast_sh[2];
+    int32_t fast_ok;
 };
 
 // Orders this wave's LDS traffic: LDS instructions of one wave execute in
@@ -34,16 +38,32 @@ __device__ __forceinline__ uint32_t mul24_shr(uint32_t a, uint32_t b, int sh) {
     return (uint32_t)(p >> sh);
 }
 
-// One coefficient through highbd_quantize_b_helper_c (EbFullLoop.c:239-296),
-// flat quant matrix.  FAST24 = operands proven < 2^24 (8/10-bit transform
-// output); otherwise exact 64-bit arithmetic.
-template <bool FAST24>
+// One coefficient through highbd_quantize_b_helper_c (EbFullLoop.c:239-296), flat quant
+// matrix.  Reference:  tw = (|c| + round) * 32;  t2 = ((tw * quant) >> 16) + tw;
+//                      aq = (t2 * quant_shift) >> (21 - log_scale);  adq = (aq * dequant) >> log_scale
+// MODE 0: exact 64-bit arithmetic (any table, any coefficient).
+// MODE 1: 24-bit multiplies, operands proven < 2^24 (8-bit transform output).
+// MODE 2: MODE 1 + quant_shift is a power of two (true for every table av1_build_quantizer
+//         emits: invert_quant, EbModeDecisionConfigurationProcess.c:322-330):
+//         t2 = floor(t1 * m / 2^11) with m = quant + 65536, so aq = floor(t1 * m / 2^fast_sh) —
+//         one 48-bit product (v_mul_u32_u24 + v_mul_hi_u32_u24) and one v_alignbit.
+template <int MODE>
 __device__ __forceinline__ void quant_one(int c, int ac, const QParams& qp, int& q, int& dq) {
     const int s = c >> 31;
     const int a = (c ^ s) - s;
-    const bool keep = a >= qp.zbin[ac];
     int aq, adq;
-    if (FAST24) {
+    if (MODE == 2) {
+        const uint32_t t1 = (uint32_t)(a + qp.round[ac]);
+        const uint64_t p = (uint64_t)(t1 & 0xffffffu) * (uint64_t)(qp.quant_m[ac] & 0xffffffu);
+        aq = (int)__builtin_amdgcn_alignbit((uint32_t)(p >> 32), (uint32_t)p, (uint32_t)qp.fast_sh[ac]);
+        aq = a >= qp.zbin[ac] ? aq : 0;
+        adq = (int)(((uint32_t)aq & 0xffffffu) * ((uint32_t)qp.dequant[ac] & 0xffffffu)) >> qp.log_scale;
+        q = (aq ^ s) - s;
+        dq = (adq ^ s) - s;
+        return;
+    }
+    const bool keep = a >= qp.zbin[ac];
+    if (MODE == 1) {
         const uint32_t tw = (uint32_t)(a + qp.round[ac]) << 5;
         const uint32_t t2 = mul24_shr(tw, qp.quant_m[ac], 16);
         aq = (int)mul24_shr(t2, (uint32_t)qp.quant_shift[ac], 21 - qp.log_scale);

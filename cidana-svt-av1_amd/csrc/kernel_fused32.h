@@ -32,8 +32,8 @@ constexpr int F32_COS_BIT = 12;              // fwd_cos_bit_col/row[3][3] (EbTra
 // slots are XOR-swizzled by f: conflict-free for the access pairs used below.
 __device__ __forceinline__ int tile_slot(int r, int s, int f) { return r * 128 + ((s ^ f) << 4); }
 
-template <bool WITH_SAD>
-__global__ __launch_bounds__(F32_WAVES * 64) void fwd_quant_sad_32x32_kernel(
+template <bool WITH_SAD, int MIN_WAVES_PER_SIMD, bool NT = false, int QMODE = 2>
+__global__ __launch_bounds__(F32_WAVES * 64, MIN_WAVES_PER_SIMD) void fwd_quant_sad_32x32_kernel(
     const uint8_t* __restrict__ src, const uint8_t* __restrict__ pred, int32_t* __restrict__ coeff,
     int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff, uint16_t* __restrict__ eob,
     uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp, uint32_t nblocks) {
@@ -145,14 +145,23 @@ __global__ __launch_bounds__(F32_WAVES * 64) void fwd_quant_sad_32x32_kernel(
             const int4 c = *reinterpret_cast<const int4*>(tile + tile_slot(row, li & 7, row & 7));
             int4 q, d;
             // only linear position 0 (k == 0, li == 0, .x) uses the DC entries
-            quant_one<true>(c.x, (k == 0 && li == 0) ? 0 : 1, qp, q.x, d.x);
-            quant_one<true>(c.y, 1, qp, q.y, d.y);
-            quant_one<true>(c.z, 1, qp, q.z, d.z);
-            quant_one<true>(c.w, 1, qp, q.w, d.w);
+            quant_one<QMODE>(c.x, (k == 0 && li == 0) ? 0 : 1, qp, q.x, d.x);
+            quant_one<QMODE>(c.y, 1, qp, q.y, d.y);
+            quant_one<QMODE>(c.z, 1, qp, q.z, d.z);
+            quant_one<QMODE>(c.w, 1, qp, q.w, d.w);
             const int e0 = q.x ? (int)(isc[k].x & 0xffffu) : 0, e1 = q.y ? (int)(isc[k].x >> 16) : 0;
             const int e2 = q.z ? (int)(isc[k].y & 0xffffu) : 0, e3 = q.w ? (int)(isc[k].y >> 16) : 0;
             eob_acc = max(eob_acc, max(max(e0, e1), max(e2, e3)));
-            if (valid) { co4[k * 32 + li] = c; qc4[k * 32 + li] = q; dq4[k * 32 + li] = d; }
+            if (valid) {
+                if (NT) {   // streaming outputs are never re-read by this kernel: bypass-friendly stores
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(v4i{c.x, c.y, c.z, c.w}, reinterpret_cast<v4i*>(&co4[k * 32 + li]));
+                    __builtin_nontemporal_store(v4i{q.x, q.y, q.z, q.w}, reinterpret_cast<v4i*>(&qc4[k * 32 + li]));
+                    __builtin_nontemporal_store(v4i{d.x, d.y, d.z, d.w}, reinterpret_cast<v4i*>(&dq4[k * 32 + li]));
+                } else {
+                    co4[k * 32 + li] = c; qc4[k * 32 + li] = q; dq4[k * 32 + li] = d;
+                }
+            }
         }
         // eob = 1 + last scan position with a non-zero level (iscan max)
         eob_acc = half_wave_max(eob_acc);

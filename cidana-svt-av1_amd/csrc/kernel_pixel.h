@@ -29,10 +29,10 @@ __global__ __launch_bounds__(256) void quantize_b_kernel(
         if (valid && !skip_block) {
             c = c4[i];
             const uint2 is = *reinterpret_cast<const uint2*>(iscan + i * 4);
-            quant_one<false>(c.x, i == 0 ? 0 : 1, qp, q.x, d.x);
-            quant_one<false>(c.y, 1, qp, q.y, d.y);
-            quant_one<false>(c.z, 1, qp, q.z, d.z);
-            quant_one<false>(c.w, 1, qp, q.w, d.w);
+            quant_one<0>(c.x, i == 0 ? 0 : 1, qp, q.x, d.x);
+            quant_one<0>(c.y, 1, qp, q.y, d.y);
+            quant_one<0>(c.z, 1, qp, q.z, d.z);
+            quant_one<0>(c.w, 1, qp, q.w, d.w);
             const int e0 = q.x ? (int)(is.x & 0xffffu) + 1 : 0, e1 = q.y ? (int)(is.x >> 16) + 1 : 0;
             const int e2 = q.z ? (int)(is.y & 0xffffu) + 1 : 0, e3 = q.w ? (int)(is.y >> 16) + 1 : 0;
             eob_acc = max(eob_acc, max(max(e0, e1), max(e2, e3)));

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(TX_WAVES * 64) void fwd_quant_generic_kernel(
     unsigned long long* __restrict__ energy, uint32_t nblocks) {
     using G = TxGeom<W, H>;
     constexpr int KW = W > 32 ? 32 : W, KH = H > 32 ? 32 : H;
-    constexpr bool FAST = sizeof(PixT) == 1;      // 24-bit quantiser arithmetic is proven for 8-bit only
+    constexpr int FAST = sizeof(PixT) == 1 ? 1 : 0;   // 24-bit quantiser arithmetic is proven for 8-bit only
     __shared__ int32_t lds[TX_WAVES * G::BPW * G::TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / G::LPB, l = lane % G::LPB;

@@ -28,6 +28,11 @@ std::mutex g_init_mu;
 int g_device = -1;
 char g_devname[300] = "";
 int g_num_cu = 256;
+// tuning knobs (svt_hip_tune): fused 32x32 kernel occupancy / grid
+int g_tune_f32_min_waves = 1;
+int g_tune_f32_wg_per_cu = 0;
+int g_tune_f32_nt = 0;
+int g_tune_f32_qmode1 = 0;
 
 int set_err(int code, const char* fmt, ...) {
     va_list ap;
@@ -79,6 +84,15 @@ QParams make_qparams(const int16_t* zbin, const int16_t* round, const int16_t* q
         qp.dequant[i] = dequant[i];
     }
     qp.log_scale = log_scale;
+    qp.fast_ok = 1;
+    for (int i = 0; i < 2; i++) {
+        const int qs = quant_shift[i];
+        int k = -1;
+        if (qs > 0 && (qs & (qs - 1)) == 0) { k = 0; while ((1 << k) != qs) k++; }
+        const int sh = 32 - log_scale - k;
+        qp.fast_sh[i] = sh;
+        if (k < 0 || sh < 1 || sh > 31 || dequant[i] < 0 || qp.round[i] < 0) qp.fast_ok = 0;
+    }
     return qp;
 }
 
@@ -222,6 +236,14 @@ extern "C" void svt_hip_shutdown(void) {
     g_inited.store(0, std::memory_order_release);
 }
 extern "C" const char* svt_hip_last_error(void) { return g_err; }
+extern "C" int svt_hip_tune(const char* key, int value) {
+    if (!key) return SVT_HIP_ERR_INVALID;
+    if (!strcmp(key, "f32_min_waves")) { g_tune_f32_min_waves = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "f32_wg_per_cu")) { g_tune_f32_wg_per_cu = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "f32_nt")) { g_tune_f32_nt = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "f32_qmode1")) { g_tune_f32_qmode1 = value; return SVT_HIP_OK; }
+    return set_err(SVT_HIP_ERR_INVALID, "unknown tuning key %s", key);
+}
 extern "C" const char* svt_hip_device_name(void) { return g_devname; }
 
 extern "C" void* svt_hip_malloc(size_t bytes) {
@@ -349,15 +371,28 @@ extern "C" int svt_hip_fwd_quant_sad_batch(const uint8_t* d_src, const uint8_t* 
             return set_err(SVT_HIP_ERR_INVALID, "negative quantizer table entry");
     const uint32_t npairs = (uint32_t)((nblocks + 1) / 2);
     uint32_t grid = (npairs + F32_WAVES - 1) / F32_WAVES;
-    const uint32_t max_grid = (uint32_t)g_num_cu * 5u * 4u;   // 5 resident WGs/CU (LDS-limited) x 4 rounds
-    if (grid > max_grid) grid = max_grid;
+    const uint32_t max_grid = (uint32_t)g_num_cu * (uint32_t)g_tune_f32_wg_per_cu;
+    if (g_tune_f32_wg_per_cu > 0 && grid > max_grid) grid = max_grid;
     hipStream_t s = (hipStream_t)stream;
-    if (d_sad)
-        hipLaunchKernelGGL((fwd_quant_sad_32x32_kernel<true>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, d_pred,
-                           d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks);
-    else
-        hipLaunchKernelGGL((fwd_quant_sad_32x32_kernel<false>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, d_pred,
-                           d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks);
+#define F32_LAUNCH(SAD, MW)                                                                                        \
+    hipLaunchKernelGGL((fwd_quant_sad_32x32_kernel<SAD, MW>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, d_pred, \
+                       d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks)
+    // QMODE 2 needs power-of-two quant_shift (every av1_build_quantizer table); else the 24-bit general form
+#define F32_LAUNCH_Q(SAD, MW, NT, QM)                                                                              \
+    hipLaunchKernelGGL((fwd_quant_sad_32x32_kernel<SAD, MW, NT, QM>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, \
+                       d_pred, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks)
+    const bool fastq = qp.fast_ok && !g_tune_f32_qmode1;
+    if (g_tune_f32_nt) {
+        if (d_sad) F32_LAUNCH_Q(true, 1, true, 1); else F32_LAUNCH_Q(false, 1, true, 1);
+    } else if (!fastq) {
+        if (d_sad) F32_LAUNCH_Q(true, 1, false, 1); else F32_LAUNCH_Q(false, 1, false, 1);
+    } else if (g_tune_f32_min_waves == 4) {
+        if (d_sad) F32_LAUNCH_Q(true, 4, false, 2); else F32_LAUNCH_Q(false, 4, false, 2);
+    } else {
+        if (d_sad) F32_LAUNCH_Q(true, 1, false, 2); else F32_LAUNCH_Q(false, 1, false, 2);
+    }
+#undef F32_LAUNCH_Q
+#undef F32_LAUNCH
     return launch_status("fwd_quant_sad_32x32");
 }
 

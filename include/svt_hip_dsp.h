@@ -77,6 +77,10 @@ const char *svt_hip_last_error(void);
 /* "gfx950 ..." description of the device in use (empty string before init) */
 const char *svt_hip_device_name(void);
 
+/* performance-tuning knobs (never change results): "f32_min_waves" (1|4|5: register cap of
+ * the fused 32x32 kernel), "f32_wg_per_cu" (persistent grid = CUs x this; 0 = one-shot grid) */
+int svt_hip_tune(const char *key, int value);
+
 /* device memory helpers for C hosts that do not link the HIP runtime */
 void *svt_hip_malloc(size_t bytes);
 void svt_hip_free(void *dptr);

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Per-kernel throughput on the GPU box: algorithmic bytes / measured time vs the 8 TB/s
+HBM peak (SURVEY §8d figures).  Not the headline bench (bench.py) — a profiling aid whose
+table goes to profiles/rNN_kernels.json."""
+import json, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import __graft_entry__ as ge
+import svtlibs
+pkg = ge.load_package(); dsp = pkg.SvtHipDsp(0)
+dev = torch.device("cuda:0")
+TW, TH = pkg.TX_W, pkg.TX_H
+def timeit(fn, iters=8):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+rows = []
+def rec(name, n, bytes_per, ms, extra=None):
+    r = {"kernel": name, "units": n, "bytes_per_unit": bytes_per, "ms": round(ms, 4), "Munits_per_s": round(n / ms / 1e3, 2),
+         "GBps": round(bytes_per * n / ms / 1e6, 1), "frac_hbm_peak": round(bytes_per * n / ms / 1e6 / 8000, 4)}
+    if extra: r.update(extra)
+    rows.append(r); print(json.dumps(r), flush=True)
+qt = svtlibs.quant_tables(8); qrow = {k: v[100].copy() for k, v in qt.items()}
+only = sys.argv[1:] 
+def want(k): return not only or any(o in k for o in only)
+# forward transforms
+for s, n in ((0, 1 << 23), (1, 1 << 22), (2, 1 << 21), (3, 1 << 20), (4, 1 << 18), (9, 1 << 20), (16, 1 << 21)):
+    if not want("fwd_txfm"): break
+    w, h = TW[s], TH[s]
+    x = torch.randint(-255, 256, (n, h, w), dtype=torch.int16, device=dev)
+    out = torch.empty((n, w * h), dtype=torch.int32, device=dev)
+    ms = timeit(lambda: dsp.fwd_txfm2d(x, s, 0, 8, out=out))
+    rec(f"fwd_txfm2d_{w}x{h}", n, 6 * w * h, ms)
+    del x, out
+# quantize
+if want("quantize"):
+    for s, ls, n in ((3, 1, 1 << 20), (2, 0, 1 << 22)):
+        w, h = TW[s], TH[s]
+        c = torch.randint(-2000, 2001, (n, w * h), dtype=torch.int32, device=dev)
+        _, isc = svtlibs.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
+        ms = timeit(lambda: dsp.quantize_b(c, qrow, iscan, ls))
+        rec(f"quantize_b_{w}x{h}", n, 12 * w * h + 2, ms)
+        del c
+# generic fused chain
+for s, n in ((1, 1 << 22), (2, 1 << 21), (4, 1 << 18), (0, 1 << 23)):
+    if not want("fused_generic"): break
+    w, h = TW[s], TH[s]
+    src = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=dev); pred = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=dev)
+    _, isc = svtlibs.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
+    nc = min(w, 32) * min(h, 32)
+    outs = (torch.empty((n, nc), dtype=torch.int32, device=dev), torch.empty((n, nc), dtype=torch.int32, device=dev),
+            torch.empty((n, nc), dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int16, device=dev), torch.zeros(n, dtype=torch.int32, device=dev))
+    ms = timeit(lambda: dsp.fwd_quant_sad(src, pred, s, 0, qrow, iscan, outs=outs))
+    rec(f"fused_generic_{w}x{h}", n, 2 * w * h + 12 * nc + 6, ms)
+    del src, pred, outs
+# inverse
+for s, n in ((3, 1 << 20), (1, 1 << 22), (2, 1 << 21), (4, 1 << 18)):
+    if not want("inv_txfm"): break
+    w, h = TW[s], TH[s]
+    nc = min(w, 32) * min(h, 32)
+    c = torch.randint(-500, 501, (n, nc), dtype=torch.int32, device=dev)
+    d = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=dev)
+    ms = timeit(lambda: dsp.inv_txfm2d_add(c, d, s, 0, 8))
+    rec(f"inv_txfm2d_add_u8_{w}x{h}", n, 4 * nc + 2 * w * h, ms)
+    del c, d
+# SAD search C3
+if want("sad_search"):
+    n = 1 << 20
+    src = torch.randint(0, 256, (n, 16, 16), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 23, 23), dtype=torch.uint8, device=dev)
+    ms = timeit(lambda: dsp.sad_search(src, ref, 8, 8))
+    rec("sad_search_16x16_64cand(C3)", n, 797, ms, {"abs_diff_per_s_T": round(n * 64 * 256 / ms / 1e9, 2)})
+    del src, ref
+# plain sad / sse / residual 32x32
+if want("pixel"):
+    n = 1 << 21
+    a = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device=dev); b = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device=dev)
+    rec("sad_32x32", n, 2052, timeit(lambda: dsp.sad(a, b)))
+    rec("sse_32x32", n, 2056, timeit(lambda: dsp.sse(a, b)))
+    rec("residual_32x32", n, 4096, timeit(lambda: dsp.residual(a, b)))
+    del a, b
+# intra
+if want("intra"):
+    n = 1 << 21
+    ab = torch.randint(0, 256, (n, 160), dtype=torch.uint8, device=dev); lf = torch.randint(0, 256, (n, 160), dtype=torch.uint8, device=dev)
+    out = torch.empty((n, 32, 32), dtype=torch.uint8, device=dev)
+    for mode, nm in ((0, "dc"), (3, "smooth"), (6, "paeth"), (10, "z1"), (11, "z2")):
+        ms = timeit(lambda: dsp.intra_pred(ab, lf, mode, 32, 32, 8, 0, 0, 64, 64, out=out))
+        rec(f"intra_{nm}_32x32_u8", n, 1024 + 2 * 65, ms)
+    del ab, lf, out
+# ME 85-PU search, 1080p worth of SBs
+if want("me_sb"):
+    n = 510
+    src = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 127, 128), dtype=torch.uint8, device=dev)
+    ms = timeit(lambda: dsp.me_sb_search(src, ref, 64, 64), iters=4)
+    rec("me_sb_search_64x64area", n, 4096 + 127 * 127 + 680, ms, {"search_points_per_s_G": round(n * 4096 / ms / 1e6, 3)})
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "kernels.json"), "w"), indent=1)
