@@ -76,6 +76,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_upsample_intra_edge_batch.argtypes = [c_void_p, c_int32, c_int, c_int, c_int, c_size_t, c_void_p]
     L.svt_hip_full_distortion32_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t, c_uint32,
                                                   c_uint32, c_int, c_void_p, c_size_t, c_void_p]
+    L.svt_hip_fwd_quant_batch.argtypes = [c_void_p, c_size_t, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p] * 5 + [c_void_p]
     L.svt_hip_fwd_quant_planes_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_size_t, c_int, c_int,
                                                  c_int, c_int] + [c_void_p] * 5 + [c_void_p] * 7 + [c_void_p]
     L.svt_hip_me_sb_search_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t, c_int, c_int,
@@ -321,3 +322,20 @@ class SvtHipDsp:
                                                              self._p(en) if want_energy else None, self._stream()),
                     "svt_hip_fwd_quant_planes_batch")
         return co, q, dq, eob, sad, en
+
+    # -- configs[1]: FwdTxfm2d + quantize on a residual batch ----------------------------------
+    def fwd_quant(self, residual, tx_size, tx_type, qrow, iscan, bd=8, outs=None):
+        """residual: int16 [n, H, W] -> coeff, qcoeff, dqcoeff (int32 [n, W*H]), eob"""
+        t = self.torch
+        n = residual.shape[0]
+        nc = TX_W[tx_size] * TX_H[tx_size]
+        if outs is None:
+            outs = (t.empty((n, nc), dtype=t.int32, device=residual.device), t.empty((n, nc), dtype=t.int32, device=residual.device),
+                    t.empty((n, nc), dtype=t.int32, device=residual.device), t.zeros(n, dtype=t.int16, device=residual.device))
+        co, q, dq, eob = outs
+        tabs = [_np16(qrow[k]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
+        self._check(self.lib.svt_hip_fwd_quant_batch(self._p(residual), n, tx_size, tx_type, bd, tabs[0].ctypes.data,
+                                                      tabs[1].ctypes.data, tabs[2].ctypes.data, tabs[3].ctypes.data,
+                                                      tabs[4].ctypes.data, self._p(iscan), self._p(co), self._p(q),
+                                                      self._p(dq), self._p(eob), self._stream()), "svt_hip_fwd_quant_batch")
+        return outs

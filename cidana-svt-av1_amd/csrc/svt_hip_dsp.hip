@@ -280,6 +280,16 @@ extern "C" int svt_hip_fwd_txfm2d_batch(const int16_t* d_in, uint32_t in_stride,
     if (nblocks == 0) return SVT_HIP_OK;
     if (nblocks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "nblocks too large");
     hipStream_t s = (hipStream_t)stream;
+    if (tx_size == SVT_TX_32X32 && in_stride == 32 && in_block_pitch == 1024 && ((uintptr_t)d_in & 15) == 0 &&
+        ((uintptr_t)d_out & 15) == 0 && (tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX)) {
+        const uint32_t npairs = (uint32_t)((nblocks + 1) / 2);
+        QParams qp = {};
+        hipLaunchKernelGGL((fwd32_kernel<false, false, false>), dim3((npairs + F32_WAVES - 1) / F32_WAVES), dim3(F32_WAVES * 64), 0,
+                           s, (const void*)d_in, (const uint8_t*)nullptr, d_out, (int32_t*)nullptr, (int32_t*)nullptr,
+                           (uint16_t*)nullptr, (uint32_t*)nullptr, (const int16_t*)nullptr, qp, tx_type == SVT_IDTX ? 1 : 0,
+                           (uint32_t)nblocks);
+        return launch_status("fwd32");
+    }
 #define CALL(W, H) launch_fwd<W, H>(d_in, in_stride, in_block_pitch, d_out, nblocks, tx_type, s)
     TX_SWITCH(tx_size, CALL)
 #undef CALL
@@ -313,6 +323,16 @@ extern "C" int svt_hip_inv_txfm2d_add_batch(const int32_t* d_coeff, void* d_dst,
     if (!dst_is_16bit && bd != 8) return set_err(SVT_HIP_ERR_INVALID, "8-bit destination needs bd = 8");
     if (nblocks == 0) return SVT_HIP_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (tx_size == SVT_TX_32X32 && ((uintptr_t)d_coeff & 15) == 0 && (tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX)) {
+        const uint32_t grid = (uint32_t)((nblocks + 2 * F32_WAVES - 1) / (2 * F32_WAVES));
+        if (dst_is_16bit)
+            hipLaunchKernelGGL((inv32_kernel<uint16_t>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_coeff, (uint16_t*)d_dst, dst_stride,
+                               dst_block_pitch, d_dst_offsets, tx_type == SVT_IDTX ? 1 : 0, bd, (uint32_t)nblocks);
+        else
+            hipLaunchKernelGGL((inv32_kernel<uint8_t>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_coeff, (uint8_t*)d_dst, dst_stride,
+                               dst_block_pitch, d_dst_offsets, tx_type == SVT_IDTX ? 1 : 0, bd, (uint32_t)nblocks);
+        return launch_status("inv32");
+    }
 #define CALL(W, H) launch_inv<W, H>(d_coeff, d_dst, dst_is_16bit, dst_stride, dst_block_pitch, d_dst_offsets, nblocks, tx_type, bd, s)
     TX_SWITCH(tx_size, CALL)
 #undef CALL
@@ -358,7 +378,7 @@ extern "C" int svt_hip_fwd_quant_sad_batch(const uint8_t* d_src, const uint8_t* 
     if (nblocks == 0) return SVT_HIP_OK;
     if (!d_src || !d_pred || !d_coeff || !d_qcoeff || !d_dqcoeff || !d_eob || !d_iscan || !zbin || !round || !quant || !quant_shift || !dequant)
         return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
-    if (tx_size != SVT_TX_32X32 || tx_type != SVT_DCT_DCT)
+    if (tx_size != SVT_TX_32X32 || (tx_type != SVT_DCT_DCT && tx_type != SVT_IDTX))
         return svt_hip_fwd_quant_planes_batch(d_src, 0, d_pred, 0, nullptr, nblocks, 0, 8, tx_size, tx_type, zbin, round, quant,
                                               quant_shift, dequant, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad,
                                               nullptr, stream);
@@ -374,13 +394,11 @@ extern "C" int svt_hip_fwd_quant_sad_batch(const uint8_t* d_src, const uint8_t* 
     const uint32_t max_grid = (uint32_t)g_num_cu * (uint32_t)g_tune_f32_wg_per_cu;
     if (g_tune_f32_wg_per_cu > 0 && grid > max_grid) grid = max_grid;
     hipStream_t s = (hipStream_t)stream;
-#define F32_LAUNCH(SAD, MW)                                                                                        \
-    hipLaunchKernelGGL((fwd_quant_sad_32x32_kernel<SAD, MW>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, d_pred, \
-                       d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks)
     // QMODE 2 needs power-of-two quant_shift (every av1_build_quantizer table); else the 24-bit general form
 #define F32_LAUNCH_Q(SAD, MW, NT, QM)                                                                              \
-    hipLaunchKernelGGL((fwd_quant_sad_32x32_kernel<SAD, MW, NT, QM>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, \
-                       d_pred, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks)
+    hipLaunchKernelGGL((fwd32_kernel<true, true, SAD, MW, NT, QM>), dim3(grid), dim3(F32_WAVES * 64), 0, s,           \
+                       (const void*)d_src, d_pred, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp,           \
+                       tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks)
     const bool fastq = qp.fast_ok && !g_tune_f32_qmode1;
     if (g_tune_f32_nt) {
         if (d_sad) F32_LAUNCH_Q(true, 1, true, 1); else F32_LAUNCH_Q(false, 1, true, 1);
@@ -438,6 +456,36 @@ extern "C" int svt_hip_fwd_quant_planes_batch(const void* d_src, uint32_t src_st
 #define CALL(W, H) launch_fq<W, H>(d_src, src_stride, d_pred, pred_stride, d_xy, nblocks, is_16bit, tx_type, qp, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_energy, s)
     TX_SWITCH(tx_size, CALL)
 #undef CALL
+}
+
+extern "C" int svt_hip_fwd_quant_batch(const int16_t* d_residual, size_t nblocks, int tx_size, int tx_type, int bd,
+                                       const int16_t* zbin, const int16_t* round, const int16_t* quant,
+                                       const int16_t* quant_shift, const int16_t* dequant, const int16_t* d_iscan,
+                                       int32_t* d_coeff, int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob,
+                                       void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_residual || !d_coeff || !d_qcoeff || !d_dqcoeff || !d_eob || !d_iscan || !zbin || !round || !quant || !quant_shift || !dequant)
+        return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    if (!txfm_allowed(tx_size, tx_type)) return set_err(SVT_HIP_ERR_INVALID, "tx_size %d / tx_type %d not defined by the reference", tx_size, tx_type);
+    const int w = kTxW[tx_size], h = kTxH[tx_size];
+    const int pels = w * h, ls = pels > 1024 ? 2 : (pels > 256 ? 1 : 0);
+    hipStream_t s = (hipStream_t)stream;
+    const QParams qp = make_qparams(zbin, round, quant, quant_shift, dequant, ls);
+    if (tx_size == SVT_TX_32X32 && bd == 8 && qp.fast_ok && ((uintptr_t)d_residual & 15) == 0 &&
+        (tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX)) {
+        // 24-bit quantiser arithmetic needs 8-bit-range residuals (|coeff| < 2^17)
+        const uint32_t npairs = (uint32_t)((nblocks + 1) / 2);
+        hipLaunchKernelGGL((fwd32_kernel<false, true, false>), dim3((npairs + F32_WAVES - 1) / F32_WAVES), dim3(F32_WAVES * 64), 0, s,
+                           (const void*)d_residual, (const uint8_t*)nullptr, d_coeff, d_qcoeff, d_dqcoeff, d_eob,
+                           (uint32_t*)nullptr, d_iscan, qp, tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks);
+        return launch_status("fwd32_quant");
+    }
+    // general sizes: transform into d_coeff, pack 64-pt outputs, quantise (two more passes over d_coeff)
+    if (w == 64 || h == 64) return set_err(SVT_HIP_ERR_UNSUPPORTED, "use svt_hip_fwd_quant_planes_batch for 64-pt sizes (packed coefficient layout)");
+    if (int rc = svt_hip_fwd_txfm2d_batch(d_residual, (uint32_t)w, (size_t)w * h, d_coeff, nblocks, tx_size, tx_type, bd, stream)) return rc;
+    return svt_hip_quantize_b_batch(d_coeff, (size_t)w * h, 0, zbin, round, quant, quant_shift, d_qcoeff, d_dqcoeff, dequant, d_eob,
+                                    d_iscan, ls, nblocks, stream);
 }
 
 static int sad_sse_common(bool sse, const uint8_t* a, uint32_t as, size_t ap, const uint8_t* b, uint32_t bs,

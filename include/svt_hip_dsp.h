@@ -149,6 +149,15 @@ int svt_hip_fwd_quant_sad_batch(const uint8_t *d_src, const uint8_t *d_pred, siz
                                 const int16_t *d_iscan, int32_t *d_coeff, int32_t *d_qcoeff,
                                 int32_t *d_dqcoeff, uint16_t *d_eob, uint32_t *d_sad, void *stream);
 
+/* BASELINE.json configs[1]: FwdTxfm2d + quantize on a batch of int16 residual blocks
+ * (dense W*H per block) — av1_estimate_transform + av1_quantize_inv_quantize
+ * (EbFullLoop.c:763, 780).  TX_32X32 8-bit runs the tuned fused kernel. */
+int svt_hip_fwd_quant_batch(const int16_t *d_residual, size_t nblocks, int tx_size, int tx_type,
+                            int bd, const int16_t *zbin, const int16_t *round, const int16_t *quant,
+                            const int16_t *quant_shift, const int16_t *dequant,
+                            const int16_t *d_iscan, int32_t *d_coeff, int32_t *d_qcoeff,
+                            int32_t *d_dqcoeff, uint16_t *d_eob, void *stream);
+
 /* The same chain for EVERY transform size / type and for 8- or 16-bit sample planes
  * (Av1EncodeLoop EbCodingLoop.c:545-950, Av1EncodeLoop16bit :1020-1351): blocks are
  * addressed inside planes by d_xy[b] = (y << 16) | x (or, when d_xy == NULL, block b

@@ -460,3 +460,41 @@ def test_me_sb_search_85_pus(dsp, sw, sh):
     bs2, bm2 = dsp.me_sb_search(dev(src), dev((255 - ref)), sw, sh, origins=dev(org), best_sad=dev(bs.view(np.int32)), best_mv=dev(bm.view(np.int32)))
     b2 = bs2.cpu().numpy().view(np.uint32)
     assert (b2 <= bs).all()
+
+
+@pytest.mark.parametrize("tx_size,tx_type", [(3, 0), (3, 9), (2, 0), (1, 5), (9, 0)])
+@pytest.mark.parametrize("qindex", [0, 100, 255])
+def test_config2_fwd_quant_on_residual_batch(dsp, tx_size, tx_type, qindex):
+    """BASELINE.json configs[1]: FwdTxfm2d + quantize, int16 residual in (tuned 32x32 kernel + composed path)"""
+    O = svtlibs.oracle()
+    w, h = TX_W[tx_size], TX_H[tx_size]
+    rng = np.random.default_rng(tx_size + qindex)
+    n = 29
+    res = rng.integers(-255, 256, size=(n, h, w)).astype(np.int16)
+    res[0] = 255; res[1] = -255; res[2] = 0
+    qt = svtlibs.quant_tables(8)
+    qrow = {k: v[qindex].copy() for k, v in qt.items()}
+    scan, iscan = svtlibs.scan_tables(tx_size, tx_type)
+    co, q, dq, eob = dsp.fwd_quant(dev(res), tx_size, tx_type, qrow, dev(iscan))
+    ls = 1 if w * h > 256 else 0
+    for i in range(n):
+        rc = np.zeros(w * h, np.int32); rq = np.zeros(w * h, np.int32); rdq = np.zeros(w * h, np.int32); reob = np.zeros(1, np.uint16)
+        O.svt_oracle_fwd_txfm2d(ptr(res[i]), ptr(rc), ctypes.c_uint32(w), tx_type, tx_size, 8)
+        O.svt_oracle_quantize_b(ptr(rc), ctypes.c_ssize_t(w * h), 0, ptr(qrow["zbin"]), ptr(qrow["round"]), ptr(qrow["quant"]),
+                                ptr(qrow["quant_shift"]), ptr(rq), ptr(rdq), ptr(qrow["dequant"]), ptr(reob), ptr(scan), ptr(iscan), ls, 0)
+        assert np.array_equal(co[i].cpu().numpy(), rc) and np.array_equal(q[i].cpu().numpy(), rq)
+        assert np.array_equal(dq[i].cpu().numpy(), rdq) and int(eob[i].item()) & 0xffff == int(reob[0])
+
+
+def test_fused32_nonstandard_quant_tables_take_the_general_path(dsp):
+    """quant_shift that is not a power of two must still be exact (QMODE 1 fallback)"""
+    rng = np.random.default_rng(5)
+    src, pred = make_pixels(rng, 9, 32, 32, "random")
+    qrow = {"zbin": np.array([37, 41] + [41] * 6, np.int16), "round": np.array([19, 23] + [23] * 6, np.int16),
+            "quant": np.array([-12345, 7001] + [7001] * 6, np.int16), "quant_shift": np.array([12000, 777] + [777] * 6, np.int16),
+            "dequant": np.array([53, 61] + [61] * 6, np.int16)}
+    _, iscan = svtlibs.scan_tables(3, 0)
+    co, q, dq, eob, sad = dsp.fwd_quant_sad(dev(src), dev(pred), 3, 0, qrow, dev(iscan))
+    rco, rq, rdq, reob, rsad = oracle_chain(src, pred, 3, 0, qrow)
+    assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(dq.cpu().numpy(), rdq)
+    assert np.array_equal(eob.cpu().numpy().view(np.uint16), reob)
