@@ -208,7 +208,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_block": BYTES_PER_BLOCK, "kernel_ms": kernel_ms,
-                         "kernel": "fwd_quant_sad_32x32_kernel"},
+                         "kernel": "fwd32_kernel<IN_U8,QUANT,WITH_SAD>"},
             "device": dsp.device_name(),
         }
         if world == 1 and not args.no_cpu_baseline:
