@@ -15,7 +15,7 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libsvt_hip_dsp.so")
 SOURCES = ["csrc/svt_hip_dsp.hip"]
 DEPS = ["csrc/svt_hip_dsp.hip", "csrc/dev_common.h", "csrc/kernel_fused32.h", "csrc/kernel_txfm.h",
-        "csrc/kernel_pixel.h", "csrc/kernel_intra.h", "csrc/kernel_me.h", "csrc/gen/txfm1d_gen.h", "../include/svt_hip_dsp.h"]
+        "csrc/kernel_pixel.h", "csrc/kernel_intra.h", "csrc/kernel_me.h", "csrc/kernel_txfm_staged.h", "csrc/gen/txfm1d_gen.h", "../include/svt_hip_dsp.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-fwrapv",
                "-Wall", "-Wno-unused-function"]
 

@@ -1,0 +1,310 @@
+// kernel_txfm_staged.h — forward transforms / fused chain for DENSE block batches of
+// every size: same math as kernel_txfm.h, but all HBM traffic is 16 B per lane and
+// fully coalesced.  A wave's 64/max(W,H) blocks are contiguous in memory, so
+//   in : linear 16-B chunks -> LDS staging (padded per block: conflict-free column reads)
+//   out: rows -> XOR-swizzled LDS tile -> linear 16-B chunks (quantised in that order)
+// MODE 0: int16 residual -> coeff (av1_fwd_txfm2d_WxH, full W*H output)
+// MODE 1: u8 src + pred -> coeff, qcoeff, dqcoeff (packed min(W,32)*min(H,32)), eob, sad,
+//         three_quad_energy  (the headline chain for sizes other than 32x32)
+#pragma once
+#include "kernel_txfm.h"
+
+namespace svtdev {
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+template <int PELS> struct StagedWaves { static constexpr int N = PELS >= 4096 ? 2 : 4; };
+
+template <int W, int H>
+struct StagedGeom {
+    using G = TxGeom<W, H>;
+    static constexpr int WAVES = StagedWaves<W * H>::N;
+    static constexpr int KW = W > 32 ? 32 : W, KH = H > 32 ? 32 : H, NC = KW * KH;
+    // out tile: row r, 16-B slot s -> slot s ^ ((r / RDIV) & SMASK)   (conflict-free b128 row writes)
+    static constexpr int NS = W / 4;
+    static constexpr int RDIV = (8 / NS) > 1 ? (8 / NS) : 1;
+    static constexpr int SMASK = (NS < 8 ? NS : 8) - 1;
+    __device__ static __forceinline__ int out_addr(int sub, int r, int s) {
+        return sub * (W * H * 4) + r * (W * 4) + ((s ^ ((r / RDIV) & SMASK)) << 4);
+    }
+};
+
+template <int W, int H, int MODE>
+__global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void fwd_staged_kernel(
+    const void* __restrict__ in0, const uint8_t* __restrict__ pred, int32_t* __restrict__ coeff,
+    int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff, uint16_t* __restrict__ eob,
+    uint32_t* __restrict__ sad, unsigned long long* __restrict__ energy, const int16_t* __restrict__ iscan,
+    QParams qp, int tx_type, uint32_t nblocks) {
+    using S = StagedGeom<W, H>;
+    using G = TxGeom<W, H>;
+    constexpr bool FUSED = MODE == 1;
+    constexpr int ES = FUSED ? 1 : 2;
+    constexpr int BB = W * H * ES;                       // input bytes per block and array
+    constexpr int PADI = (W * ES >= 32) ? 32 : 16;       // staging pad per block
+    constexpr int IN_ONE = G::BPW * (BB + PADI);
+    constexpr int IN_BYTES = IN_ONE * (FUSED ? 2 : 1);
+    constexpr int TILE_BYTES = G::BPW * G::TILE * 4;
+    constexpr int OUT_BYTES = G::BPW * W * H * 4;
+    constexpr int WAVE_LDS = (cmax(cmax(IN_BYTES, TILE_BYTES), OUT_BYTES) + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) char lds[S::WAVES * WAVE_LDS];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* wl = lds + wave * WAVE_LDS;
+    const uint32_t first = (blockIdx.x * S::WAVES + wave) * G::BPW;
+    if (first >= nblocks) return;                         // wave-uniform
+    const int sub = lane / G::LPB, l = lane % G::LPB;
+    const uint32_t blk = first + sub;
+    const bool valid = blk < nblocks;
+    const int vk = kVKind[tx_type], hk = kHKind[tx_type];
+    const bool ud = vk == K1D_FLIPADST, lr = hk == K1D_FLIPADST;
+    constexpr int CBC = fwd_cos_col(W, H), CBR = fwd_cos_row(W, H);
+    constexpr int S0 = fwd_shift(W, H, 0), S1 = fwd_shift(W, H, 1), S2 = fwd_shift(W, H, 2);
+
+    // ---- stage the wave's input: linear 16-B chunks ---------------------------------------
+    {
+        constexpr int NCH = G::BPW * BB / 16;
+        const char* g0 = static_cast<const char*>(in0) + (size_t)first * BB;
+        const char* g1 = FUSED ? reinterpret_cast<const char*>(pred) + (size_t)first * BB : nullptr;
+#pragma unroll
+        for (int q0 = 0; q0 < NCH; q0 += 64) {
+            const int q = q0 + lane;
+            if (NCH % 64 == 0 || q < NCH) {
+                const int b = (q * 16) / BB;
+                const bool ok = first + b < nblocks;
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                *reinterpret_cast<uint4*>(wl + q * 16 + b * PADI) = ok ? *reinterpret_cast<const uint4*>(g0 + (size_t)q * 16) : z;
+                if (FUSED)
+                    *reinterpret_cast<uint4*>(wl + IN_ONE + q * 16 + b * PADI) = ok ? *reinterpret_cast<const uint4*>(g1 + (size_t)q * 16) : z;
+            }
+        }
+    }
+    wave_lds_fence();
+    // ---- column pass ----------------------------------------------------------------------
+    unsigned sad_acc = 0;
+    int x[H];
+    if (l < W) {
+        const char* bs = wl + sub * (BB + PADI);
+#pragma unroll
+        for (int r = 0; r < H; r++) {
+            const int idx = (ud ? H - 1 - r : r) * W + l;
+            int d;
+            if (FUSED) {
+                d = (int)*reinterpret_cast<const uint8_t*>(bs + idx) - (int)*reinterpret_cast<const uint8_t*>(bs + IN_ONE + idx);
+                sad_acc += (unsigned)(d < 0 ? -d : d);
+            } else {
+                d = *reinterpret_cast<const short*>(bs + idx * 2);
+            }
+            x[r] = round_shift_c<-S0>(d);
+        }
+        fwd1d<H, CBC>(vk, x);
+    }
+    wave_lds_fence();                                     // staging is dead: the tile may overwrite it
+    int32_t* tile = reinterpret_cast<int32_t*>(wl) + sub * G::TILE;
+    if (l < W) {
+        const int cdst = lr ? W - 1 - l : l;
+#pragma unroll
+        for (int r = 0; r < H; r++) tile[r * G::PITCH + cdst] = round_shift_c<-S1>(x[r]);
+    }
+    wave_lds_fence();
+    // ---- row pass -------------------------------------------------------------------------
+    unsigned long long en = 0;
+    int y[W];
+    if (l < H) {
+#pragma unroll
+        for (int c = 0; c < W; c++) y[c] = tile[l * G::PITCH + c];
+        fwd1d<W, CBR>(hk, y);
+#pragma unroll
+        for (int c = 0; c < W; c++) {
+            int t = round_shift_c<-S2>(y[c]);
+            if (G::RECT2) t = mul_q12(t, 5793);
+            y[c] = t;
+        }
+        if (FUSED && (W > 32 || H > 32)) {
+#pragma unroll
+            for (int c = 0; c < W; c++)
+                if (l >= S::KH || c >= S::KW) { const long long v = y[c]; en += (unsigned long long)(v * v); }
+        }
+    }
+    wave_lds_fence();                                     // tile is dead: the out tile may overwrite it
+    if (l < H) {
+#pragma unroll
+        for (int s = 0; s < W / 4; s++)
+            *reinterpret_cast<int4*>(wl + S::out_addr(sub, l, s)) = make_int4(y[4 * s], y[4 * s + 1], y[4 * s + 2], y[4 * s + 3]);
+    }
+    wave_lds_fence();
+    if (FUSED) {
+        sad_acc = group_sum<G::LPB>(sad_acc);
+        if (W > 32 || H > 32) en = group_sum64<G::LPB>(en);
+        if (valid && l == 0) {
+            if (sad) sad[blk] = sad_acc;
+            if (energy) energy[blk] = en;
+        }
+    }
+    // ---- linear phase: coalesced stores (and quantisation) ----------------------------------
+    if (!FUSED) {
+        constexpr int CPB = W * H / 4;                    // chunks per block
+        constexpr int NOUT = G::BPW * CPB;
+        int4* o4 = reinterpret_cast<int4*>(coeff + (size_t)first * (W * H));
+#pragma unroll
+        for (int q0 = 0; q0 < NOUT; q0 += 64) {
+            const int q = q0 + lane;
+            if (NOUT % 64 == 0 || q < NOUT) {
+                const int b = q / CPB, w4 = q % CPB;
+                const int4 v = *reinterpret_cast<const int4*>(wl + S::out_addr(b, w4 / (W / 4), w4 % (W / 4)));
+                if (first + b < nblocks) o4[q] = v;
+            }
+        }
+    } else {
+        constexpr int CPB = S::NC / 4;
+        constexpr int NOUT = G::BPW * CPB;
+        int eob_acc = 0;
+#pragma unroll
+        for (int q0 = 0; q0 < NOUT; q0 += 64) {
+            const int q = q0 + lane;
+            const bool act = (NOUT % 64 == 0) || q < NOUT;
+            const int b = act ? q / CPB : 0, w4 = act ? q % CPB : 0;
+            const bool ok = act && (first + b < nblocks);
+            const int4 c = *reinterpret_cast<const int4*>(wl + S::out_addr(b, w4 / (S::KW / 4), w4 % (S::KW / 4)));
+            int4 qv, dv;
+            // QMODE 2: the host only takes this kernel when quant_shift is a power of two
+            quant_one<2>(c.x, w4 == 0 ? 0 : 1, qp, qv.x, dv.x);
+            quant_one<2>(c.y, 1, qp, qv.y, dv.y);
+            quant_one<2>(c.z, 1, qp, qv.z, dv.z);
+            quant_one<2>(c.w, 1, qp, qv.w, dv.w);
+            const uint2 is = *reinterpret_cast<const uint2*>(iscan + w4 * 4);
+            int e = max(max(qv.x ? (int)(is.x & 0xffffu) + 1 : 0, qv.y ? (int)(is.x >> 16) + 1 : 0),
+                        max(qv.z ? (int)(is.y & 0xffffu) + 1 : 0, qv.w ? (int)(is.y >> 16) + 1 : 0));
+            if (!act) e = 0;
+            if (ok) {
+                const size_t o = (size_t)(first + b) * S::NC + (size_t)w4 * 4;
+                *reinterpret_cast<int4*>(coeff + o) = c;
+                *reinterpret_cast<int4*>(qcoeff + o) = qv;
+                *reinterpret_cast<int4*>(dqcoeff + o) = dv;
+            }
+            if constexpr (CPB >= 64) {                    // one block spans CPB/64 iterations of the whole wave
+                eob_acc = max(eob_acc, e);
+                if (((q0 / 64) + 1) % (CPB / 64) == 0) {
+                    const int m = group_max<64>(eob_acc);
+                    if (lane == 0 && ok) eob[first + b] = (uint16_t)m;
+                    eob_acc = 0;
+                }
+            } else {                                      // 64/CPB blocks per iteration
+                const int m = group_max<(CPB < 64 ? CPB : 64)>(e);
+                if (ok && w4 == 0) eob[first + b] = (uint16_t)m;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// inverse + add for DENSE batches (coefficients packed KW*KH per block, destination
+// blocks W*H samples back to back): linear coefficient chunks -> padded LDS rows ->
+// row pass -> transpose tile -> column pass -> int16 residual tile in row order ->
+// destination read / add / clip / write in linear 16-B chunks.
+// Math == inv_txfm2d_add_kernel (kernel_txfm.h) == inv_txfm2d_add_c (EbTransforms.c:8180).
+// ---------------------------------------------------------------------------
+template <int W, int H, typename PixT>
+__global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
+    const int32_t* __restrict__ in, PixT* __restrict__ dst, int tx_type, int bd, uint32_t nblocks) {
+    using S = StagedGeom<W, H>;
+    using G = TxGeom<W, H>;
+    constexpr int KW = S::KW, KH = S::KH, NC = S::NC;
+    constexpr int PQ = (KW == 4) ? 3 : KW / 4 + 1;       // row pitch of the coefficient tile in 16-B units (odd-ish: conflict-free b128 row reads)
+    constexpr int IN_BYTES = G::BPW * KH * PQ * 16;
+    constexpr int TILE_BYTES = G::BPW * G::TILE * 4;
+    constexpr int RES_BYTES = G::BPW * W * H * 2;
+    constexpr int WAVE_LDS = (cmax(cmax(IN_BYTES, TILE_BYTES), RES_BYTES) + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) char lds[S::WAVES * WAVE_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* wl = lds + wave * WAVE_LDS;
+    const uint32_t first = (blockIdx.x * S::WAVES + wave) * G::BPW;
+    if (first >= nblocks) return;
+    const int sub = lane / G::LPB, l = lane % G::LPB;
+    const int vk = kVKind[tx_type], hk = kHKind[tx_type];
+    const bool ud = vk == K1D_FLIPADST, lr = hk == K1D_FLIPADST;
+    const int row_bits = bd == 8 ? 16 : (bd == 10 ? 18 : 20);
+    const int col_bits = bd == 12 ? 18 : 16;
+    const int in_bits = bd + 8;
+    const int colin_bits = bd + 6 > 16 ? bd + 6 : 16;
+    constexpr int S0 = inv_shift0(W, H);
+    // ---- stage coefficients ----------------------------------------------------------------
+    {
+        constexpr int CPB = NC / 4, NCH = G::BPW * CPB;
+        const int4* g = reinterpret_cast<const int4*>(in + (size_t)first * NC);
+#pragma unroll
+        for (int q0 = 0; q0 < NCH; q0 += 64) {
+            const int q = q0 + lane;
+            if (NCH % 64 == 0 || q < NCH) {
+                const int b = q / CPB, w4 = q % CPB;
+                const int4 v = (first + b < nblocks) ? g[q] : make_int4(0, 0, 0, 0);
+                *reinterpret_cast<int4*>(wl + ((b * KH + w4 / (KW / 4)) * PQ + w4 % (KW / 4)) * 16) = v;
+            }
+        }
+    }
+    wave_lds_fence();
+    // ---- row pass ----------------------------------------------------------------------------
+    int x[W];
+    if (l < H) {
+        if (l < KH) {
+#pragma unroll
+            for (int s = 0; s < KW / 4; s++) {
+                const int4 v = *reinterpret_cast<const int4*>(wl + ((sub * KH + l) * PQ + s) * 16);
+                x[4 * s] = v.x; x[4 * s + 1] = v.y; x[4 * s + 2] = v.z; x[4 * s + 3] = v.w;
+            }
+#pragma unroll
+            for (int c = 0; c < W; c++) {
+                int v = c < KW ? x[c] : 0;
+                if (G::RECT2) v = mul_q12(v, 2896);
+                x[c] = svtgen::svt_clamp(v, -(1 << (in_bits - 1)), (1 << (in_bits - 1)) - 1);
+            }
+            inv1d<W>(hk, x, -(1 << (row_bits - 1)), (1 << (row_bits - 1)) - 1);
+        } else {
+#pragma unroll
+            for (int c = 0; c < W; c++) x[c] = 0;
+        }
+    }
+    wave_lds_fence();
+    int32_t* tile = reinterpret_cast<int32_t*>(wl) + sub * G::TILE;
+    if (l < H) {
+#pragma unroll
+        for (int c = 0; c < W; c++) tile[l * G::PITCH + c] = round_shift_c<-S0>(x[c]);
+    }
+    wave_lds_fence();
+    // ---- column pass -------------------------------------------------------------------------
+    int y[H];
+    if (l < W) {
+        const int csrc = lr ? W - 1 - l : l;
+#pragma unroll
+        for (int r = 0; r < H; r++)
+            y[r] = svtgen::svt_clamp(tile[r * G::PITCH + csrc], -(1 << (colin_bits - 1)), (1 << (colin_bits - 1)) - 1);
+        inv1d<H>(vk, y, -(1 << (col_bits - 1)), (1 << (col_bits - 1)) - 1);
+    }
+    wave_lds_fence();
+    if (l < W) {
+        short* res = reinterpret_cast<short*>(wl) + sub * (W * H);
+#pragma unroll
+        for (int r = 0; r < H; r++) res[r * W + l] = (short)round_shift_c<4>(y[ud ? H - 1 - r : r]);
+    }
+    wave_lds_fence();
+    // ---- destination: linear 16-B chunks --------------------------------------------------------
+    {
+        constexpr int PPL = 16 / (int)sizeof(PixT);
+        constexpr int CPB = W * H / PPL, NCH = G::BPW * CPB;
+        static_assert(W * H % PPL == 0, "block must be a whole number of 16-B chunks");
+        const int maxpix = (1 << bd) - 1;
+        uint4* d4 = reinterpret_cast<uint4*>(dst + (size_t)first * (W * H));
+#pragma unroll
+        for (int q0 = 0; q0 < NCH; q0 += 64) {
+            const int q = q0 + lane;
+            if ((NCH % 64 == 0 || q < NCH) && (first + q / CPB < nblocks)) {
+                const short* rs = reinterpret_cast<const short*>(wl) + (size_t)q * PPL;
+                uint4 pv = d4[q];
+                PixT* px = reinterpret_cast<PixT*>(&pv);
+#pragma unroll
+                for (int j = 0; j < PPL; j++) px[j] = (PixT)min(max((int)px[j] + (int)rs[j], 0), maxpix);
+                d4[q] = pv;
+            }
+        }
+    }
+}
+
+}  // namespace svtdev

@@ -17,6 +17,7 @@
 #include "kernel_me.h"
 #include "kernel_pixel.h"
 #include "kernel_txfm.h"
+#include "kernel_txfm_staged.h"
 
 using namespace svtdev;
 
@@ -33,6 +34,7 @@ int g_tune_f32_min_waves = 1;
 int g_tune_f32_wg_per_cu = 0;
 int g_tune_f32_nt = 0;
 int g_tune_f32_qmode1 = 0;
+int g_tune_no_staged = 0;
 
 int set_err(int code, const char* fmt, ...) {
     va_list ap;
@@ -132,6 +134,34 @@ int launch_fwd(const int16_t* in, uint32_t in_stride, size_t pitch, int32_t* out
     hipLaunchKernelGGL((fwd_txfm2d_kernel<W, H>), dim3(grid), dim3(TX_WAVES * 64), 0, s, in, out, in_stride,
                        pitch, tx_type, (uint32_t)n);
     return launch_status("fwd_txfm2d");
+}
+template <int W, int H>
+int launch_fwd_staged(const int16_t* in, int32_t* out, size_t n, int tx_type, hipStream_t s) {
+    using SG = StagedGeom<W, H>;
+    const uint32_t per_wg = SG::WAVES * TxGeom<W, H>::BPW;
+    QParams qp = {};
+    hipLaunchKernelGGL((fwd_staged_kernel<W, H, 0>), dim3((uint32_t)((n + per_wg - 1) / per_wg)), dim3(SG::WAVES * 64), 0, s,
+                       (const void*)in, (const uint8_t*)nullptr, out, (int32_t*)nullptr, (int32_t*)nullptr, (uint16_t*)nullptr,
+                       (uint32_t*)nullptr, (unsigned long long*)nullptr, (const int16_t*)nullptr, qp, tx_type, (uint32_t)n);
+    return launch_status("fwd_staged");
+}
+template <int W, int H>
+int launch_fq_staged(const uint8_t* src, const uint8_t* pred, size_t n, int tx_type, const QParams& qp, const int16_t* iscan,
+                     int32_t* co, int32_t* q, int32_t* dq, uint16_t* eob, uint32_t* sad, uint64_t* energy, hipStream_t s) {
+    using SG = StagedGeom<W, H>;
+    const uint32_t per_wg = SG::WAVES * TxGeom<W, H>::BPW;
+    hipLaunchKernelGGL((fwd_staged_kernel<W, H, 1>), dim3((uint32_t)((n + per_wg - 1) / per_wg)), dim3(SG::WAVES * 64), 0, s,
+                       (const void*)src, pred, co, q, dq, eob, sad, (unsigned long long*)energy, iscan, qp, tx_type, (uint32_t)n);
+    return launch_status("fwd_quant_staged");
+}
+template <int W, int H>
+int launch_inv_staged(const int32_t* in, void* dst, int is16, size_t n, int tx_type, int bd, hipStream_t s) {
+    using SG = StagedGeom<W, H>;
+    const uint32_t per_wg = SG::WAVES * TxGeom<W, H>::BPW;
+    const uint32_t grid = (uint32_t)((n + per_wg - 1) / per_wg);
+    if (is16) hipLaunchKernelGGL((inv_staged_kernel<W, H, uint16_t>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint16_t*)dst, tx_type, bd, (uint32_t)n);
+    else hipLaunchKernelGGL((inv_staged_kernel<W, H, uint8_t>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint8_t*)dst, tx_type, bd, (uint32_t)n);
+    return launch_status("inv_staged");
 }
 template <int W, int H>
 int launch_inv(const int32_t* in, void* dst, int is16, int32_t stride, size_t pitch, const uint32_t* offs,
@@ -242,6 +272,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "f32_wg_per_cu")) { g_tune_f32_wg_per_cu = value; return SVT_HIP_OK; }
     if (!strcmp(key, "f32_nt")) { g_tune_f32_nt = value; return SVT_HIP_OK; }
     if (!strcmp(key, "f32_qmode1")) { g_tune_f32_qmode1 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_staged")) { g_tune_no_staged = value; return SVT_HIP_OK; }
     return set_err(SVT_HIP_ERR_INVALID, "unknown tuning key %s", key);
 }
 extern "C" const char* svt_hip_device_name(void) { return g_devname; }
@@ -290,6 +321,12 @@ extern "C" int svt_hip_fwd_txfm2d_batch(const int16_t* d_in, uint32_t in_stride,
                            (uint32_t)nblocks);
         return launch_status("fwd32");
     }
+    if (!g_tune_no_staged && in_stride == (uint32_t)kTxW[tx_size] && in_block_pitch == (size_t)kTxW[tx_size] * kTxH[tx_size] &&
+        ((uintptr_t)d_in & 15) == 0 && ((uintptr_t)d_out & 15) == 0) {
+#define CALLS(W, H) launch_fwd_staged<W, H>(d_in, d_out, nblocks, tx_type, s)
+        TX_SWITCH(tx_size, CALLS)
+#undef CALLS
+    }
 #define CALL(W, H) launch_fwd<W, H>(d_in, in_stride, in_block_pitch, d_out, nblocks, tx_type, s)
     TX_SWITCH(tx_size, CALL)
 #undef CALL
@@ -332,6 +369,12 @@ extern "C" int svt_hip_inv_txfm2d_add_batch(const int32_t* d_coeff, void* d_dst,
             hipLaunchKernelGGL((inv32_kernel<uint8_t>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_coeff, (uint8_t*)d_dst, dst_stride,
                                dst_block_pitch, d_dst_offsets, tx_type == SVT_IDTX ? 1 : 0, bd, (uint32_t)nblocks);
         return launch_status("inv32");
+    }
+    if (!g_tune_no_staged && !d_dst_offsets && dst_stride == kTxW[tx_size] && dst_block_pitch == (size_t)kTxW[tx_size] * kTxH[tx_size] &&
+        ((uintptr_t)d_coeff & 15) == 0 && ((uintptr_t)d_dst & 15) == 0 && (kTxW[tx_size] * kTxH[tx_size] * (dst_is_16bit ? 2 : 1)) % 16 == 0) {
+#define CALLS(W, H) launch_inv_staged<W, H>(d_coeff, d_dst, dst_is_16bit, nblocks, tx_type, bd, s)
+        TX_SWITCH(tx_size, CALLS)
+#undef CALLS
     }
 #define CALL(W, H) launch_inv<W, H>(d_coeff, d_dst, dst_is_16bit, dst_stride, dst_block_pitch, d_dst_offsets, nblocks, tx_type, bd, s)
     TX_SWITCH(tx_size, CALL)
@@ -453,6 +496,12 @@ extern "C" int svt_hip_fwd_quant_planes_batch(const void* d_src, uint32_t src_st
     for (int i = 0; i < 2; i++)
         if (qp.quant_shift[i] < 0 || qp.dequant[i] < 0 || qp.round[i] < 0) return set_err(SVT_HIP_ERR_INVALID, "negative quantizer table entry");
     hipStream_t s = (hipStream_t)stream;
+    if (!g_tune_no_staged && qp.fast_ok && pels > 16 && !d_xy && !is_16bit && ((uintptr_t)d_src & 15) == 0 && ((uintptr_t)d_pred & 15) == 0 &&
+        ((uintptr_t)d_coeff & 15) == 0 && ((uintptr_t)d_qcoeff & 15) == 0 && ((uintptr_t)d_dqcoeff & 15) == 0) {
+#define CALLS(W, H) launch_fq_staged<W, H>((const uint8_t*)d_src, (const uint8_t*)d_pred, nblocks, tx_type, qp, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_energy, s)
+        TX_SWITCH(tx_size, CALLS)
+#undef CALLS
+    }
 #define CALL(W, H) launch_fq<W, H>(d_src, src_stride, d_pred, pred_stride, d_xy, nblocks, is_16bit, tx_type, qp, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_energy, s)
     TX_SWITCH(tx_size, CALL)
 #undef CALL
