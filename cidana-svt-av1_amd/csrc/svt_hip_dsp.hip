@@ -35,6 +35,7 @@ int g_tune_f32_wg_per_cu = 0;
 int g_tune_f32_nt = 0;
 int g_tune_f32_qmode1 = 0;
 int g_tune_no_staged = 0;
+int g_tune_no_qsad = 0;
 
 int set_err(int code, const char* fmt, ...) {
     va_list ap;
@@ -273,6 +274,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "f32_nt")) { g_tune_f32_nt = value; return SVT_HIP_OK; }
     if (!strcmp(key, "f32_qmode1")) { g_tune_f32_qmode1 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_staged")) { g_tune_no_staged = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_qsad")) { g_tune_no_qsad = value; return SVT_HIP_OK; }
     return set_err(SVT_HIP_ERR_INVALID, "unknown tuning key %s", key);
 }
 extern "C" const char* svt_hip_device_name(void) { return g_devname; }
@@ -592,10 +594,37 @@ extern "C" int svt_hip_sad_search_batch(const uint8_t* d_src, uint32_t src_strid
     if (search_area_width <= 0 || search_area_height <= 0) return set_err(SVT_HIP_ERR_INVALID, "empty search area");
     if (nblocks == 0) return SVT_HIP_OK;
     const uint32_t win_w = width + search_area_width - 1;
-    const uint32_t wpitch = (win_w + 3 + 8) & ~3u;
-    const uint32_t spitch = (width + 3) & ~3u;
     const bool plain = ref_stride == ref_stride_raw;
     const uint32_t nrows = plain ? (uint32_t)(search_area_height + height - 1) : (uint32_t)search_area_height * height;
+    if ((width & 3) == 0 && !g_tune_no_qsad) {
+        // quad-SAD kernel: 4 candidates per lane
+        const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+        const uint32_t src_bytes = (width * height + 15) & ~15u;
+        const uint32_t ref_bytes = (wpitch * nrows + 16 + 15) & ~15u;
+        const uint32_t per_blk = src_bytes + ref_bytes;
+        if (per_blk > 64 * 1024) return set_err(SVT_HIP_ERR_INVALID, "search window needs %u B of LDS per block (> 64 KiB)", per_blk);
+        const uint32_t groups = (uint32_t)((search_area_width + 3) / 4) * (uint32_t)search_area_height;
+        uint32_t lpb = 1;
+        while (lpb < groups && lpb < 64) lpb <<= 1;
+        uint32_t threads = 256;
+        while (threads > lpb && (size_t)(threads / lpb) * per_blk > 64 * 1024) threads >>= 1;
+        const uint32_t slots = threads / lpb;
+        const uint32_t grid = (uint32_t)((nblocks + slots - 1) / slots);
+#define SSQ(CW, CH)                                                                                                     \
+    hipLaunchKernelGGL((sad_search_q_kernel<CW, CH>), dim3(grid), dim3(threads), (size_t)slots * per_blk, (hipStream_t)stream, \
+                       d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_stride_raw, ref_block_pitch, width, height,  \
+                       (int)search_area_width, (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, src_bytes, \
+                       ref_bytes, lpb, (uint32_t)nblocks)
+        if (width == 16 && height == 16) SSQ(16, 16);
+        else if (width == 8 && height == 8) SSQ(8, 8);
+        else if (width == 32 && height == 32) SSQ(32, 32);
+        else if (width == 64 && height == 64) SSQ(64, 64);
+        else SSQ(0, 0);
+#undef SSQ
+        return launch_status("sad_search_q");
+    }
+    const uint32_t wpitch = (win_w + 3 + 8) & ~3u;
+    const uint32_t spitch = (width + 3) & ~3u;
     const uint32_t src_bytes = (spitch * height + 15) & ~15u;
     const uint32_t ref_bytes = (wpitch * nrows + 16 + 15) & ~15u;
     const uint32_t per_wave = src_bytes + ref_bytes;

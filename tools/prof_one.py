@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Run ONE kernel a few times (for rocprofv3 --pmc / --kernel-trace).  usage: prof_one.py <name>"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import __graft_entry__ as ge
+import svtlibs
+pkg = ge.load_package(); dsp = pkg.SvtHipDsp(0)
+dev = torch.device("cuda:0")
+name = sys.argv[1]
+qt = svtlibs.quant_tables(8); qrow = {k: v[100].copy() for k, v in qt.items()}
+if name == "sad_search":
+    n = 1 << 20
+    src = torch.randint(0, 256, (n, 16, 16), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 23, 23), dtype=torch.uint8, device=dev)
+    fn = lambda: dsp.sad_search(src, ref, 8, 8)
+elif name == "inv32":
+    n = 1 << 20
+    c = torch.randint(-500, 501, (n, 1024), dtype=torch.int32, device=dev); d = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device=dev)
+    fn = lambda: dsp.inv_txfm2d_add(c, d, 3, 0, 8)
+elif name == "intra_dc":
+    n = 1 << 21
+    ab = torch.randint(0, 256, (n, 160), dtype=torch.uint8, device=dev); lf = torch.randint(0, 256, (n, 160), dtype=torch.uint8, device=dev)
+    out = torch.empty((n, 32, 32), dtype=torch.uint8, device=dev)
+    fn = lambda: dsp.intra_pred(ab, lf, 0, 32, 32, 8, out=out)
+elif name == "me_sb":
+    n = 510
+    src = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 127, 128), dtype=torch.uint8, device=dev)
+    fn = lambda: dsp.me_sb_search(src, ref, 64, 64)
+else:
+    raise SystemExit("unknown " + name)
+for _ in range(5): fn()
+torch.cuda.synchronize()
