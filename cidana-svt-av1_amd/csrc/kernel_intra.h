@@ -32,91 +32,122 @@ __device__ constexpr uint8_t kSmWeights[128] = {
 // above_row / left_col lives at index NB_ORIGIN + p (p >= -2).
 constexpr int NB_ORIGIN = 16;
 
-template <typename PixT>
+template <typename PixT, int MODE>
+__device__ __forceinline__ void intra_row(PixT (&out)[16 / sizeof(PixT)], const PixT* __restrict__ above,
+                                          const PixT* __restrict__ left, int r, int c0, int ppl, int bw, int bh, int wh,
+                                          int dc, int up_above, int up_left, int dx, int dy, int maxv) {
+    constexpr int PXL = 16 / (int)sizeof(PixT);
+    PixT ab[PXL];                                          // above[c0 .. c0+ppl-1] in one wide load
+    if (MODE == IM_V || MODE == IM_SMOOTH || MODE == IM_SMOOTH_V || MODE == IM_PAETH) {
+        if (ppl == PXL) __builtin_memcpy(ab, above + c0, 16);
+        else {
+#pragma unroll
+            for (int k = 0; k < PXL; k++) ab[k] = k < ppl ? above[c0 + k] : (PixT)0;
+        }
+    }
+    const int lft = (MODE == IM_H || MODE == IM_SMOOTH || MODE == IM_SMOOTH_H || MODE == IM_PAETH) ? (int)left[r] : 0;
+    const int bl = (MODE == IM_SMOOTH || MODE == IM_SMOOTH_V) ? (int)left[bh - 1] : 0;
+    const int tr = (MODE == IM_SMOOTH || MODE == IM_SMOOTH_H) ? (int)above[bw - 1] : 0;
+    const int tl = MODE == IM_PAETH ? (int)above[-1] : 0;
+#pragma unroll
+    for (int k = 0; k < PXL; k++) {
+        const int c = c0 + (k < ppl ? k : 0);          // lanes of narrow blocks recompute pixel 0 (discarded)
+        int v;
+        if (MODE == IM_V) v = ab[k];
+        else if (MODE == IM_H) v = lft;
+        else if (MODE == IM_SMOOTH) {
+            const int ww = kSmWeights[bw + c];
+            v = (wh * ab[k] + (256 - wh) * bl + ww * lft + (256 - ww) * tr + 256) >> 9;
+        } else if (MODE == IM_SMOOTH_V) v = (wh * ab[k] + (256 - wh) * bl + 128) >> 8;
+        else if (MODE == IM_SMOOTH_H) {
+            const int ww = kSmWeights[bw + c];
+            v = (ww * lft + (256 - ww) * tr + 128) >> 8;
+        } else if (MODE == IM_PAETH) {
+            const int t = ab[k];
+            const int base = t + lft - tl;
+            const int pl = abs(base - lft), pt = abs(base - t), ptl = abs(base - tl);
+            v = (pl <= pt && pl <= ptl) ? lft : (pt <= ptl ? t : tl);
+        } else if (MODE == IM_Z1) {
+            const int x = dx * (r + 1);
+            const int base = (x >> (6 - up_above)) + (c << up_above);
+            const int sh = ((x << up_above) & 0x3f) >> 1;
+            const int max_base = (bw + bh - 1) << up_above;
+            if (base < max_base) v = min(max((above[base] * (32 - sh) + above[base + 1] * sh + 16) >> 5, 0), maxv);
+            else v = above[max_base];
+        } else if (MODE == IM_Z3) {
+            const int y = dy * (c + 1);
+            const int base = (y >> (6 - up_left)) + (r << up_left);
+            const int sh = ((y << up_left) & 0x3f) >> 1;
+            const int max_base = (bw + bh - 1) << up_left;
+            if (base < max_base) v = min(max((left[base] * (32 - sh) + left[base + 1] * sh + 16) >> 5, 0), maxv);
+            else v = left[max_base];
+        } else if (MODE == IM_Z2) {
+            const int x = -dx * (r + 1);
+            const int base1 = (x >> (6 - up_above)) + (c << up_above);
+            if (base1 >= -(1 << up_above)) {
+                const int s1 = ((x * (1 << up_above)) & 0x3f) >> 1;
+                v = (above[base1] * (32 - s1) + above[base1 + 1] * s1 + 16) >> 5;
+            } else {
+                const int y = (r << 6) - dy * (c + 1);
+                const int base2 = y >> (6 - up_left);
+                const int s2 = ((y * (1 << up_left)) & 0x3f) >> 1;
+                v = (left[base2] * (32 - s2) + left[base2 + 1] * s2 + 16) >> 5;
+            }
+            v = min(max(v, 0), maxv);
+        } else v = dc;
+        out[k] = (PixT)v;
+    }
+}
+
+// Work split: a block is covered by LB = bw*bh/ppl consecutive lanes (ppl = pixels per lane =
+// min(bw, 16 B / sizeof(PixT))), i.e. one lane writes 16 B (or a whole narrow row) of one output
+// row.  DC sums are formed cooperatively by the lanes of a block (strided partial sums + a
+// cross-lane reduction), and each lane fetches its `above` segment with one wide unaligned load.
+template <typename PixT, int MODE>
 __global__ __launch_bounds__(256) void intra_pred_kernel(
     PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
-    const PixT* __restrict__ above_all, const PixT* __restrict__ left_all, int32_t nb_pitch, int mode, int bw,
+    const PixT* __restrict__ above_all, const PixT* __restrict__ left_all, int32_t nb_pitch, int mode_rt, int bw,
     int bh, int up_above, int up_left, int dx, int dy, int bd, uint32_t nblocks) {
     constexpr int PXL = 16 / (int)sizeof(PixT);            // pixels per lane when the block is wide enough
     const int ppl = bw < PXL ? bw : PXL;                   // pixels per lane
     const int lanes_per_row = bw / ppl;
-    const uint32_t per_block = (uint32_t)(lanes_per_row * bh);
+    const uint32_t per_block = (uint32_t)(lanes_per_row * bh);      // LB: power of two, 4 .. 512
     const size_t total = (size_t)per_block * nblocks;
     const int maxv = (1 << bd) - 1;
-    for (size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x; item < total;
-         item += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t blk = (uint32_t)(item / per_block);
-        const uint32_t j = (uint32_t)(item - (size_t)blk * per_block);
-        const int r = (int)(j / lanes_per_row), c0 = (int)(j % lanes_per_row) * ppl;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    // the grid is a multiple of per_block (host), so every lane keeps its (row, column) and only
+    // the block index advances: no per-iteration division
+    const size_t item0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int pb_shift = __builtin_ctz(per_block);                  // per_block is a power of two
+    const uint32_t j = (uint32_t)(item0 & (per_block - 1));
+    const int r = (int)(j / lanes_per_row), c0 = (int)(j % lanes_per_row) * ppl;
+    const int wh = kSmWeights[bh + r];
+    constexpr int mode = MODE;
+    (void)mode_rt;
+    for (size_t item = item0; item < total; item += nthreads) {
+        const uint32_t blk = (uint32_t)(item >> pb_shift);
         const PixT* above = above_all + (size_t)blk * nb_pitch + NB_ORIGIN;
         const PixT* left = left_all + (size_t)blk * nb_pitch + NB_ORIGIN;
         int dc = 0;
         if (mode == IM_DC || mode == IM_DC_TOP || mode == IM_DC_LEFT) {
-            int sum = 0, cnt = 0;
-            if (mode != IM_DC_LEFT) { for (int i = 0; i < bw; i++) sum += above[i]; cnt += bw; }
-            if (mode != IM_DC_TOP) { for (int i = 0; i < bh; i++) sum += left[i]; cnt += bh; }
+            // cooperative sum: lane j of the block adds samples j, j+LB, ... then the block's lanes
+            // reduce (LB <= 64: shuffles inside the wave; LB > 64: every wave sums everything itself)
+            const int na = mode != IM_DC_LEFT ? bw : 0, nl = mode != IM_DC_TOP ? bh : 0;
+            const int grp = per_block < 64 ? (int)per_block : 64;
+            const int lj = (int)(j % (uint32_t)grp);
+            int sum = 0;
+            for (int i = lj; i < na; i += grp) sum += above[i];
+            for (int i = lj; i < nl; i += grp) sum += left[i];
+            for (int m = grp >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+            const int cnt = na + nl;
             dc = (sum + (cnt >> 1)) / cnt;                 // exact division (EbIntraPrediction.c:1880-1896)
         } else if (mode == IM_DC_128) {
             dc = 128 << (bd - 8);
         }
         PixT out[PXL];
-        const int wh = kSmWeights[bh + r];
-#pragma unroll
-        for (int k = 0; k < PXL; k++) {
-            const int c = c0 + (k < ppl ? k : 0);      // lanes of narrow blocks recompute pixel 0 (discarded)
-            int v;
-            switch (mode) {
-            case IM_V: v = above[c]; break;
-            case IM_H: v = left[r]; break;
-            case IM_SMOOTH: {
-                const int ww = kSmWeights[bw + c];
-                v = (wh * above[c] + (256 - wh) * left[bh - 1] + ww * left[r] + (256 - ww) * above[bw - 1] + 256) >> 9;
-            } break;
-            case IM_SMOOTH_V: v = (wh * above[c] + (256 - wh) * left[bh - 1] + 128) >> 8; break;
-            case IM_SMOOTH_H: {
-                const int ww = kSmWeights[bw + c];
-                v = (ww * left[r] + (256 - ww) * above[bw - 1] + 128) >> 8;
-            } break;
-            case IM_PAETH: {
-                const int l = left[r], t = above[c], tl = above[-1];
-                const int base = t + l - tl;
-                const int pl = abs(base - l), pt = abs(base - t), ptl = abs(base - tl);
-                v = (pl <= pt && pl <= ptl) ? l : (pt <= ptl ? t : tl);
-            } break;
-            case IM_Z1: {
-                const int x = dx * (r + 1);
-                const int base = (x >> (6 - up_above)) + (c << up_above);
-                const int sh = ((x << up_above) & 0x3f) >> 1;
-                const int max_base = (bw + bh - 1) << up_above;
-                if (base < max_base) v = min(max((above[base] * (32 - sh) + above[base + 1] * sh + 16) >> 5, 0), maxv);
-                else v = above[max_base];
-            } break;
-            case IM_Z3: {
-                const int y = dy * (c + 1);
-                const int base = (y >> (6 - up_left)) + (r << up_left);
-                const int sh = ((y << up_left) & 0x3f) >> 1;
-                const int max_base = (bw + bh - 1) << up_left;
-                if (base < max_base) v = min(max((left[base] * (32 - sh) + left[base + 1] * sh + 16) >> 5, 0), maxv);
-                else v = left[max_base];
-            } break;
-            case IM_Z2: {
-                const int x = -dx * (r + 1);
-                const int base1 = (x >> (6 - up_above)) + (c << up_above);
-                if (base1 >= -(1 << up_above)) {
-                    const int s1 = ((x * (1 << up_above)) & 0x3f) >> 1;
-                    v = (above[base1] * (32 - s1) + above[base1 + 1] * s1 + 16) >> 5;
-                } else {
-                    const int y = (r << 6) - dy * (c + 1);
-                    const int base2 = y >> (6 - up_left);
-                    const int s2 = ((y * (1 << up_left)) & 0x3f) >> 1;
-                    v = (left[base2] * (32 - s2) + left[base2 + 1] * s2 + 16) >> 5;
-                }
-                v = min(max(v, 0), maxv);
-            } break;
-            default: v = dc; break;
-            }
-            out[k] = (PixT)v;
-        }
+        // MODE is a template parameter: one kernel per mode keeps the register footprint of the
+        // gather-heavy directional bodies away from the simple ones
+        intra_row<PixT, MODE>(out, above, left, r, c0, ppl, bw, bh, wh, dc, up_above, up_left, dx, dy, maxv);
         const size_t base_off = dst_offsets ? (size_t)dst_offsets[blk] : (size_t)blk * dst_block_pitch;
         PixT* d = dst + base_off + (size_t)r * dst_stride + c0;
         if (ppl == PXL && ((reinterpret_cast<uintptr_t>(d) & 15) == 0)) {

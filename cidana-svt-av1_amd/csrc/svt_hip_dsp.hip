@@ -701,18 +701,29 @@ extern "C" int svt_hip_intra_pred_batch(void* d_dst, int32_t dst_stride, size_t 
     }
     const int es = is_16bit ? 2 : 1;
     const int pxl = 16 / es, ppl = bw < pxl ? bw : pxl;
-    const size_t items = (size_t)(bw / ppl) * bh * nblocks;
+    const size_t per_block = (size_t)(bw / ppl) * bh;            // lanes per block: power of two, 4..512
+    const size_t items = per_block * nblocks;
     size_t grid = (items + 255) / 256;
     if (grid > 16384) grid = 16384;
+    // grid * 256 must be a multiple of per_block so that a lane keeps its (row, column) across iterations
+    if (per_block > 256) grid = (grid + 1) & ~(size_t)1;
     hipStream_t s = (hipStream_t)stream;
-    if (is_16bit)
-        hipLaunchKernelGGL((intra_pred_kernel<uint16_t>), dim3((uint32_t)grid), dim3(256), 0, s, (uint16_t*)d_dst, dst_stride,
-                           dst_block_pitch, d_dst_offsets, (const uint16_t*)d_above, (const uint16_t*)d_left, nb_pitch, mode,
-                           bw, bh, upsample_above, upsample_left, dx, dy, bd, (uint32_t)nblocks);
-    else
-        hipLaunchKernelGGL((intra_pred_kernel<uint8_t>), dim3((uint32_t)grid), dim3(256), 0, s, (uint8_t*)d_dst, dst_stride,
-                           dst_block_pitch, d_dst_offsets, (const uint8_t*)d_above, (const uint8_t*)d_left, nb_pitch, mode,
-                           bw, bh, upsample_above, upsample_left, dx, dy, bd, (uint32_t)nblocks);
+#define IPL(T, M)                                                                                                     \
+    hipLaunchKernelGGL((intra_pred_kernel<T, M>), dim3((uint32_t)grid), dim3(256), 0, s, (T*)d_dst, dst_stride,          \
+                       dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, mode, bw, bh,      \
+                       upsample_above, upsample_left, dx, dy, bd, (uint32_t)nblocks)
+#define IPM(T)                                                                                                        \
+    switch (mode) {                                                                                                   \
+    case SVT_INTRA_DC: IPL(T, IM_DC); break; case SVT_INTRA_V: IPL(T, IM_V); break; case SVT_INTRA_H: IPL(T, IM_H); break; \
+    case SVT_INTRA_SMOOTH: IPL(T, IM_SMOOTH); break; case SVT_INTRA_SMOOTH_V: IPL(T, IM_SMOOTH_V); break;             \
+    case SVT_INTRA_SMOOTH_H: IPL(T, IM_SMOOTH_H); break; case SVT_INTRA_PAETH: IPL(T, IM_PAETH); break;               \
+    case SVT_INTRA_DC_TOP: IPL(T, IM_DC_TOP); break; case SVT_INTRA_DC_LEFT: IPL(T, IM_DC_LEFT); break;               \
+    case SVT_INTRA_DC_128: IPL(T, IM_DC_128); break; case SVT_INTRA_Z1: IPL(T, IM_Z1); break;                         \
+    case SVT_INTRA_Z2: IPL(T, IM_Z2); break; default: IPL(T, IM_Z3); break;                                           \
+    }
+    if (is_16bit) { IPM(uint16_t) } else { IPM(uint8_t) }
+#undef IPM
+#undef IPL
     return launch_status("intra_pred");
 }
 
