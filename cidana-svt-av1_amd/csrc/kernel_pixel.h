@@ -54,20 +54,44 @@ __global__ __launch_bounds__(256) void sad_sse_kernel(
     const uint8_t* __restrict__ a, uint32_t a_stride, size_t a_block_pitch,
     const uint8_t* __restrict__ b, uint32_t b_stride, size_t b_block_pitch,
     uint32_t width, uint32_t height, void* __restrict__ out, uint32_t nblocks) {
-    // 16 lanes per block, 4 blocks per wave
+    // 16 lanes per block, 4 blocks per wave; a lane walks (row, chunk) items with chunks of
+    // cs = 16 / 8 / 4 / 1 bytes fetched by one unaligned load each.  SAD: v_sad_u8 per dword;
+    // SSE: sum (x-y)^2 = x.x + y.y - 2 x.y with three v_dot4_u32_u8 per dword (exact in u32).
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 4, l = lane & 15;
     const uint32_t blk = (blockIdx.x * 4 + wave) * 4 + sub;
     const bool valid = blk < nblocks;
-    const uint8_t* pa = a + (size_t)blk * a_block_pitch;
-    const uint8_t* pb = b + (size_t)blk * b_block_pitch;
     unsigned long long acc = 0;
     if (valid) {
-        const uint32_t total = width * height;
-        for (uint32_t i = l; i < total; i += 16) {
-            const uint32_t y = i / width, x = i - y * width;
-            const int d = (int)pa[(size_t)y * a_stride + x] - (int)pb[(size_t)y * b_stride + x];
-            acc += SSE ? (unsigned)(d * d) : (unsigned)(d < 0 ? -d : d);
+        const uint8_t* pa = a + (size_t)blk * a_block_pitch;
+        const uint8_t* pb = b + (size_t)blk * b_block_pitch;
+        const uint32_t cs = (width & 15) == 0 ? 16u : ((width & 7) == 0 ? 8u : ((width & 3) == 0 ? 4u : 1u));
+        const uint32_t cpr = width / cs, items = cpr * height;
+        uint32_t y = l / cpr, c = l - y * cpr;                 // advance (y, c) by 16 items without dividing again
+        const uint32_t dy16 = 16 / cpr, dc16 = 16 - dy16 * cpr;
+        for (uint32_t i = l; i < items; i += 16) {
+            uint32_t va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0};
+            const uint8_t* qa = pa + (size_t)y * a_stride + c * cs;
+            const uint8_t* qb = pb + (size_t)y * b_stride + c * cs;
+            if (cs == 16) { __builtin_memcpy(va, qa, 16); __builtin_memcpy(vb, qb, 16); }
+            else if (cs == 8) { __builtin_memcpy(va, qa, 8); __builtin_memcpy(vb, qb, 8); }
+            else if (cs == 4) { __builtin_memcpy(va, qa, 4); __builtin_memcpy(vb, qb, 4); }
+            else { va[0] = qa[0]; vb[0] = qb[0]; }
+            unsigned t = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (SSE) {
+                    const unsigned aa = __builtin_amdgcn_udot4(va[k], va[k], 0u, false);
+                    const unsigned bb = __builtin_amdgcn_udot4(vb[k], vb[k], 0u, false);
+                    const unsigned ab = __builtin_amdgcn_udot4(va[k], vb[k], 0u, false);
+                    t += aa + bb - 2u * ab;
+                } else {
+                    t = __builtin_amdgcn_sad_u8(va[k], vb[k], t);
+                }
+            }
+            acc += t;
+            y += dy16; c += dc16;
+            if (c >= cpr) { c -= cpr; y++; }
         }
     }
     acc = group_sum64<16>(acc);
@@ -77,20 +101,34 @@ __global__ __launch_bounds__(256) void sad_sse_kernel(
     }
 }
 
-// residual_kernel_c (EbPictureOperators.c:166): int16 res = src - pred
+// residual_kernel_c (EbPictureOperators.c:166): int16 res = src - pred.  One item = up to 16
+// pixels of one row (one wide load per input, 32 B of output).
 __global__ __launch_bounds__(256) void residual_kernel(
     const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
     const uint8_t* __restrict__ pred, uint32_t pred_stride, size_t pred_block_pitch,
     int16_t* __restrict__ res, uint32_t res_stride, size_t res_block_pitch, uint32_t width,
     uint32_t height, uint32_t nblocks) {
-    const size_t per = (size_t)width * height;
-    const size_t total = per * nblocks;
+    const uint32_t cs = (width & 15) == 0 ? 16u : ((width & 7) == 0 ? 8u : ((width & 3) == 0 ? 4u : 1u));
+    const uint32_t cpr = width / cs;
+    const size_t per = (size_t)cpr * height, total = per * nblocks;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t blk = i / per;
-        const uint32_t j = (uint32_t)(i - blk * per), y = j / width, x = j - y * width;
-        res[blk * res_block_pitch + (size_t)y * res_stride + x] =
-            (int16_t)((int)src[blk * src_block_pitch + (size_t)y * src_stride + x] -
-                      (int)pred[blk * pred_block_pitch + (size_t)y * pred_stride + x]);
+        const uint32_t j = (uint32_t)(i - blk * per), y = j / cpr, c = j - y * cpr;
+        const uint8_t* ps = src + blk * src_block_pitch + (size_t)y * src_stride + c * cs;
+        const uint8_t* pp = pred + blk * pred_block_pitch + (size_t)y * pred_stride + c * cs;
+        int16_t* pr = res + blk * res_block_pitch + (size_t)y * res_stride + c * cs;
+        uint8_t vs[16], vp[16];
+        if (cs == 16) { __builtin_memcpy(vs, ps, 16); __builtin_memcpy(vp, pp, 16); }
+        else if (cs == 8) { __builtin_memcpy(vs, ps, 8); __builtin_memcpy(vp, pp, 8); }
+        else if (cs == 4) { __builtin_memcpy(vs, ps, 4); __builtin_memcpy(vp, pp, 4); }
+        else { vs[0] = ps[0]; vp[0] = pp[0]; }
+        int16_t o[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) o[k] = (int16_t)((int)vs[k] - (int)vp[k]);
+        if (cs == 16) __builtin_memcpy(pr, o, 32);
+        else if (cs == 8) __builtin_memcpy(pr, o, 16);
+        else if (cs == 4) __builtin_memcpy(pr, o, 8);
+        else pr[0] = o[0];
     }
 }
 

@@ -572,9 +572,10 @@ extern "C" int svt_hip_residual_batch(const uint8_t* d_src, uint32_t src_stride,
     if (!d_src || !d_pred || !d_res) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
     if (width == 0 || height == 0) return set_err(SVT_HIP_ERR_INVALID, "empty block");
     if (nblocks == 0) return SVT_HIP_OK;
-    const size_t total = (size_t)width * height * nblocks;
+    const uint32_t rcs = (width & 15) == 0 ? 16u : ((width & 7) == 0 ? 8u : ((width & 3) == 0 ? 4u : 1u));
+    const size_t total = (size_t)(width / rcs) * height * nblocks;
     size_t grid = (total + 255) / 256;
-    if (grid > 8192) grid = 8192;
+    if (grid > 16384) grid = 16384;
     hipLaunchKernelGGL(residual_kernel, dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_src, src_stride,
                        src_block_pitch, d_pred, pred_stride, pred_block_pitch, d_res, res_stride, res_block_pitch,
                        width, height, (uint32_t)nblocks);
