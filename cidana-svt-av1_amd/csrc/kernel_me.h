@@ -8,13 +8,14 @@
 // packed MV ((uint16)y << 18) | (uint16)(x << 2).
 //
 // Mapping: one workgroup (4 waves) per superblock.  The even source rows (32 x 64 B)
-// and the whole reference window live in LDS; lane t evaluates search points
-// t, t+256, ...  For one search point a lane walks the 8 bands of 8 rows: 4 even
-// rows x 16 dwords of v_sad_u8 against reference dwords rebuilt with v_alignbyte
-// into 8 accumulators (= the band's eight 8x8 SADs), folding them on the fly into
-// 16x16 / 32x32 / 64x64 sums.  Every PU keeps one packed 32-bit key
-// (sad << 12 | search-point index) per lane, so "first strict minimum" is a plain
-// unsigned min; the 85 keys are min-reduced over the workgroup at the end.
+// and the whole reference window live in LDS; a lane evaluates groups of FOUR
+// horizontally adjacent search points with v_qsad_pk_u16_u8 (aligned reference dword
+// pairs, 4 points x 4 pixels per instruction), walking the 8 bands of 8 rows: 4 even
+// rows x 16 dwords into 8 packed accumulators (= the band's eight 8x8 SADs of the 4
+// points), folded on the fly into 16x16 (still packed u16) and 32x32 / 64x64 (u32)
+// sums.  Every PU keeps one packed 32-bit key (sad << 12 | search-point index) per
+// lane, so "first strict minimum" is a plain unsigned min; the 85 keys are
+// min-reduced over the workgroup at the end.
 // Limits: search_w * search_h <= 4096 (12-bit index), window must fit 64 KiB LDS.
 #pragma once
 #include "dev_common.h"
@@ -44,15 +45,39 @@ __global__ __launch_bounds__(ME_THREADS) void me_sb_search_kernel(
     const int tid = threadIdx.x;
     const uint8_t* gs = src + (size_t)blk * src_block_pitch;
     const uint8_t* gr = ref + (size_t)blk * ref_block_pitch;
-    // stage even source rows (dword loads when aligned, else bytes)
-    for (int i = tid; i < 32 * 64; i += ME_THREADS) {
-        const int r = i >> 6, c = i & 63;
-        reinterpret_cast<uint8_t*>(s_src)[i] = gs[(size_t)(2 * r) * src_stride + c];
+    // stage the even source rows and the reference window with 16-B unaligned loads
+    if (tid < 128) {
+        const int r = tid >> 2, c = tid & 3;
+        uint4 v;
+        __builtin_memcpy(&v, gs + (size_t)(2 * r) * src_stride + c * 16, 16);
+        reinterpret_cast<uint4*>(s_src)[tid] = v;
     }
     const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
-    for (uint32_t i = tid; i < wpitch * win_h; i += ME_THREADS) {
-        const uint32_t y = i / wpitch, x = i - y * wpitch;
-        s_ref[i] = x < win_w ? gr[(size_t)y * ref_stride + x] : 0;
+    {
+        const uint32_t cpr = (win_w + 15) >> 4;                       // 16-B chunks per window row (<= 16 for search_w <= 193)
+        const size_t span = (size_t)(win_h - 1) * ref_stride + win_w;  // the window's own footprint: never read past it
+        for (uint32_t c = tid & 15; c < cpr; c += 16)
+            for (uint32_t y0 = tid >> 4; y0 < win_h; y0 += 64) {       // 4 loads in flight per lane
+                uint4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t y = y0 + 16 * k;
+                    v[k] = make_uint4(0, 0, 0, 0);
+                    if (y < win_h) {
+                        const size_t off = (size_t)y * ref_stride + c * 16;
+                        if (off + 16 <= span) __builtin_memcpy(&v[k], gr + off, 16);
+                        else {
+                            uint8_t* vb = reinterpret_cast<uint8_t*>(&v[k]);
+                            for (uint32_t b = 0; b < 16; b++) if (off + b < span) vb[b] = gr[off + b];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t y = y0 + 16 * k;
+                    if (y < win_h) *reinterpret_cast<uint4*>(s_ref + (size_t)y * wpitch + c * 16) = v[k];
+                }
+            }
     }
     __syncthreads();
 
@@ -60,16 +85,25 @@ __global__ __launch_bounds__(ME_THREADS) void me_sb_search_kernel(
 #pragma unroll
     for (int i = 0; i < ME_PUS; i++) best[i] = 0xffffffffu;
 
+    // A lane owns FOUR horizontally adjacent search points (xs0 .. xs0+3, xs0 % 4 == 0): every
+    // reference dword pair is then aligned and one v_qsad_pk_u16_u8 gives 4 points x 4 pixels.
+    // Packed u16 sums are safe up to the 16x16 level (4 * 4 rows * 8 px * 255 * 4 = 32 640 before
+    // the final doubling); 32x32 / 64x64 are summed per point in u32.
+    const int gx = (search_w + 3) >> 2;
+    const int ngroups = gx * search_h;
     const int ncand = search_w * search_h;
-    for (int cand = tid; cand < ncand; cand += ME_THREADS) {
-        const int ys = cand / search_w, xs = cand - ys * search_w;
-        const unsigned sh = (unsigned)(xs & 3);
-        const uint8_t* rbase = s_ref + (size_t)ys * wpitch + (xs & ~3);
-        unsigned s32acc[4] = {0, 0, 0, 0};
-        unsigned s16acc[4] = {0, 0, 0, 0};   // the four 16x16 of the current 16-row band
+    for (int grp = tid; grp < ngroups; grp += ME_THREADS) {
+        const int ys = grp / gx, xg = grp - ys * gx;
+        const int xs0 = xg * 4, cand0 = ys * search_w + xs0;
+        unsigned bad[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) bad[jj] = (xs0 + jj < search_w) ? 0u : 0xffffffffu;
+        const uint8_t* rbase = s_ref + (size_t)ys * wpitch + xs0;
+        unsigned s32acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // [quadrant][point]
+        unsigned long long s16acc[4] = {0, 0, 0, 0};      // packed 4 x u16, the four 16x16 of the current 16-row band
 #pragma unroll
         for (int band = 0; band < 8; band++) {          // 8-row band = one row of 8x8 blocks
-            unsigned acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const int r = band * 8 + rr * 2;
@@ -79,38 +113,55 @@ __global__ __launch_bounds__(ME_THREADS) void me_sb_search_kernel(
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const uint32_t hi = rrow[q + 1];
-                    const uint32_t rv = __builtin_amdgcn_alignbyte(hi, lo, sh);
-                    acc[q >> 1] = __builtin_amdgcn_sad_u8(srow[q], rv, acc[q >> 1]);
+                    acc[q >> 1] = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)hi << 32) | lo, srow[q], acc[q >> 1]);
                     lo = hi;
                 }
             }
             const int by16 = band >> 1, kr = band & 1;
 #pragma unroll
             for (int bx = 0; bx < 8; bx++) {
-                const unsigned s = acc[bx] << 1;
                 const int bx16 = bx >> 1;
                 const int z = ((by16 >> 1) * 2 + (bx16 >> 1)) * 4 + (by16 & 1) * 2 + (bx16 & 1);
                 const int idx = 4 * z + kr * 2 + (bx & 1);
-                best[idx] = min(best[idx], (s << 12) | (unsigned)cand);
-                s16acc[bx16] += s;
+                const unsigned alo = (unsigned)acc[bx], ahi = (unsigned)(acc[bx] >> 32);
+                // key = (2*s) << 12 | point = s << 13 | point
+                unsigned k0 = ((alo & 0xffffu) << 13) | (unsigned)(cand0 + 0) | bad[0];
+                unsigned k1 = ((alo >> 16) << 13) | (unsigned)(cand0 + 1) | bad[1];
+                unsigned k2 = ((ahi & 0xffffu) << 13) | (unsigned)(cand0 + 2) | bad[2];
+                unsigned k3 = ((ahi >> 16) << 13) | (unsigned)(cand0 + 3) | bad[3];
+                best[idx] = min(min(best[idx], min(k0, k1)), min(k2, k3));
+                // packed u16 add of the four lanes (no carry between lanes: sums stay < 2^16)
+                s16acc[bx16] += acc[bx];
             }
             if (kr == 1) {
 #pragma unroll
                 for (int bx16 = 0; bx16 < 4; bx16++) {
                     const int z = ((by16 >> 1) * 2 + (bx16 >> 1)) * 4 + (by16 & 1) * 2 + (bx16 & 1);
-                    best[64 + z] = min(best[64 + z], (s16acc[bx16] << 12) | (unsigned)cand);
-                    s32acc[(by16 >> 1) * 2 + (bx16 >> 1)] += s16acc[bx16];
+                    const unsigned alo = (unsigned)s16acc[bx16], ahi = (unsigned)(s16acc[bx16] >> 32);
+                    const unsigned s0 = (alo & 0xffffu) << 1, s1 = (alo >> 16) << 1, s2 = (ahi & 0xffffu) << 1, s3 = (ahi >> 16) << 1;
+                    const unsigned k0 = (s0 << 12) | (unsigned)(cand0 + 0) | bad[0], k1 = (s1 << 12) | (unsigned)(cand0 + 1) | bad[1];
+                    const unsigned k2 = (s2 << 12) | (unsigned)(cand0 + 2) | bad[2], k3 = (s3 << 12) | (unsigned)(cand0 + 3) | bad[3];
+                    best[64 + z] = min(min(best[64 + z], min(k0, k1)), min(k2, k3));
+                    const int qd = (by16 >> 1) * 2 + (bx16 >> 1);
+                    s32acc[qd][0] += s0; s32acc[qd][1] += s1; s32acc[qd][2] += s2; s32acc[qd][3] += s3;
                     s16acc[bx16] = 0;
                 }
             }
         }
-        unsigned s64 = 0;
+        unsigned s64[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            best[80 + q] = min(best[80 + q], (s32acc[q] << 12) | (unsigned)cand);
-            s64 += s32acc[q];
+            unsigned kk[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) { kk[jj] = (s32acc[q][jj] << 12) | (unsigned)(cand0 + jj) | bad[jj]; s64[jj] += s32acc[q][jj]; }
+            best[80 + q] = min(min(best[80 + q], min(kk[0], kk[1])), min(kk[2], kk[3]));
         }
-        best[84] = min(best[84], (s64 << 12) | (unsigned)cand);
+        {
+            unsigned kk[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) kk[jj] = (s64[jj] << 12) | (unsigned)(cand0 + jj) | bad[jj];
+            best[84] = min(min(best[84], min(kk[0], kk[1])), min(kk[2], kk[3]));
+        }
     }
     // workgroup min-reduction of the 85 keys
     const int lane = tid & 63, wave = tid >> 6;

@@ -651,7 +651,7 @@ extern "C" int svt_hip_me_sb_search_batch(const uint8_t* d_src, uint32_t src_str
     if (search_w <= 0 || search_h <= 0 || search_w * search_h > 4096)
         return set_err(SVT_HIP_ERR_INVALID, "search area %dx%d (1..4096 points)", search_w, search_h);
     const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
-    const uint32_t wpitch = (win_w + 3 + 8) & ~3u;
+    const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
     const size_t lds = 32 * 64 + (size_t)wpitch * win_h;
     if (lds > 60 * 1024) return set_err(SVT_HIP_ERR_INVALID, "search window needs %zu B of LDS (> 60 KiB)", lds);
     hipLaunchKernelGGL(me_sb_search_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
