@@ -214,21 +214,35 @@ __global__ __launch_bounds__(F32_WAVES * 64, MIN_WAVES_PER_SIMD) void fwd32_kern
 // samples are read, updated and written 16 B per lane.
 // dst block b at dst + (offsets ? offsets[b] : b*block_pitch), row stride dst_stride.
 // ---------------------------------------------------------------------------
-template <typename PixT>
+template <typename PixT, int BD>
 __global__ __launch_bounds__(F32_WAVES * 64) void inv32_kernel(
     const int32_t* __restrict__ coeff, PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch,
-    const uint32_t* __restrict__ dst_offsets, int is_idtx, int bd, uint32_t nblocks) {
+    const uint32_t* __restrict__ dst_offsets, int is_idtx, uint32_t nblocks) {
+    constexpr int bd = BD;    // compile-time ranges: min(max(x, lo), hi) becomes one v_med3_i32
     __shared__ __attribute__((aligned(16))) int32_t lds[F32_WAVES * 2 * F32_TILE_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, li = lane & 31;
     char* tile = reinterpret_cast<char*>(lds + (wave * 2 + half) * F32_TILE_WORDS);
     const uint32_t blk = (blockIdx.x * F32_WAVES + wave) * 2 + half;
     const bool valid = blk < nblocks;
-    const int row_bits = bd == 8 ? 16 : (bd == 10 ? 18 : 20);     // av1_gen_inv_stage_range (:5404-5456)
-    const int col_bits = bd == 12 ? 18 : 16;
-    const int in_lo = -(1 << (bd + 7)), in_hi = (1 << (bd + 7)) - 1;
-    const int cin_bits = bd + 6 > 16 ? bd + 6 : 16;
+    constexpr int row_bits = bd == 8 ? 16 : (bd == 10 ? 18 : 20);     // av1_gen_inv_stage_range (:5404-5456)
+    constexpr int col_bits = bd == 12 ? 18 : 16;
+    constexpr int in_lo = -(1 << (bd + 7)), in_hi = (1 << (bd + 7)) - 1;
+    constexpr int cin_bits = bd + 6 > 16 ? bd + 6 : 16;
     int x[32];
+    // destination samples are fetched up front (their latency hides under the two transform passes)
+    constexpr int PPL = 16 / (int)sizeof(PixT);          // pixels per lane per step
+    constexpr int STEPS = 1024 / (32 * PPL);
+    const size_t dbase = valid ? (dst_offsets ? (size_t)dst_offsets[blk] : (size_t)blk * dst_block_pitch) : 0;
+    const bool dst_aligned = (((reinterpret_cast<uintptr_t>(dst) + dbase * sizeof(PixT)) & 15) == 0) && ((dst_stride * (int)sizeof(PixT)) & 15) == 0;
+    uint4 dpre[STEPS];
+    if (valid && dst_aligned) {
+#pragma unroll
+        for (int k = 0; k < STEPS; k++) {
+            const int p = (k * 32 + li) * PPL;
+            dpre[k] = *reinterpret_cast<const uint4*>(dst + dbase + (size_t)(p >> 5) * dst_stride + (p & 31));
+        }
+    }
     // ---- linear coefficient load -> tile A (row reads: swizzle (row>>1)&7) -------------
     const int4* c4 = reinterpret_cast<const int4*>(coeff + (size_t)blk * 1024);
 #pragma unroll
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(F32_WAVES * 64) void inv32_kernel(
         *reinterpret_cast<int4*>(tile + tile_slot(li, s, li & 7)) =
             make_int4((x[s * 4 + 0] + 2) >> 2, (x[s * 4 + 1] + 2) >> 2, (x[s * 4 + 2] + 2) >> 2, (x[s * 4 + 3] + 2) >> 2);  // shift[0] = -2
     wave_lds_fence();
-    const int c_lo = -(1 << (cin_bits - 1)), c_hi = (1 << (cin_bits - 1)) - 1;
+    constexpr int c_lo = -(1 << (cin_bits - 1)), c_hi = (1 << (cin_bits - 1)) - 1;
 #pragma unroll
     for (int r = 0; r < 32; r++) {
         const int v = *reinterpret_cast<const int*>(tile + tile_slot(r, li >> 2, r & 7) + (li & 3) * 4);
@@ -270,15 +284,12 @@ __global__ __launch_bounds__(F32_WAVES * 64) void inv32_kernel(
         *reinterpret_cast<int*>(tile + r * 128 + li * 4) = (x[r] + 8) >> 4;                             // shift[1] = -4
     wave_lds_fence();
     if (valid) {
-        const size_t base = dst_offsets ? (size_t)dst_offsets[blk] : (size_t)blk * dst_block_pitch;
-        const int maxpix = (1 << bd) - 1;
-        constexpr int PPL = 16 / (int)sizeof(PixT);          // pixels per lane per step
-        constexpr int STEPS = 1024 / (32 * PPL);
+        constexpr int maxpix = (1 << bd) - 1;
 #pragma unroll
         for (int k = 0; k < STEPS; k++) {
             const int p = (k * 32 + li) * PPL;               // linear pixel index in the block
             const int row = p >> 5, col = p & 31;
-            PixT* d = dst + base + (size_t)row * dst_stride + col;
+            PixT* d = dst + dbase + (size_t)row * dst_stride + col;
             const int* rs = reinterpret_cast<const int*>(tile + p * 4);
             int rv[PPL];
 #pragma unroll
@@ -286,8 +297,8 @@ __global__ __launch_bounds__(F32_WAVES * 64) void inv32_kernel(
                 const int4 t = *reinterpret_cast<const int4*>(rs + j);
                 rv[j] = t.x; rv[j + 1] = t.y; rv[j + 2] = t.z; rv[j + 3] = t.w;
             }
-            if ((reinterpret_cast<uintptr_t>(d) & 15) == 0) {
-                uint4 pv = *reinterpret_cast<const uint4*>(d);
+            if (dst_aligned) {
+                uint4 pv = dpre[k];                          // fetched before the transforms started
                 PixT* px = reinterpret_cast<PixT*>(&pv);
 #pragma unroll
                 for (int j = 0; j < PPL; j++) px[j] = (PixT)min(max((int)px[j] + rv[j], 0), maxpix);

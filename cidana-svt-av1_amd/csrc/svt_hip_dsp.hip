@@ -364,12 +364,11 @@ extern "C" int svt_hip_inv_txfm2d_add_batch(const int32_t* d_coeff, void* d_dst,
     hipStream_t s = (hipStream_t)stream;
     if (tx_size == SVT_TX_32X32 && ((uintptr_t)d_coeff & 15) == 0 && (tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX)) {
         const uint32_t grid = (uint32_t)((nblocks + 2 * F32_WAVES - 1) / (2 * F32_WAVES));
-        if (dst_is_16bit)
-            hipLaunchKernelGGL((inv32_kernel<uint16_t>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_coeff, (uint16_t*)d_dst, dst_stride,
-                               dst_block_pitch, d_dst_offsets, tx_type == SVT_IDTX ? 1 : 0, bd, (uint32_t)nblocks);
-        else
-            hipLaunchKernelGGL((inv32_kernel<uint8_t>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_coeff, (uint8_t*)d_dst, dst_stride,
-                               dst_block_pitch, d_dst_offsets, tx_type == SVT_IDTX ? 1 : 0, bd, (uint32_t)nblocks);
+#define INV32(T, B) hipLaunchKernelGGL((inv32_kernel<T, B>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_coeff, (T*)d_dst, dst_stride, \
+                                      dst_block_pitch, d_dst_offsets, tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks)
+        if (dst_is_16bit) { if (bd == 8) INV32(uint16_t, 8); else if (bd == 10) INV32(uint16_t, 10); else INV32(uint16_t, 12); }
+        else INV32(uint8_t, 8);
+#undef INV32
         return launch_status("inv32");
     }
     if (!g_tune_no_staged && !d_dst_offsets && dst_stride == kTxW[tx_size] && dst_block_pitch == (size_t)kTxW[tx_size] * kTxH[tx_size] &&
