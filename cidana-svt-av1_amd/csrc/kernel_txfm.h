@@ -67,6 +67,7 @@ __device__ __forceinline__ void fwd1d(int kind, int (&x)[N]) {
 template <int N>
 __device__ __forceinline__ void inv1d(int kind, int (&x)[N], int lo, int hi) {
     using namespace svtgen;
+    lo = svt_vgpr(lo); hi = svt_vgpr(hi);     // clamp bounds live in two VGPRs (see svt_clamp)
     constexpr int BIT = 12;   // inv_cos_bit_* are all INV_COS_BIT = 12 (EbTransforms.h:252-267)
     if constexpr (N == 4) {
         if (kind == K1D_DCT) svt_idct4<BIT>(x, lo, hi); else if (kind == K1D_IDTX) svt_iidentity4<BIT>(x, lo, hi); else svt_iadst4<BIT>(x, lo, hi);

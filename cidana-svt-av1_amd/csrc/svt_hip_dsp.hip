@@ -36,6 +36,8 @@ int g_tune_f32_nt = 0;
 int g_tune_f32_qmode1 = 0;
 int g_tune_no_staged = 0;
 int g_tune_no_qsad = 0;
+int g_tune_inv32_waves = 4;
+int g_tune_inv32_var = 0;
 
 int set_err(int code, const char* fmt, ...) {
     va_list ap;
@@ -275,6 +277,8 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "f32_qmode1")) { g_tune_f32_qmode1 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_staged")) { g_tune_no_staged = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_qsad")) { g_tune_no_qsad = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "inv32_waves")) { g_tune_inv32_waves = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "inv32_var")) { g_tune_inv32_var = value; return SVT_HIP_OK; }
     return set_err(SVT_HIP_ERR_INVALID, "unknown tuning key %s", key);
 }
 extern "C" const char* svt_hip_device_name(void) { return g_devname; }
@@ -363,6 +367,15 @@ extern "C" int svt_hip_inv_txfm2d_add_batch(const int32_t* d_coeff, void* d_dst,
     if (nblocks == 0) return SVT_HIP_OK;
     hipStream_t s = (hipStream_t)stream;
     if (tx_size == SVT_TX_32X32 && ((uintptr_t)d_coeff & 15) == 0 && (tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX)) {
+        if (!dst_is_16bit && (g_tune_inv32_waves != 4 || g_tune_inv32_var != 0)) {     // tuning probes (tools/tune_inv32.py)
+#define INVV(WV, VR) if (g_tune_inv32_waves == WV && g_tune_inv32_var == VR) { \
+            hipLaunchKernelGGL((inv32_kernel<uint8_t, 8, WV, VR>), dim3((uint32_t)((nblocks + 2 * WV - 1) / (2 * WV))), dim3(WV * 64), 0, s, d_coeff, \
+                               (uint8_t*)d_dst, dst_stride, dst_block_pitch, d_dst_offsets, tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks); \
+            return launch_status("inv32 probe"); }
+            INVV(4, 1) INVV(4, 2) INVV(4, 4) INVV(4, 5) INVV(2, 0)
+#undef INVV
+            return set_err(SVT_HIP_ERR_INVALID, "inv32 probe variant not built");
+        }
         const uint32_t grid = (uint32_t)((nblocks + 2 * F32_WAVES - 1) / (2 * F32_WAVES));
 #define INV32(T, B) hipLaunchKernelGGL((inv32_kernel<T, B>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_coeff, (T*)d_dst, dst_stride, \
                                       dst_block_pitch, d_dst_offsets, tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks)

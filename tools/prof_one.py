@@ -17,6 +17,9 @@ if name == "sad_search":
 elif name == "inv32":
     n = 1 << 20
     c = torch.randint(-500, 501, (n, 1024), dtype=torch.int32, device=dev); d = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device=dev)
+    if os.environ.get("INV32_VAR"):
+        wv, vr = (int(t) for t in os.environ["INV32_VAR"].split(","))
+        dsp.lib.svt_hip_tune(b"inv32_waves", wv); dsp.lib.svt_hip_tune(b"inv32_var", vr)
     fn = lambda: dsp.inv_txfm2d_add(c, d, 3, 0, 8)
 elif name == "intra_dc":
     n = 1 << 21
