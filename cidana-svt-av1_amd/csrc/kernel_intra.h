@@ -11,6 +11,7 @@
 // allows; neighbour rows are tiny and served from L1/L2.
 #pragma once
 #include "dev_common.h"
+#include <type_traits>
 
 namespace svtdev {
 
@@ -32,130 +33,318 @@ __device__ constexpr uint8_t kSmWeights[128] = {
 // above_row / left_col lives at index NB_ORIGIN + p (p >= -2).
 constexpr int NB_ORIGIN = 16;
 
-template <typename PixT, int MODE>
-__device__ __forceinline__ void intra_row(PixT (&out)[16 / sizeof(PixT)], const PixT* __restrict__ above,
-                                          const PixT* __restrict__ left, int r, int c0, int ppl, int bw, int bh, int wh,
-                                          int dc, int up_above, int up_left, int dx, int dy, int maxv) {
+// ---- non-directional modes -------------------------------------------------------------
+// Work split: a block is covered by LB = bw*bh/ppl consecutive lanes (ppl = pixels per lane =
+// min(bw, 16 B / sizeof(PixT))), i.e. one lane writes 16 B (or a whole narrow row) of one output
+// row, ONE item per lane and a grid as large as the job.  tools/probe/store_probe.hip: for a
+// write-only stream "one 16-B store per lane, huge grid" reaches 6.8 TB/s, 4 stores per lane 6.0,
+// grid-stride loops 4.1-5.7 (on gfx9 loads and stores share vmcnt, so a loop of load -> store makes
+// each iteration wait for the previous iteration's stores); 4 blocks per lane measured slower as well.
+
+// One lane's output: `ppl` pixels (16 B when the block is wide enough).  The value is packed into
+// four dwords first and stored with the widest instruction the address allows; keeping the three
+// paths structurally different stops the compiler from "hoisting common stores" out of them, which
+// had turned the aligned 16-B store into byte + short + dwordx3 + byte stores (half the bandwidth).
+template <typename PixT>
+__device__ __forceinline__ void intra_store(PixT* d, const PixT (&out)[16 / sizeof(PixT)], int ppl) {
+    uint4 v;
+    __builtin_memcpy(&v, out, 16);
+    const int nbytes = ppl * (int)sizeof(PixT);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d);
+    if (nbytes == 16 && (a & 15) == 0) {
+        *reinterpret_cast<uint4*>(d) = v;
+    } else if ((a & 3) == 0) {                       // nbytes is 4, 8 or 16
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t* d4 = reinterpret_cast<uint32_t*>(d);
+        for (int q = 0; q < (nbytes >> 2); q++) d4[q] = w[q];
+    } else {
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
+        uint8_t* d1 = reinterpret_cast<uint8_t*>(d);
+        for (int q = 0; q < nbytes; q++) d1[q] = b[q];
+    }
+}
+
+__device__ const uint32_t kZeroWord[1] = {0};     // stand-in offset table (keeps the offset fetch branch-free)
+
+template <typename PixT>
+struct IntraNb {                       // what one lane needs from a block's neighbours
+    PixT ab[16 / sizeof(PixT)];        // above[c0 .. c0+ppl-1]
+    uint8_t ww[16 / sizeof(PixT)];     // smooth weights of those columns
+    int lft, bl, tr, tl, sum;
+};
+
+// WIDE = the block is at least 16 B wide (ppl == PXL): every access below is then a single wide
+// instruction and the whole kernel is straight-line code up to the store, so all of a lane's loads
+// are in flight together (with the runtime narrow/wide branches the compiler had put an
+// s_waitcnt vmcnt(0) after every load).
+template <typename PixT, int MODE, bool WIDE>
+__device__ __forceinline__ void intra_load(IntraNb<PixT>& nb, const PixT* __restrict__ above, const PixT* __restrict__ left,
+                                           int r, int c0, int ppl, int bw, int bh, int lj, int grp) {
     constexpr int PXL = 16 / (int)sizeof(PixT);
-    PixT ab[PXL];                                          // above[c0 .. c0+ppl-1] in one wide load
     if (MODE == IM_V || MODE == IM_SMOOTH || MODE == IM_SMOOTH_V || MODE == IM_PAETH) {
-        if (ppl == PXL) __builtin_memcpy(ab, above + c0, 16);
+        if (WIDE) __builtin_memcpy(nb.ab, above + c0, 16);
         else {
 #pragma unroll
-            for (int k = 0; k < PXL; k++) ab[k] = k < ppl ? above[c0 + k] : (PixT)0;
+            for (int k = 0; k < PXL; k++) nb.ab[k] = k < ppl ? above[c0 + k] : (PixT)0;
         }
     }
-    const int lft = (MODE == IM_H || MODE == IM_SMOOTH || MODE == IM_SMOOTH_H || MODE == IM_PAETH) ? (int)left[r] : 0;
-    const int bl = (MODE == IM_SMOOTH || MODE == IM_SMOOTH_V) ? (int)left[bh - 1] : 0;
-    const int tr = (MODE == IM_SMOOTH || MODE == IM_SMOOTH_H) ? (int)above[bw - 1] : 0;
-    const int tl = MODE == IM_PAETH ? (int)above[-1] : 0;
+    if (MODE == IM_SMOOTH || MODE == IM_SMOOTH_H) {
+        if (WIDE) __builtin_memcpy(nb.ww, kSmWeights + bw + c0, PXL);
+        else {
+#pragma unroll
+            for (int k = 0; k < PXL; k++) nb.ww[k] = kSmWeights[bw + c0 + (k < ppl ? k : 0)];
+        }
+    }
+    nb.lft = (MODE == IM_H || MODE == IM_SMOOTH || MODE == IM_SMOOTH_H || MODE == IM_PAETH) ? (int)left[r] : 0;
+    nb.bl = (MODE == IM_SMOOTH || MODE == IM_SMOOTH_V) ? (int)left[bh - 1] : 0;
+    nb.tr = (MODE == IM_SMOOTH || MODE == IM_SMOOTH_H) ? (int)above[bw - 1] : 0;
+    nb.tl = MODE == IM_PAETH ? (int)above[-1] : 0;
+    nb.sum = 0;
+    if (MODE == IM_DC || MODE == IM_DC_TOP || MODE == IM_DC_LEFT) {
+        // cooperative sum over 4-sample chunks (bw, bh are multiples of 4): lane lj of the block's
+        // reduction group takes chunks lj, lj+grp, ...; the group is reduced after all loads are out
+        const int na = MODE != IM_DC_LEFT ? bw : 0, nl = MODE != IM_DC_TOP ? bh : 0;
+        const int nch = (na + nl) >> 2;
+        if (WIDE && nch <= grp) {
+            // one predicated chunk per lane, no loop (every wide block except 16x4)
+            const int o = lj << 2;
+            const PixT* q = o < na ? above + o : left + (o - na);
+            PixT t[4] = {0, 0, 0, 0};
+            if (lj < nch) __builtin_memcpy(t, q, 4 * sizeof(PixT));
+            nb.sum = (int)t[0] + (int)t[1] + (int)t[2] + (int)t[3];
+        } else {
+            for (int ch = lj; ch < nch; ch += grp) {
+                const int o = ch << 2;
+                const PixT* q = o < na ? above + o : left + (o - na);
+                PixT t[4];
+                __builtin_memcpy(t, q, 4 * sizeof(PixT));
+                nb.sum += (int)t[0] + (int)t[1] + (int)t[2] + (int)t[3];
+            }
+        }
+    }
+}
+
+template <typename PixT, int MODE, bool WIDE>
+__device__ __forceinline__ void intra_row(PixT (&out)[16 / sizeof(PixT)], const IntraNb<PixT>& nb, int wh, int dc) {
+    constexpr int PXL = 16 / (int)sizeof(PixT);
+    // terms that do not depend on the column
+    const int sm_c = (256 - wh) * nb.bl + 256 * nb.tr + 256;          // SMOOTH: + wh*ab + ww*(lft - tr)
+    const int smv_c = (256 - wh) * nb.bl + 128;                       // SMOOTH_V
+    const int smh_c = 256 * nb.tr + 128;                              // SMOOTH_H: + ww*(lft - tr)
+    const int dlt = nb.lft - nb.tr;
+    const int p_t = abs(nb.lft - nb.tl);                              // PAETH: |base - top|  = |left - topleft|
+    const int p_k = nb.lft - 2 * nb.tl;                               //        |base - tl|   = |top + left - 2 topleft|
 #pragma unroll
     for (int k = 0; k < PXL; k++) {
-        const int c = c0 + (k < ppl ? k : 0);          // lanes of narrow blocks recompute pixel 0 (discarded)
         int v;
-        if (MODE == IM_V) v = ab[k];
-        else if (MODE == IM_H) v = lft;
-        else if (MODE == IM_SMOOTH) {
-            const int ww = kSmWeights[bw + c];
-            v = (wh * ab[k] + (256 - wh) * bl + ww * lft + (256 - ww) * tr + 256) >> 9;
-        } else if (MODE == IM_SMOOTH_V) v = (wh * ab[k] + (256 - wh) * bl + 128) >> 8;
-        else if (MODE == IM_SMOOTH_H) {
-            const int ww = kSmWeights[bw + c];
-            v = (ww * lft + (256 - ww) * tr + 128) >> 8;
-        } else if (MODE == IM_PAETH) {
-            const int t = ab[k];
-            const int base = t + lft - tl;
-            const int pl = abs(base - lft), pt = abs(base - t), ptl = abs(base - tl);
-            v = (pl <= pt && pl <= ptl) ? lft : (pt <= ptl ? t : tl);
-        } else if (MODE == IM_Z1) {
-            const int x = dx * (r + 1);
-            const int base = (x >> (6 - up_above)) + (c << up_above);
-            const int sh = ((x << up_above) & 0x3f) >> 1;
-            const int max_base = (bw + bh - 1) << up_above;
-            if (base < max_base) v = min(max((above[base] * (32 - sh) + above[base + 1] * sh + 16) >> 5, 0), maxv);
-            else v = above[max_base];
-        } else if (MODE == IM_Z3) {
-            const int y = dy * (c + 1);
-            const int base = (y >> (6 - up_left)) + (r << up_left);
-            const int sh = ((y << up_left) & 0x3f) >> 1;
-            const int max_base = (bw + bh - 1) << up_left;
-            if (base < max_base) v = min(max((left[base] * (32 - sh) + left[base + 1] * sh + 16) >> 5, 0), maxv);
-            else v = left[max_base];
-        } else if (MODE == IM_Z2) {
-            const int x = -dx * (r + 1);
-            const int base1 = (x >> (6 - up_above)) + (c << up_above);
-            if (base1 >= -(1 << up_above)) {
-                const int s1 = ((x * (1 << up_above)) & 0x3f) >> 1;
-                v = (above[base1] * (32 - s1) + above[base1 + 1] * s1 + 16) >> 5;
-            } else {
-                const int y = (r << 6) - dy * (c + 1);
-                const int base2 = y >> (6 - up_left);
-                const int s2 = ((y * (1 << up_left)) & 0x3f) >> 1;
-                v = (left[base2] * (32 - s2) + left[base2 + 1] * s2 + 16) >> 5;
-            }
-            v = min(max(v, 0), maxv);
+        if (MODE == IM_V) v = nb.ab[k];
+        else if (MODE == IM_H) v = nb.lft;
+        else if (MODE == IM_SMOOTH) v = (wh * nb.ab[k] + nb.ww[k] * dlt + sm_c) >> 9;
+        else if (MODE == IM_SMOOTH_V) v = (wh * nb.ab[k] + smv_c) >> 8;
+        else if (MODE == IM_SMOOTH_H) v = (nb.ww[k] * dlt + smh_c) >> 8;
+        else if (MODE == IM_PAETH) {
+            const int t = nb.ab[k];
+            const int pl = abs(t - nb.tl), ptl = abs(t + p_k);        // |base - left| = |top - topleft|
+            v = (pl <= p_t && pl <= ptl) ? nb.lft : (p_t <= ptl ? t : nb.tl);
         } else v = dc;
         out[k] = (PixT)v;
     }
 }
 
-// Work split: a block is covered by LB = bw*bh/ppl consecutive lanes (ppl = pixels per lane =
-// min(bw, 16 B / sizeof(PixT))), i.e. one lane writes 16 B (or a whole narrow row) of one output
-// row.  DC sums are formed cooperatively by the lanes of a block (strided partial sums + a
-// cross-lane reduction), and each lane fetches its `above` segment with one wide unaligned load.
-template <typename PixT, int MODE>
+template <typename PixT, int MODE, bool WIDE, int IU>
 __global__ __launch_bounds__(256) void intra_pred_kernel(
     PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
-    const PixT* __restrict__ above_all, const PixT* __restrict__ left_all, int32_t nb_pitch, int mode_rt, int bw,
-    int bh, int up_above, int up_left, int dx, int dy, int bd, uint32_t nblocks) {
+    const PixT* __restrict__ above_all, const PixT* __restrict__ left_all, int32_t nb_pitch, int bw, int bh, int bd,
+    uint32_t dc_magic, uint32_t nblocks) {
     constexpr int PXL = 16 / (int)sizeof(PixT);            // pixels per lane when the block is wide enough
-    const int ppl = bw < PXL ? bw : PXL;                   // pixels per lane
-    const int lanes_per_row = bw / ppl;
+    const int ppl = WIDE ? PXL : bw;                       // pixels per lane (host picks WIDE = bw >= PXL)
+    const int lanes_per_row = WIDE ? bw >> __builtin_ctz((uint32_t)PXL) : 1;
     const uint32_t per_block = (uint32_t)(lanes_per_row * bh);      // LB: power of two, 4 .. 512
     const size_t total = (size_t)per_block * nblocks;
-    const int maxv = (1 << bd) - 1;
-    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
-    // the grid is a multiple of per_block (host), so every lane keeps its (row, column) and only
-    // the block index advances: no per-iteration division
-    const size_t item0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int pb_shift = __builtin_ctz(per_block);                  // per_block is a power of two
-    const uint32_t j = (uint32_t)(item0 & (per_block - 1));
-    const int r = (int)(j / lanes_per_row), c0 = (int)(j % lanes_per_row) * ppl;
-    const int wh = kSmWeights[bh + r];
-    constexpr int mode = MODE;
-    (void)mode_rt;
-    for (size_t item = item0; item < total; item += nthreads) {
-        const uint32_t blk = (uint32_t)(item >> pb_shift);
-        const PixT* above = above_all + (size_t)blk * nb_pitch + NB_ORIGIN;
-        const PixT* left = left_all + (size_t)blk * nb_pitch + NB_ORIGIN;
+    const int lr_shift = __builtin_ctz((uint32_t)lanes_per_row);
+    const uint32_t j = (uint32_t)(item & (per_block - 1));
+    const int r = (int)(j >> lr_shift), c0 = (int)(j & (uint32_t)(lanes_per_row - 1)) * ppl;
+    const int wh = (MODE == IM_SMOOTH || MODE == IM_SMOOTH_V) ? kSmWeights[bh + r] : 0;
+    const int grp = per_block < 64 ? (int)per_block : 64;          // DC reduction group (inside one wave)
+    const int lj = (int)(j & (uint32_t)(grp - 1));
+    constexpr bool IS_DC = MODE == IM_DC || MODE == IM_DC_TOP || MODE == IM_DC_LEFT;
+    const int cnt = MODE == IM_DC ? bw + bh : (MODE == IM_DC_TOP ? bw : bh);
+    // a lane owns IU items, `nthreads` apart (nthreads is a multiple of per_block: same row / column)
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    bool live[IU];
+    uint32_t blk[IU];
+    IntraNb<PixT> nb[IU];
+    size_t boff[IU];
+    const bool has_offs = dst_offsets != nullptr;
+    // ---- every load of this lane, back to back -----------------------------------------------
+#pragma unroll
+    for (int u = 0; u < IU; u++) {
+        const size_t it = item + (size_t)u * nthreads;
+        live[u] = it < total;
+        blk[u] = live[u] ? (uint32_t)(it >> pb_shift) : 0u;         // dead slots re-read block 0 (never stored)
+        const PixT* above = above_all + (size_t)blk[u] * nb_pitch + NB_ORIGIN;
+        const PixT* left = left_all + (size_t)blk[u] * nb_pitch + NB_ORIGIN;
+        intra_load<PixT, MODE, WIDE>(nb[u], above, left, r, c0, ppl, bw, bh, lj, grp);
+        const uint32_t off_word = (has_offs ? dst_offsets : kZeroWord)[has_offs ? blk[u] : 0u];
+        boff[u] = has_offs ? (size_t)off_word : (size_t)blk[u] * dst_block_pitch;
+    }
+    // ---- reduce, predict, store ---------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < IU; u++) {
         int dc = 0;
-        if (mode == IM_DC || mode == IM_DC_TOP || mode == IM_DC_LEFT) {
-            // cooperative sum: lane j of the block adds samples j, j+LB, ... then the block's lanes
-            // reduce (LB <= 64: shuffles inside the wave; LB > 64: every wave sums everything itself)
-            const int na = mode != IM_DC_LEFT ? bw : 0, nl = mode != IM_DC_TOP ? bh : 0;
-            const int grp = per_block < 64 ? (int)per_block : 64;
-            const int lj = (int)(j % (uint32_t)grp);
-            int sum = 0;
-            for (int i = lj; i < na; i += grp) sum += above[i];
-            for (int i = lj; i < nl; i += grp) sum += left[i];
+        if (IS_DC) {
+            int sum = nb[u].sum;
             for (int m = grp >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
-            const int cnt = na + nl;
-            dc = (sum + (cnt >> 1)) / cnt;                 // exact division (EbIntraPrediction.c:1880-1896)
-        } else if (mode == IM_DC_128) {
+            // (sum + cnt/2) / cnt, exact (EbIntraPrediction.c:1880-1896): cnt <= 128, numerator < 2^20,
+            // dc_magic = floor(2^32 / cnt) + 1 (host) makes the high product the exact quotient
+            dc = (int)__umulhi((uint32_t)(sum + (cnt >> 1)), dc_magic);
+        } else if (MODE == IM_DC_128) {
             dc = 128 << (bd - 8);
         }
         PixT out[PXL];
-        // MODE is a template parameter: one kernel per mode keeps the register footprint of the
-        // gather-heavy directional bodies away from the simple ones
-        intra_row<PixT, MODE>(out, above, left, r, c0, ppl, bw, bh, wh, dc, up_above, up_left, dx, dy, maxv);
-        const size_t base_off = dst_offsets ? (size_t)dst_offsets[blk] : (size_t)blk * dst_block_pitch;
-        PixT* d = dst + base_off + (size_t)r * dst_stride + c0;
-        if (ppl == PXL && ((reinterpret_cast<uintptr_t>(d) & 15) == 0)) {
-            *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(out);
+        intra_row<PixT, MODE, WIDE>(out, nb[u], wh, dc);
+        if (live[u]) intra_store<PixT>(dst + boff[u] + (size_t)r * dst_stride + c0, out, ppl);
+    }
+}
+
+// ---- directional modes (av1_dr_prediction_z1/z2/z3, :370-477 / :3394-3506) ------------------
+// Same lane -> (row, 16-B column segment) mapping, one step per workgroup.  The two edge arrays of
+// the blocks a workgroup works on are first copied into LDS (every edge sample is used by many
+// pixels of the block) and PADDED with copies of their last valid sample edge[max_base]: the
+// reference's "base >= max_base -> edge[max_base]" case then falls out of the same interpolation
+// ((32*e + 16) >> 5 == e), so the pixel loop has no bounds test.  Each pixel is
+//   (a*(32-sh) + b*sh + 16) >> 5  =  two multiply-adds and a shift,
+// z1 walks one edge with a fixed phase per row (ppl+1 LDS reads for ppl pixels); results are packed
+// into dwords with v_lshl_or.
+__device__ __forceinline__ uint32_t dir_lerp(uint32_t a, uint32_t b, uint32_t w0, uint32_t sh) {
+    return (__umul24(b, sh) + (__umul24(a, w0) + 16u)) >> 5;
+}
+
+template <typename PixT, int MODE>
+__global__ __launch_bounds__(256) void intra_dir_kernel(
+    PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
+    const PixT* __restrict__ above_all, const PixT* __restrict__ left_all, int32_t nb_pitch, int bw, int bh,
+    int up_above, int up_left, int dx, int dy, int lim_a, int lim_l, int n_pad, int bd, uint32_t nblocks) {
+    // interpolated values of in-range samples are in range; 16-bit input may carry out-of-range
+    // samples, which clip_pixel_highbd (EbIntraPrediction.c:3394-3506) would clip: keep that
+    const uint32_t maxv = (1u << bd) - 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t dir_smem[];
+    PixT* sm = reinterpret_cast<PixT*>(dir_smem);
+    constexpr int PXL = 16 / (int)sizeof(PixT);
+    constexpr int PPW = 4 / (int)sizeof(PixT);                             // pixels per output dword
+    const int ppl = bw < PXL ? bw : PXL;
+    const int lanes_per_row = bw >> __builtin_ctz((uint32_t)ppl);
+    const uint32_t per_block = (uint32_t)(lanes_per_row * bh);             // power of two, 4 .. 512
+    const int pb_shift = __builtin_ctz(per_block);
+    const int lr_shift = __builtin_ctz((uint32_t)lanes_per_row);
+    const uint32_t lpb = per_block >= 256 ? 256u : per_block;              // this workgroup's lanes on one block
+    const uint32_t slot = threadIdx.x >> __builtin_ctz(lpb);               // which of the workgroup's blocks
+    const uint32_t jl = threadIdx.x & (lpb - 1);                           // lane inside that block's group
+    const size_t total = (size_t)per_block * nblocks;
+    const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = (uint32_t)(item & (per_block - 1));
+    const int r = (int)(j >> lr_shift), c0 = (int)(j & (uint32_t)(lanes_per_row - 1)) * ppl;
+    const int estride = (n_pad + 7) & ~7;                                  // samples per staged edge
+    PixT* sa = sm + (size_t)slot * 2 * estride;                            // above edge of this lane's block
+    PixT* sl = sa + estride;
+    const bool live = item < total;
+    const uint32_t blk = live ? (uint32_t)(item >> pb_shift) : 0u;
+    const bool has_offs = dst_offsets != nullptr;
+    const uint32_t off_word = (has_offs ? dst_offsets : kZeroWord)[has_offs ? blk : 0u];
+    // ---- stage the block's two edges: array positions [NB_ORIGIN-2, lim] from memory (lim = NB_ORIGIN +
+    // max_base), everything after it = edge[max_base].  All loads of a lane are issued before the
+    // first LDS write (fixed trip count, clamped index: no branch, no wait between the loads).
+    {
+        const PixT* ga = above_all + (size_t)blk * nb_pitch;
+        const PixT* gl = left_all + (size_t)blk * nb_pitch;
+        const int i0 = NB_ORIGIN - 2 + (int)jl, last = n_pad - 1;
+        auto stage = [&](auto itc) {
+            constexpr int IT = decltype(itc)::value;
+            PixT va[IT], vl[IT];
+#pragma unroll
+            for (int t = 0; t < IT; t++) {
+                const int i = min(i0 + t * (int)lpb, last);
+                va[t] = ga[min(i, lim_a)]; vl[t] = gl[min(i, lim_l)];
+            }
+#pragma unroll
+            for (int t = 0; t < IT; t++) {
+                const int i = min(i0 + t * (int)lpb, last);
+                sa[i] = va[t]; sl[i] = vl[t];
+            }
+        };
+        const int niter = (n_pad - (NB_ORIGIN - 2) + (int)lpb - 1) >> __builtin_ctz(lpb);
+        if (niter <= 1) stage(std::integral_constant<int, 1>{});
+        else if (niter <= 2) stage(std::integral_constant<int, 2>{});
+        else if (niter <= 4) stage(std::integral_constant<int, 4>{});
+        else if (niter <= 8) stage(std::integral_constant<int, 8>{});
+        else for (int i = i0; i < n_pad; i += (int)lpb) { sa[i] = ga[min(i, lim_a)]; sl[i] = gl[min(i, lim_l)]; }
+    }
+    __syncthreads();
+    const PixT* A = sa + NB_ORIGIN;
+    const PixT* L = sl + NB_ORIGIN;
+    uint32_t px[PXL];
+    if (MODE == IM_Z1) {
+        const int x = dx * (r + 1);
+        const uint32_t sh = (uint32_t)(((x << up_above) & 0x3f) >> 1), w0 = 32u - sh;
+        // a start at or past max_base reads only padding (= above[max_base]), as the reference's tail fill does
+        const PixT* q = A + min((x >> (6 - up_above)) + (c0 << up_above), lim_a - NB_ORIGIN);
+        if (up_above == 0) {
+            uint32_t a = q[0];
+#pragma unroll
+            for (int k = 0; k < PXL; k++) {
+                const uint32_t b = q[k + 1];
+                px[k] = dir_lerp(a, b, w0, sh);
+                a = b;
+            }
         } else {
 #pragma unroll
-            for (int k = 0; k < PXL; k++) if (k < ppl) d[k] = out[k];
+            for (int k = 0; k < PXL; k++) px[k] = dir_lerp(q[2 * k], q[2 * k + 1], w0, sh);
         }
+    } else if (MODE == IM_Z3) {
+        int y = dy * (c0 + 1);
+#pragma unroll
+        for (int k = 0; k < PXL; k++) {
+            const uint32_t sh = (uint32_t)(((y << up_left) & 0x3f) >> 1);
+            const PixT* e = L + min((y >> (6 - up_left)) + (r << up_left), lim_l - NB_ORIGIN);
+            px[k] = dir_lerp(e[0], e[1], 32u - sh, sh);
+            y += dy;
+        }
+    } else {   // IM_Z2
+        const int x = -dx * (r + 1);
+        const uint32_t s1 = (uint32_t)(((x * (1 << up_above)) & 0x3f) >> 1);
+        const int lim = -(1 << up_above);
+        const int aoff = (int)(A - sm) + (x >> (6 - up_above)) + (c0 << up_above), loff = (int)(L - sm);
+        int y = (r << 6) - dy * (c0 + 1);
+#pragma unroll
+        for (int k = 0; k < PXL; k++) {
+            const int base1 = (x >> (6 - up_above)) + ((c0 + k) << up_above);
+            const bool ab = base1 >= lim;
+            const uint32_t s2 = (uint32_t)(((y * (1 << up_left)) & 0x3f) >> 1);
+            const int idx = ab ? aoff + (k << up_above) : loff + (y >> (6 - up_left));
+            const uint32_t sh = ab ? s1 : s2;
+            px[k] = dir_lerp(sm[idx], sm[idx + 1], 32u - sh, sh);
+            y -= dy;
+        }
+    }
+    if (live) {
+        if (sizeof(PixT) == 2) {
+#pragma unroll
+            for (int k = 0; k < PXL; k++) px[k] = min(px[k], maxv);
+        }
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t v = px[q * PPW];
+#pragma unroll
+            for (int t = 1; t < PPW; t++) v |= px[q * PPW + t] << (8 * (int)sizeof(PixT) * t);
+            w[q] = v;
+        }
+        PixT out[PXL];
+        __builtin_memcpy(out, w, 16);
+        const size_t base_off = has_offs ? (size_t)off_word : (size_t)blk * dst_block_pitch;
+        intra_store<PixT>(dst + base_off + (size_t)r * dst_stride + c0, out, ppl);
     }
 }
 

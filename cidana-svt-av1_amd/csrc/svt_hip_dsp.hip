@@ -717,22 +717,51 @@ extern "C" int svt_hip_intra_pred_batch(void* d_dst, int32_t dst_stride, size_t 
     const size_t per_block = (size_t)(bw / ppl) * bh;            // lanes per block: power of two, 4..512
     const size_t items = per_block * nblocks;
     size_t grid = (items + 255) / 256;
-    if (grid > 16384) grid = 16384;
+    if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
     // grid * 256 must be a multiple of per_block so that a lane keeps its (row, column) across iterations
     if (per_block > 256) grid = (grid + 1) & ~(size_t)1;
     hipStream_t s = (hipStream_t)stream;
+    if (mode >= SVT_INTRA_Z1) {
+        // last edge sample the reference may read: index max_base = (bw + bh - 1) << upsample; the LDS copy
+        // continues with copies of it for one lane-row (+2) so the pixel loop needs no bounds test
+        const int lim_a = NB_ORIGIN + ((bw + bh - 1) << upsample_above), lim_l = NB_ORIGIN + ((bw + bh - 1) << upsample_left);
+        const int up = upsample_above > upsample_left ? upsample_above : upsample_left;
+        const int n_pad = (lim_a > lim_l ? lim_a : lim_l) + ((16 / es) << up) + 3;
+        const size_t slots = per_block >= 256 ? 1 : 256 / per_block;
+        const size_t shmem = slots * 2 * (size_t)((n_pad + 7) & ~7) * es;
+#define IDL(T, M)                                                                                                     \
+    hipLaunchKernelGGL((intra_dir_kernel<T, M>), dim3((uint32_t)grid), dim3(256), shmem, s, (T*)d_dst, dst_stride,        \
+                       dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh,            \
+                       upsample_above, upsample_left, dx, dy, lim_a, lim_l, n_pad, bd, (uint32_t)nblocks)
+#define IDM(T)                                                                                                        \
+    switch (mode) {                                                                                                   \
+    case SVT_INTRA_Z1: IDL(T, IM_Z1); break; case SVT_INTRA_Z2: IDL(T, IM_Z2); break; default: IDL(T, IM_Z3); break;  \
+    }
+        if (is_16bit) { IDM(uint16_t) } else { IDM(uint8_t) }
+#undef IDM
+#undef IDL
+        return launch_status("intra_dir");
+    }
+    const int cnt = mode == SVT_INTRA_DC ? bw + bh : (mode == SVT_INTRA_DC_TOP ? bw : bh);
+    const uint32_t dc_magic = (uint32_t)(0x100000000ull / (uint64_t)cnt) + 1u;
+    constexpr int INTRA_IU = 2;                                    // blocks per lane in the wide kernels
+    const size_t grid_w = (grid + INTRA_IU - 1) / INTRA_IU;
 #define IPL(T, M)                                                                                                     \
-    hipLaunchKernelGGL((intra_pred_kernel<T, M>), dim3((uint32_t)grid), dim3(256), 0, s, (T*)d_dst, dst_stride,          \
-                       dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, mode, bw, bh,      \
-                       upsample_above, upsample_left, dx, dy, bd, (uint32_t)nblocks)
+    if (bw >= 16 / (int)sizeof(T))                                                                                    \
+        hipLaunchKernelGGL((intra_pred_kernel<T, M, true, INTRA_IU>), dim3((uint32_t)(per_block > 256 ? (grid_w + 1) & ~(size_t)1 : grid_w)), dim3(256), 0, s, (T*)d_dst, dst_stride, \
+                           dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh, bd,    \
+                           dc_magic, (uint32_t)nblocks);                                                              \
+    else                                                                                                              \
+        hipLaunchKernelGGL((intra_pred_kernel<T, M, false, 1>), dim3((uint32_t)grid), dim3(256), 0, s, (T*)d_dst, dst_stride, \
+                           dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh, bd,    \
+                           dc_magic, (uint32_t)nblocks)
 #define IPM(T)                                                                                                        \
     switch (mode) {                                                                                                   \
     case SVT_INTRA_DC: IPL(T, IM_DC); break; case SVT_INTRA_V: IPL(T, IM_V); break; case SVT_INTRA_H: IPL(T, IM_H); break; \
     case SVT_INTRA_SMOOTH: IPL(T, IM_SMOOTH); break; case SVT_INTRA_SMOOTH_V: IPL(T, IM_SMOOTH_V); break;             \
     case SVT_INTRA_SMOOTH_H: IPL(T, IM_SMOOTH_H); break; case SVT_INTRA_PAETH: IPL(T, IM_PAETH); break;               \
     case SVT_INTRA_DC_TOP: IPL(T, IM_DC_TOP); break; case SVT_INTRA_DC_LEFT: IPL(T, IM_DC_LEFT); break;               \
-    case SVT_INTRA_DC_128: IPL(T, IM_DC_128); break; case SVT_INTRA_Z1: IPL(T, IM_Z1); break;                         \
-    case SVT_INTRA_Z2: IPL(T, IM_Z2); break; default: IPL(T, IM_Z3); break;                                           \
+    default: IPL(T, IM_DC_128); break;                                                                                \
     }
     if (is_16bit) { IPM(uint16_t) } else { IPM(uint8_t) }
 #undef IPM

@@ -89,7 +89,7 @@ if want("intra"):
     n = 1 << 21
     ab = torch.randint(0, 256, (n, 160), dtype=torch.uint8, device=dev); lf = torch.randint(0, 256, (n, 160), dtype=torch.uint8, device=dev)
     out = torch.empty((n, 32, 32), dtype=torch.uint8, device=dev)
-    for mode, nm in ((0, "dc"), (3, "smooth"), (6, "paeth"), (10, "z1"), (11, "z2")):
+    for mode, nm in ((0, "dc"), (9, "dc128"), (1, "v"), (2, "h"), (3, "smooth"), (6, "paeth"), (10, "z1"), (11, "z2"), (12, "z3")):
         ms = timeit(lambda: dsp.intra_pred(ab, lf, mode, 32, 32, 8, 0, 0, 64, 64, out=out))
         rec(f"intra_{nm}_32x32_u8", n, 1024 + 2 * 65, ms)
     del ab, lf, out

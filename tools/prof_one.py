@@ -26,6 +26,11 @@ elif name == "intra_dc":
     ab = torch.randint(0, 256, (n, 160), dtype=torch.uint8, device=dev); lf = torch.randint(0, 256, (n, 160), dtype=torch.uint8, device=dev)
     out = torch.empty((n, 32, 32), dtype=torch.uint8, device=dev)
     fn = lambda: dsp.intra_pred(ab, lf, 0, 32, 32, 8, out=out)
+elif name.startswith("intra:"):
+    mode = int(name.split(":")[1]); n = 1 << 21
+    ab = torch.randint(0, 256, (n, 160), dtype=torch.uint8, device=dev); lf = torch.randint(0, 256, (n, 160), dtype=torch.uint8, device=dev)
+    out = torch.empty((n, 32, 32), dtype=torch.uint8, device=dev)
+    fn = lambda: dsp.intra_pred(ab, lf, mode, 32, 32, 8, 0, 0, 64, 64, out=out)
 elif name == "me_sb":
     n = 510
     src = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 127, 128), dtype=torch.uint8, device=dev)
