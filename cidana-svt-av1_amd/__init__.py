@@ -60,6 +60,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
                                                c_int, c_int, c_int, c_void_p]
     L.svt_hip_quantize_b_batch.argtypes = [c_void_p, c_size_t, c_int] + [c_void_p] * 4 + [c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_int, c_size_t, c_void_p]
+    L.svt_hip_encode_recon_batch.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_int] + [c_void_p] * 5 + [c_void_p] * 8
     L.svt_hip_fwd_quant_sad_batch.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_int] + [c_void_p] * 5 + \
                                              [c_void_p] * 6 + [c_void_p]
     for name in ("svt_hip_sad_batch", "svt_hip_sse_batch"):
@@ -192,6 +193,28 @@ class SvtHipDsp:
                                                           self._p(sad) if want_sad else None, self._stream()),
                     "svt_hip_fwd_quant_sad_batch")
         return outs
+
+    def encode_recon(self, src, pred, tx_size, tx_type, qrow, iscan, keep_coeff=True, want_sad=True):
+        """Encode-pass chain (Av1EncodeLoop): src, pred uint8 [n, H, W] ->
+        dict(coeff, qcoeff, dqcoeff, eob, sad, recon); coeff/dqcoeff are None when keep_coeff is False."""
+        t = self.torch
+        n = src.shape[0]
+        nc = min(TX_W[tx_size], 32) * min(TX_H[tx_size], 32)
+        mk = lambda: t.empty((n, nc), dtype=t.int32, device=src.device)
+        co, dq = (mk(), mk()) if keep_coeff else (None, None)
+        q = mk()
+        eob = t.zeros(n, dtype=t.int16, device=src.device)
+        sad = t.zeros(n, dtype=t.int32, device=src.device) if want_sad else None
+        recon = t.empty_like(pred)
+        tabs = [_np16(qrow[k]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
+        self._check(self.lib.svt_hip_encode_recon_batch(self._p(src), self._p(pred), n, tx_size, tx_type,
+                                                         tabs[0].ctypes.data, tabs[1].ctypes.data, tabs[2].ctypes.data,
+                                                         tabs[3].ctypes.data, tabs[4].ctypes.data, self._p(iscan),
+                                                         self._p(co) if keep_coeff else None, self._p(q),
+                                                         self._p(dq) if keep_coeff else None, self._p(eob),
+                                                         self._p(sad) if want_sad else None, self._p(recon), self._stream()),
+                    "svt_hip_encode_recon_batch")
+        return {"coeff": co, "qcoeff": q, "dqcoeff": dq, "eob": eob, "sad": sad, "recon": recon}
 
     # -- K4 / K7 / K8 ---------------------------------------------------------------
     def sad(self, a, b):

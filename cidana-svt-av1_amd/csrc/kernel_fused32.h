@@ -381,4 +381,190 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(5)))
     }
 }
 
+// ---------------------------------------------------------------------------
+// enc32_kernel — the encode-pass chain of one 32x32 8-bit transform block in ONE kernel
+// (reference call sequence in Av1EncodeLoop, EbCodingLoop.c:545-950):
+//   ResidualKernel -> av1_estimate_transform (32x32 DCT_DCT / IDTX) -> av1_quantize_inv_quantize
+//   (aom_highbd_quantize_b_32x32: qcoeff, dqcoeff, eob) -> av1_inv_transform_recon8bit (pred + inverse)
+// plus the 32x32 SAD(src, pred).  The forward coefficients, the dequantised coefficients and the
+// residual never leave the CU: HBM traffic per block is 2 x 1024 B in + 4096 B (qcoeff) + 1024 B (recon)
+// + 6 B out = 7 174 B, against 14 342 + 6 144 B for the two separate kernels.  coeff / dqcoeff are
+// written too when the caller passes buffers for them (KEEP).
+// The body is fwd32_kernel<IN_U8, QUANT> up to the quantiser, whose dequantised int4 chunks are exactly
+// the linear 16-B chunks inv32_kernel loads, and the prediction samples already sit in registers in
+// the 16-B-per-lane layout of its reconstruction stage.
+// ---------------------------------------------------------------------------
+template <bool KEEP, bool WITH_SAD>
+__global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3))) void enc32_kernel(
+    const uint8_t* __restrict__ src, const uint8_t* __restrict__ pred, uint8_t* __restrict__ recon,
+    int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
+    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
+    int is_idtx, uint32_t nblocks) {
+    __shared__ __attribute__((aligned(16))) int32_t lds[F32_WAVES * 2 * F32_TILE_WORDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, li = lane & 31;
+    char* tile = reinterpret_cast<char*>(lds + (wave * 2 + half) * F32_TILE_WORDS);
+    const uint32_t blk = (blockIdx.x * F32_WAVES + wave) * 2 + half;
+    const bool valid = blk < nblocks;
+    const size_t pix_off = (size_t)blk * 1024;
+
+    // ---- load 2 x 1 KB, coalesced 16 B per lane; SAD on the raw bytes ----------------------
+    uint4 s0 = {0, 0, 0, 0}, s1 = s0, p0 = s0, p1 = s0;
+    if (valid) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(src + pix_off);
+        const uint4* p4 = reinterpret_cast<const uint4*>(pred + pix_off);
+        s0 = s4[li]; s1 = s4[li + 32]; p0 = p4[li]; p1 = p4[li + 32];
+    }
+    unsigned sad_acc = 0;
+    if (WITH_SAD) {
+        sad_acc = __builtin_amdgcn_sad_u8(s0.x, p0.x, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s0.y, p0.y, sad_acc);
+        sad_acc = __builtin_amdgcn_sad_u8(s0.z, p0.z, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s0.w, p0.w, sad_acc);
+        sad_acc = __builtin_amdgcn_sad_u8(s1.x, p1.x, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s1.y, p1.y, sad_acc);
+        sad_acc = __builtin_amdgcn_sad_u8(s1.z, p1.z, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s1.w, p1.w, sad_acc);
+    }
+    int x[32];
+    {   // residual as packed int16 pairs -> LDS -> columns (layout: see fwd32_kernel)
+        const uint32_t sw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+        for (int kp = 0; kp < 4; kp++) {
+            uint32_t r[4];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; h2++) {
+                const uint32_t a = sw[kp * 2 + h2], b = pw[kp * 2 + h2];
+                const int d0 = (int)(a & 0xff) - (int)(b & 0xff);
+                const int d1 = (int)((a >> 8) & 0xff) - (int)((b >> 8) & 0xff);
+                const int d2 = (int)((a >> 16) & 0xff) - (int)((b >> 16) & 0xff);
+                const int d3 = (int)(a >> 24) - (int)(b >> 24);
+                r[h2 * 2 + 0] = ((uint32_t)d0 & 0xffffu) | ((uint32_t)d1 << 16);
+                r[h2 * 2 + 1] = ((uint32_t)d2 & 0xffffu) | ((uint32_t)d3 << 16);
+            }
+            *reinterpret_cast<uint4*>(tile + kp * 544 + li * 16) = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+        wave_lds_fence();
+        const char* colbase = tile + ((li >> 3) & 1) * 544 + (li >> 4) * 16 + (li & 7) * 2;
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            const short v = *reinterpret_cast<const short*>(colbase + (r >> 4) * 1088 + (r & 15) * 32);
+            x[r] = (int)v * 4;                                   // shift[0] = 2 (fwd_shift_32x32)
+        }
+    }
+    // ---- forward: column pass, transpose, row pass, re-order to linear ------------------------
+    if (is_idtx) svtgen::svt_fidentity32<F32_COS_BIT>(x); else svtgen::svt_fdct32<F32_COS_BIT>(x);
+#pragma unroll
+    for (int r = 0; r < 32; r++) x[r] = (x[r] + 8) >> 4;      // shift[1] = -4
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 32; r++)
+        *reinterpret_cast<int*>(tile + tile_slot(r, li >> 2, (r >> 1) & 7) + (li & 3) * 4) = x[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int4 v = *reinterpret_cast<const int4*>(tile + tile_slot(li, s, (li >> 1) & 7));
+        x[s * 4 + 0] = v.x; x[s * 4 + 1] = v.y; x[s * 4 + 2] = v.z; x[s * 4 + 3] = v.w;
+    }
+    if (is_idtx) svtgen::svt_fidentity32<F32_COS_BIT>(x); else svtgen::svt_fdct32<F32_COS_BIT>(x);
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+        *reinterpret_cast<int4*>(tile + tile_slot(li, s, li & 7)) =
+            make_int4(x[s * 4 + 0], x[s * 4 + 1], x[s * 4 + 2], x[s * 4 + 3]);
+    wave_lds_fence();
+    // ---- quantise the lane's 8 linear 16-B chunks; dequantised chunks stay in registers ---------
+    int4 dqv[8];
+    {
+        int4 cv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int row = 4 * k + (li >> 3);
+            cv[k] = *reinterpret_cast<const int4*>(tile + tile_slot(row, li & 7, row & 7));
+        }
+        wave_lds_fence();                                        // the tile is free for the inverse now
+        int4* co4 = reinterpret_cast<int4*>(coeff + pix_off);
+        int4* qc4 = reinterpret_cast<int4*>(qcoeff + pix_off);
+        int4* dq4 = reinterpret_cast<int4*>(dqcoeff + pix_off);
+        int eob_acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint2 isc = *reinterpret_cast<const uint2*>(iscan + (k * 32 + li) * 4);
+            int4 q;
+            quant_one<2>(cv[k].x, (k == 0 && li == 0) ? 0 : 1, qp, q.x, dqv[k].x);
+            quant_one<2>(cv[k].y, 1, qp, q.y, dqv[k].y);
+            quant_one<2>(cv[k].z, 1, qp, q.z, dqv[k].z);
+            quant_one<2>(cv[k].w, 1, qp, q.w, dqv[k].w);
+            const int e0 = q.x ? (int)(isc.x & 0xffffu) + 1 : 0, e1 = q.y ? (int)(isc.x >> 16) + 1 : 0;
+            const int e2 = q.z ? (int)(isc.y & 0xffffu) + 1 : 0, e3 = q.w ? (int)(isc.y >> 16) + 1 : 0;
+            eob_acc = max(eob_acc, max(max(e0, e1), max(e2, e3)));
+            if (valid) {
+                qc4[k * 32 + li] = q;
+                if (KEEP) { co4[k * 32 + li] = cv[k]; dq4[k * 32 + li] = dqv[k]; }
+            }
+        }
+        eob_acc = half_wave_max(eob_acc);
+        if (WITH_SAD) sad_acc = half_wave_sum(sad_acc);
+        if (valid && li == 0) {
+            eob[blk] = (uint16_t)eob_acc;
+            if (WITH_SAD) sad[blk] = sad_acc;
+        }
+    }
+    // ---- inverse (inv32_kernel<uint8_t, 8> from its tile-A stage on) ---------------------------
+    const int c_hi = svtgen::svt_vgpr(32767), c_lo = ~c_hi;       // bd = 8: every clamp range is 16-bit
+    const int a_w = (li >> 3) * 128 + (((li & 7) ^ (li >> 4)) << 4);
+    const int a_r = li * 128 + (((li >> 1) & 7) << 4);
+    const int b_w = li * 128 + ((li & 7) << 4);
+    const int b_r = ((li >> 2) << 4) + (li & 3) * 4;
+#pragma unroll
+    for (int k = 0; k < 8; k++) *reinterpret_cast<int4*>(tile + (a_w ^ (((2 * k) & 7) << 4)) + k * 512) = dqv[k];
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int4 v = *reinterpret_cast<const int4*>(tile + (a_r ^ (s << 4)));
+        x[s * 4 + 0] = svtgen::svt_clamp(v.x, c_lo, c_hi); x[s * 4 + 1] = svtgen::svt_clamp(v.y, c_lo, c_hi);
+        x[s * 4 + 2] = svtgen::svt_clamp(v.z, c_lo, c_hi); x[s * 4 + 3] = svtgen::svt_clamp(v.w, c_lo, c_hi);
+    }
+    if (is_idtx) svtgen::svt_iidentity32<12>(x, 0, 0); else svtgen::svt_idct32<12>(x, c_lo, c_hi);
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+        *reinterpret_cast<int4*>(tile + (b_w ^ (s << 4))) =
+            make_int4((x[s * 4 + 0] + 2) >> 2, (x[s * 4 + 1] + 2) >> 2, (x[s * 4 + 2] + 2) >> 2, (x[s * 4 + 3] + 2) >> 2);
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        const int v = *reinterpret_cast<const int*>(tile + (b_r ^ ((r & 7) << 4)) + r * 128);
+        x[r] = svtgen::svt_clamp(v, c_lo, c_hi);
+    }
+    if (is_idtx) svtgen::svt_iidentity32<12>(x, 0, 0); else svtgen::svt_idct32<12>(x, c_lo, c_hi);
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 32; r++)
+        *reinterpret_cast<int*>(tile + (b_r ^ (((r >> 1) & 3) << 4)) + r * 128) = (x[r] + 8) >> 4;
+    wave_lds_fence();
+    if (valid) {
+        const uint4 pk[2] = {p0, p1};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int L = k * 32 + li;
+            const int g = (L >> 2) & 3;
+            int rv[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int4 t = *reinterpret_cast<const int4*>(tile + L * 64 + ((j ^ g) << 4));
+                rv[4 * j] = t.x; rv[4 * j + 1] = t.y; rv[4 * j + 2] = t.z; rv[4 * j + 3] = t.w;
+            }
+            const uint32_t pw[4] = {pk[k].x, pk[k].y, pk[k].z, pk[k].w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t pe = pw[q] & 0x00ff00ffu, po = (pw[q] >> 8) & 0x00ff00ffu;
+                const uint32_t re = __builtin_amdgcn_perm((uint32_t)rv[4 * q + 2], (uint32_t)rv[4 * q + 0], 0x05040100u);
+                const uint32_t ro = __builtin_amdgcn_perm((uint32_t)rv[4 * q + 3], (uint32_t)rv[4 * q + 1], 0x05040100u);
+                const uint32_t ue = sat_pk_u8_i16(pk_add_i16(pe, re)), uo = sat_pk_u8_i16(pk_add_i16(po, ro));
+                ow[q] = __builtin_amdgcn_perm(uo, ue, 0x05010400u);
+            }
+            reinterpret_cast<uint4*>(recon + pix_off)[L] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+    }
+}
+
 }  // namespace svtdev

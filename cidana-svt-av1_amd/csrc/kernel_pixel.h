@@ -101,35 +101,41 @@ __global__ __launch_bounds__(256) void sad_sse_kernel(
     }
 }
 
-// residual_kernel_c (EbPictureOperators.c:166): int16 res = src - pred.  One item = up to 16
-// pixels of one row (one wide load per input, 32 B of output).
+// residual_kernel_c (EbPictureOperators.c:166): int16 res = src - pred.  One item = CS pixels of one
+// row (one wide load per input, 2*CS bytes of output), ONE item per lane and a grid as large as the
+// job (tools/probe/store_probe.hip: grid-stride loops cost 15-40 % of the store bandwidth).
+// POW2: items per row and per block are powers of two (every AV1 block size), so the item -> (block,
+// row, chunk) split is shifts and masks; otherwise 64-bit divisions.
+template <int CS, bool POW2>
 __global__ __launch_bounds__(256) void residual_kernel(
     const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
     const uint8_t* __restrict__ pred, uint32_t pred_stride, size_t pred_block_pitch,
     int16_t* __restrict__ res, uint32_t res_stride, size_t res_block_pitch, uint32_t width,
     uint32_t height, uint32_t nblocks) {
-    const uint32_t cs = (width & 15) == 0 ? 16u : ((width & 7) == 0 ? 8u : ((width & 3) == 0 ? 4u : 1u));
-    const uint32_t cpr = width / cs;
+    const uint32_t cpr = width / CS;
     const size_t per = (size_t)cpr * height, total = per * nblocks;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t blk = i / per;
-        const uint32_t j = (uint32_t)(i - blk * per), y = j / cpr, c = j - y * cpr;
-        const uint8_t* ps = src + blk * src_block_pitch + (size_t)y * src_stride + c * cs;
-        const uint8_t* pp = pred + blk * pred_block_pitch + (size_t)y * pred_stride + c * cs;
-        int16_t* pr = res + blk * res_block_pitch + (size_t)y * res_stride + c * cs;
-        uint8_t vs[16], vp[16];
-        if (cs == 16) { __builtin_memcpy(vs, ps, 16); __builtin_memcpy(vp, pp, 16); }
-        else if (cs == 8) { __builtin_memcpy(vs, ps, 8); __builtin_memcpy(vp, pp, 8); }
-        else if (cs == 4) { __builtin_memcpy(vs, ps, 4); __builtin_memcpy(vp, pp, 4); }
-        else { vs[0] = ps[0]; vp[0] = pp[0]; }
-        int16_t o[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) o[k] = (int16_t)((int)vs[k] - (int)vp[k]);
-        if (cs == 16) __builtin_memcpy(pr, o, 32);
-        else if (cs == 8) __builtin_memcpy(pr, o, 16);
-        else if (cs == 4) __builtin_memcpy(pr, o, 8);
-        else pr[0] = o[0];
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    size_t blk; uint32_t y, c;
+    if (POW2) {
+        const int cs = __builtin_ctz(cpr), ps = __builtin_ctzll((unsigned long long)per);
+        blk = i >> ps;
+        const uint32_t j = (uint32_t)(i & (per - 1));
+        y = j >> cs; c = j & (cpr - 1);
+    } else {
+        blk = i / per;
+        const uint32_t j = (uint32_t)(i - blk * per);
+        y = j / cpr; c = j - y * cpr;
     }
+    const uint8_t* ps_ = src + blk * src_block_pitch + (size_t)y * src_stride + c * CS;
+    const uint8_t* pp = pred + blk * pred_block_pitch + (size_t)y * pred_stride + c * CS;
+    int16_t* pr = res + blk * res_block_pitch + (size_t)y * res_stride + c * CS;
+    uint8_t vs[CS], vp[CS];
+    __builtin_memcpy(vs, ps_, CS); __builtin_memcpy(vp, pp, CS);
+    int16_t o[CS];
+#pragma unroll
+    for (int k = 0; k < CS; k++) o[k] = (int16_t)((int)vs[k] - (int)vp[k]);
+    __builtin_memcpy(pr, o, 2 * CS);
 }
 
 // ---------------------------------------------------------------------------

@@ -78,7 +78,9 @@ __device__ __forceinline__ void inv1d(int kind, int (&x)[N], int lo, int hi) {
     } else if constexpr (N == 32) {
         if (kind == K1D_IDTX) svt_iidentity32<BIT>(x, lo, hi); else svt_idct32<BIT>(x, lo, hi);
     } else {
-        svt_idct64<BIT>(x, lo, hi);
+        // elements 32..63 of every 64-point inverse input are zero in AV1 (only 32x32 coefficients are
+        // coded, EbTransforms.c:8226-8240; the callers zero-fill them): zero-propagated network
+        svt_idct64_low32<BIT>(x, lo, hi);
     }
 }
 

@@ -471,6 +471,42 @@ extern "C" int svt_hip_fwd_quant_sad_batch(const uint8_t* d_src, const uint8_t* 
     return launch_status("fwd_quant_sad_32x32");
 }
 
+extern "C" int svt_hip_encode_recon_batch(const uint8_t* d_src, const uint8_t* d_pred, size_t nblocks, int tx_size,
+                                          int tx_type, const int16_t* zbin, const int16_t* round, const int16_t* quant,
+                                          const int16_t* quant_shift, const int16_t* dequant, const int16_t* d_iscan,
+                                          int32_t* d_coeff, int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob,
+                                          uint32_t* d_sad, uint8_t* d_recon, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_src || !d_pred || !d_qcoeff || !d_eob || !d_recon || !d_iscan || !zbin || !round || !quant || !quant_shift || !dequant)
+        return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    if (!txfm_allowed(tx_size, tx_type)) return set_err(SVT_HIP_ERR_INVALID, "tx_size %d / tx_type %d not defined by the reference", tx_size, tx_type);
+    if (d_recon == d_src || d_recon == d_pred) return set_err(SVT_HIP_ERR_INVALID, "d_recon must not alias d_src / d_pred");
+    if (nblocks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "nblocks too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (tx_size == SVT_TX_32X32 && (tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX)) {
+        const QParams qp = make_qparams(zbin, round, quant, quant_shift, dequant, 1);
+        bool ok = qp.fast_ok;
+        for (int i = 0; i < 2; i++) ok = ok && qp.quant_shift[i] >= 0 && qp.dequant[i] >= 0 && qp.round[i] >= 0;
+        if (ok && ((d_coeff != nullptr) == (d_dqcoeff != nullptr))) {
+            const uint32_t grid = (uint32_t)((nblocks + 2 * F32_WAVES - 1) / (2 * F32_WAVES));
+#define ENC32(KEEP, SAD) hipLaunchKernelGGL((enc32_kernel<KEEP, SAD>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, d_pred, d_recon, \
+                                         d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks)
+            if (d_coeff) { if (d_sad) ENC32(true, true); else ENC32(true, false); }
+            else { if (d_sad) ENC32(false, true); else ENC32(false, false); }
+#undef ENC32
+            return launch_status("encode_recon_32x32");
+        }
+    }
+    // composed path: the two batched stages around a device copy of the prediction
+    if (!d_coeff || !d_dqcoeff) return set_err(SVT_HIP_ERR_INVALID, "this size/type/quantizer needs d_coeff and d_dqcoeff");
+    if (int rc = svt_hip_fwd_quant_sad_batch(d_src, d_pred, nblocks, tx_size, tx_type, zbin, round, quant, quant_shift, dequant,
+                                             d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, stream)) return rc;
+    const size_t pels = (size_t)kTxW[tx_size] * kTxH[tx_size];
+    HIP_TRY(hipMemcpyAsync(d_recon, d_pred, pels * nblocks, hipMemcpyDeviceToDevice, s));
+    return svt_hip_inv_txfm2d_add_batch(d_dqcoeff, d_recon, 0, kTxW[tx_size], pels, nullptr, nblocks, tx_size, tx_type, 8, stream);
+}
+
 template <int W, int H>
 int launch_fq(const void* src, uint32_t ss, const void* pred, uint32_t ps, const uint32_t* xy, size_t n, int is16, int tx_type,
               const QParams& qp, const int16_t* iscan, int32_t* co, int32_t* q, int32_t* dq, uint16_t* eob, uint32_t* sad,
@@ -586,11 +622,18 @@ extern "C" int svt_hip_residual_batch(const uint8_t* d_src, uint32_t src_stride,
     if (nblocks == 0) return SVT_HIP_OK;
     const uint32_t rcs = (width & 15) == 0 ? 16u : ((width & 7) == 0 ? 8u : ((width & 3) == 0 ? 4u : 1u));
     const size_t total = (size_t)(width / rcs) * height * nblocks;
-    size_t grid = (total + 255) / 256;
-    if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(residual_kernel, dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_src, src_stride,
-                       src_block_pitch, d_pred, pred_stride, pred_block_pitch, d_res, res_stride, res_block_pitch,
-                       width, height, (uint32_t)nblocks);
+    const size_t grid = (total + 255) / 256;
+    if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+    const uint32_t cpr = width / rcs;
+    const size_t per = (size_t)cpr * height;
+    const bool pow2 = (cpr & (cpr - 1)) == 0 && (per & (per - 1)) == 0;
+#define RESL(CS, P2) hipLaunchKernelGGL((residual_kernel<CS, P2>), dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_src, src_stride, \
+                       src_block_pitch, d_pred, pred_stride, pred_block_pitch, d_res, res_stride, res_block_pitch,   \
+                       width, height, (uint32_t)nblocks)
+#define RESC(CS) if (pow2) RESL(CS, true); else RESL(CS, false)
+    if (rcs == 16) { RESC(16); } else if (rcs == 8) { RESC(8); } else if (rcs == 4) { RESC(4); } else { RESC(1); }
+#undef RESC
+#undef RESL
     return launch_status("residual");
 }
 

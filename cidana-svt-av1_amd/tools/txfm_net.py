@@ -476,6 +476,73 @@ def build_inv(kind: str, n: int) -> Net:
     return INV_BUILDERS[kind](n)
 
 
+def specialize_zero_inputs(net: Net, nz: int, name: str) -> Net:
+    """Network for inputs whose elements >= nz are known to be zero (AV1 64-point
+    inverse: only the first 32 coefficients of a row / column can be non-zero,
+    EbTransforms.c:8226-8240).  Zeros are propagated and the ops they kill are
+    dropped; a half_btf with one zero operand becomes the one-term form
+    ('hb1', w, a) = (w*a + 2^(bit-1)) >> bit — bit-identical to the full network
+    on such inputs (tests/test_txfm_net.py)."""
+    Z = -1
+    out = Net(n_in=net.n_in, name=name)
+    m: List[int] = []
+    clamp_of = {}                      # (new id, which) -> new id of its clamp
+    for op in net.ops:
+        k = op[0]
+        if k == "in":
+            r = Z if op[1] >= nz else out._emit(op)
+        elif k == "add":
+            a, b = m[op[1]], m[op[2]]
+            r = Z if (a == Z and b == Z) else (a if b == Z else (b if a == Z else out._emit(("add", a, b))))
+        elif k == "sub":
+            a, b = m[op[1]], m[op[2]]
+            r = Z if (a == Z and b == Z) else (a if b == Z else (out._emit(("neg", b)) if a == Z else out._emit(("sub", a, b))))
+        elif k == "neg":
+            r = Z if m[op[1]] == Z else out._emit(("neg", m[op[1]]))
+        elif k == "hb":
+            a, b = m[op[2]], m[op[4]]
+            if a == Z and b == Z:
+                r = Z
+            elif b == Z:
+                r = out._emit(("hb1", op[1], a))
+            elif a == Z:
+                r = out._emit(("hb1", op[3], b))
+            else:
+                r = out._emit(("hb", op[1], a, op[3], b))
+        elif k in ("mulc",):
+            r = Z if m[op[2]] == Z else out._emit((k, op[1], m[op[2]]))
+        elif k in ("rsr",):
+            r = Z if m[op[1]] == Z else out._emit((k, m[op[1]]))
+        elif k in ("sqrt2", "shl"):
+            r = Z if m[op[1]] == Z else out._emit((k, m[op[1]], op[2]))
+        elif k == "clamp":
+            a = m[op[1]]
+            if a == Z:
+                r = Z
+            else:
+                src = out.ops[a]
+                if src[0] == "clamp" and src[2] == op[2]:
+                    r = a                                   # clamp(clamp(x)) with the same range
+                elif (a, op[2]) in clamp_of:
+                    r = clamp_of[(a, op[2])]
+                else:
+                    r = out._emit(("clamp", a, op[2]))
+                    clamp_of[(a, op[2])] = r
+        else:
+            raise ValueError(k)
+        m.append(r)
+    zero_id = None
+    for o in net.outs:
+        if m[o] == Z:
+            if zero_id is None:
+                zero_id = out._emit(("zero",))
+            out.outs.append(zero_id)
+        else:
+            out.outs.append(m[o])
+    return out
+
+
+
 # ---------------------------------------------------------------------------
 # numpy evaluator (reference semantics: int32 products, 64-bit sums)
 # ---------------------------------------------------------------------------
@@ -510,6 +577,10 @@ def evaluate(net: Net, x: np.ndarray, cos_bit: int, clamp_ranges=None) -> np.nda
             p0 = _i32(_w(op[1], cos_bit) * vals[op[2]])
             p1 = _i32(_w(op[3], cos_bit) * vals[op[4]])
             v = _i32((p0 + p1 + (1 << (cos_bit - 1))) >> cos_bit)
+        elif k == "hb1":
+            v = _i32((_i32(_w(op[1], cos_bit) * vals[op[2]]) + (1 << (cos_bit - 1))) >> cos_bit)
+        elif k == "zero":
+            v = np.zeros(x.shape[:-1], dtype=np.int64)
         elif k == "mulc":
             v = _i32(_w(op[1], cos_bit) * vals[op[2]])
         elif k == "rsr":

@@ -149,6 +149,24 @@ int svt_hip_fwd_quant_sad_batch(const uint8_t *d_src, const uint8_t *d_pred, siz
                                 const int16_t *d_iscan, int32_t *d_coeff, int32_t *d_qcoeff,
                                 int32_t *d_dqcoeff, uint16_t *d_eob, uint32_t *d_sad, void *stream);
 
+/* Encode-pass chain of the transform blocks of one prediction, as the reference runs it per block
+ * in Av1EncodeLoop (EbCodingLoop.c:545-950):
+ *   residual = src - pred              ResidualKernel                 (EbCodingLoop.c:617)
+ *   coeff    = FwdTxfm2d(residual)     av1_estimate_transform         (EbCodingLoop.c:632)
+ *   q,dq,eob = quantize_b(coeff)       av1_quantize_inv_quantize      (EbCodingLoop.c:647)
+ *   recon    = pred + InvTxfm2d(dq)    av1_inv_transform_recon8bit    (EbCodingLoop.c:753)
+ * (+ sad = SAD(src, pred) when d_sad != NULL).  8-bit, dense W*H blocks; d_recon must not alias
+ * d_src / d_pred.  TX_32X32 with DCT_DCT or IDTX runs ONE fused kernel in which coefficients and
+ * residual never leave the CU (7 174 B of HBM traffic per block instead of 20 486); d_coeff and
+ * d_dqcoeff are optional there (NULL = not written).  Every other size/type runs
+ * svt_hip_fwd_quant_planes_batch + a device copy + svt_hip_inv_txfm2d_add_batch and needs both buffers. */
+int svt_hip_encode_recon_batch(const uint8_t *d_src, const uint8_t *d_pred, size_t nblocks, int tx_size,
+                               int tx_type, const int16_t *zbin, const int16_t *round,
+                               const int16_t *quant, const int16_t *quant_shift, const int16_t *dequant,
+                               const int16_t *d_iscan, int32_t *d_coeff, int32_t *d_qcoeff,
+                               int32_t *d_dqcoeff, uint16_t *d_eob, uint32_t *d_sad, uint8_t *d_recon,
+                               void *stream);
+
 /* BASELINE.json configs[1]: FwdTxfm2d + quantize on a batch of int16 residual blocks
  * (dense W*H per block) — av1_estimate_transform + av1_quantize_inv_quantize
  * (EbFullLoop.c:763, 780).  TX_32X32 8-bit runs the tuned fused kernel. */

@@ -1,0 +1,99 @@
+"""GPU parity of the encode-pass chain svt_hip_encode_recon_batch (residual -> forward -> quantize /
+dequantize -> inverse + prediction) against the CPU oracle's separate stages, i.e. the reference call
+sequence of Av1EncodeLoop (EbCodingLoop.c:545-950).  Bit-exact; there is no reference unit test for the
+chain as a whole, so the pins are the per-stage oracle functions (themselves pinned in
+test_oracle_vs_ref.py / test_oracle_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+import svtlibs
+from svtlibs import TX_H, TX_W, ptr
+from test_gpu_parity import dev, make_pixels, oracle_chain
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_recon(pred, dq, tx_size, tx_type):
+    O = svtlibs.oracle()
+    n, h, w = pred.shape
+    rec = pred.copy()
+    full = np.zeros(w * h, np.int32)
+    for i in range(n):
+        full[:] = 0
+        full[:dq.shape[1]] = dq[i]
+        O.svt_oracle_inv_txfm2d_add_u8(ptr(full), ptr(rec[i]), w, tx_type, tx_size)
+    return rec
+
+
+def check(dsp, src, pred, tx_size, tx_type, qindex, keep):
+    qt = svtlibs.quant_tables(8)
+    qrow = {k: v[qindex].copy() for k, v in qt.items()}
+    _, iscan = svtlibs.scan_tables(tx_size, tx_type)
+    out = dsp.encode_recon(dev(src), dev(pred), tx_size, tx_type, qrow, dev(iscan), keep_coeff=keep)
+    torch.cuda.synchronize()
+    rco, rq, rdq, reob, rsad = oracle_chain(src, pred, tx_size, tx_type, qrow)
+    assert np.array_equal(out["qcoeff"].cpu().numpy(), rq)
+    assert np.array_equal(out["eob"].cpu().numpy().view(np.uint16), reob)
+    assert np.array_equal(out["sad"].cpu().numpy().view(np.uint32), rsad)
+    if keep:
+        assert np.array_equal(out["coeff"].cpu().numpy(), rco)
+        assert np.array_equal(out["dqcoeff"].cpu().numpy(), rdq)
+    assert np.array_equal(out["recon"].cpu().numpy(), oracle_recon(pred, rdq, tx_size, tx_type))
+
+
+@pytest.mark.parametrize("qindex", [0, 25, 100, 255])
+@pytest.mark.parametrize("kind", ["random", "extreme", "smooth"])
+@pytest.mark.parametrize("keep", [False, True])
+def test_fused_encode_recon_32x32(dsp, qindex, kind, keep):
+    rng = np.random.default_rng(4242 + qindex)
+    src, pred = make_pixels(rng, 37, 32, 32, kind)             # odd count: half-empty last wave
+    check(dsp, src, pred, 3, 0, qindex, keep)
+
+
+def test_fused_encode_recon_32x32_idtx(dsp):
+    rng = np.random.default_rng(99)
+    src, pred = make_pixels(rng, 21, 32, 32, "smooth")
+    check(dsp, src, pred, 3, 9, 100, False)                     # IDTX
+
+
+@pytest.mark.parametrize("tx_size,tx_type", [(0, 0), (1, 5), (2, 1), (4, 0), (9, 0), (12, 0), (16, 10)])
+def test_composed_encode_recon_other_sizes(dsp, tx_size, tx_type):
+    if not svtlibs.txfm_allowed(tx_size, tx_type):
+        pytest.skip("type not defined for this size")
+    rng = np.random.default_rng(7 + tx_size)
+    src, pred = make_pixels(rng, 11, TX_H[tx_size], TX_W[tx_size], "smooth")
+    check(dsp, src, pred, tx_size, tx_type, 60, True)
+
+
+def test_encode_recon_argument_errors(dsp, pkg):
+    qt = svtlibs.quant_tables(8)
+    qrow = {k: v[100].copy() for k, v in qt.items()}
+    _, iscan = svtlibs.scan_tables(2, 0)
+    src = torch.zeros((3, 16, 16), dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(RuntimeError):                           # composed path needs coeff / dqcoeff buffers
+        dsp.encode_recon(src, src.clone(), 2, 0, qrow, dev(iscan), keep_coeff=False)
+    out = dsp.encode_recon(src[:0], src[:0].clone(), 2, 0, qrow, dev(iscan))     # empty batch is a no-op
+    assert out["recon"].shape[0] == 0
+
+
+def test_encode_recon_full_size_round_trip_property(dsp):
+    """BASELINE-size property: at qindex 0 (lossless-ish step 4) the reconstruction stays within the
+    quantiser's error bound of the source on 2^17 smooth blocks, and equals the two-kernel path."""
+    rng = np.random.default_rng(5)
+    n = 1 << 17
+    g = torch.Generator(device="cuda:0"); g.manual_seed(77)
+    src = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device="cuda:0", generator=g)
+    pred = (src.to(torch.int16) + torch.randint(-6, 7, (n, 32, 32), dtype=torch.int16, device="cuda:0", generator=g)).clamp(0, 255).to(torch.uint8)
+    qt = svtlibs.quant_tables(8)
+    qrow = {k: v[40].copy() for k, v in qt.items()}
+    _, iscan = svtlibs.scan_tables(3, 0)
+    isc = dev(iscan)
+    a = dsp.encode_recon(src, pred, 3, 0, qrow, isc, keep_coeff=False)
+    co, q, dq, eob, sad = dsp.fwd_quant_sad(src, pred, 3, 0, qrow, isc)
+    rec2 = pred.clone()
+    dsp.inv_txfm2d_add(dq, rec2, 3, 0, 8)
+    torch.cuda.synchronize()
+    assert torch.equal(a["recon"], rec2) and torch.equal(a["qcoeff"], q) and torch.equal(a["eob"], eob) and torch.equal(a["sad"], sad)
+    err = (a["recon"].to(torch.int16) - src.to(torch.int16)).abs().max().item()
+    assert err <= 24, err

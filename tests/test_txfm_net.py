@@ -59,6 +59,24 @@ def test_inverse_net_equals_oracle(kind, n):
         assert np.array_equal(T.evaluate(net, x, 12, {"stage": bits}), ref)
 
 
+def test_idct64_low32_net_equals_oracle():
+    """The zero-propagated 64-point inverse (inputs 32..63 = 0, the only way AV1 uses it) against the
+    oracle's full av1_idct64_new restatement on such inputs, including extreme values."""
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(6464)
+    net = T.specialize_zero_inputs(T.build_inv("dct", 64), 32, "idct64_low32")
+    assert sum(1 for op in net.ops if op[0] == "in") == 32
+    for bits in (16, 18, 20):
+        x = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=(96, 64)).astype(np.int32)
+        x[:20] >>= 5
+        x[20] = (1 << (bits - 1)) - 1; x[21] = -(1 << (bits - 1))
+        x[:, 32:] = 0
+        ref = np.zeros_like(x)
+        for i in range(x.shape[0]):
+            O.svt_oracle_inv_txfm1d(KIND["dct"], 64, ptr(np.ascontiguousarray(x[i])), ptr(ref[i]), 12, bits)
+        assert np.array_equal(T.evaluate(net, x, 12, {"stage": bits}), ref)
+
+
 def test_generated_header_is_current():
     """csrc/gen/txfm1d_gen.h must be exactly what gen_device.py emits."""
     cur = open(os.path.join(ROOT, "cidana-svt-av1_amd", "csrc", "gen", "txfm1d_gen.h")).read()

@@ -84,6 +84,15 @@ if want("pixel"):
     rec("sse_32x32", n, 2056, timeit(lambda: dsp.sse(a, b)))
     rec("residual_32x32", n, 4096, timeit(lambda: dsp.residual(a, b)))
     del a, b
+# fused encode-pass chain (residual -> fwd -> quant/dequant -> inverse -> recon), 32x32
+if want("encode_recon"):
+    n = 1 << 20
+    src = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device=dev)
+    pred = (src.to(torch.int16) + torch.randint(-20, 21, (n, 32, 32), dtype=torch.int16, device=dev)).clamp(0, 255).to(torch.uint8)
+    _, isc = svtlibs.scan_tables(3, 0); iscan = torch.from_numpy(isc).to(dev)
+    rec(f"encode_recon_32x32_fused(qcoeff+recon)", n, 2048 + 4096 + 1024 + 6, timeit(lambda: dsp.encode_recon(src, pred, 3, 0, qrow, iscan, keep_coeff=False)))
+    rec(f"encode_recon_32x32_fused(+coeff,dqcoeff)", n, 2048 + 3 * 4096 + 1024 + 6, timeit(lambda: dsp.encode_recon(src, pred, 3, 0, qrow, iscan, keep_coeff=True)))
+    del src, pred
 # intra
 if want("intra"):
     n = 1 << 21
