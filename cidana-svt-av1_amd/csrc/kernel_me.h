@@ -59,23 +59,36 @@ __global__ __launch_bounds__(ME_THREADS) void me_sb_search_kernel(
         for (uint32_t c = tid & 15; c < cpr; c += 16)
             for (uint32_t y0 = tid >> 4; y0 < win_h; y0 += 64) {       // 4 loads in flight per lane
                 uint4 v[4];
+                uint32_t back[4];           // a chunk that would end past the footprint is fetched `back` bytes earlier
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t y = y0 + 16 * k;
                     v[k] = make_uint4(0, 0, 0, 0);
+                    back[k] = 0;
                     if (y < win_h) {
                         const size_t off = (size_t)y * ref_stride + c * 16;
                         if (off + 16 <= span) __builtin_memcpy(&v[k], gr + off, 16);
-                        else {
-                            uint8_t* vb = reinterpret_cast<uint8_t*>(&v[k]);
-                            for (uint32_t b = 0; b < 16; b++) if (off + b < span) vb[b] = gr[off + b];
+                        else if (off < span) {
+                            // the footprint's last 16 bytes (span >= 64 here), stored shifted: the bytes it
+                            // re-writes are the same data or row slack.  (Byte-wise global loads would cost
+                            // one memory latency each.)
+                            back[k] = (uint32_t)(off - (span - 16));
+                            __builtin_memcpy(&v[k], gr + (span - 16), 16);
                         }
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t y = y0 + 16 * k;
-                    if (y < win_h) *reinterpret_cast<uint4*>(s_ref + (size_t)y * wpitch + c * 16) = v[k];
+                    if (y < win_h) {
+                        if (back[k] == 0) *reinterpret_cast<uint4*>(s_ref + (size_t)y * wpitch + c * 16) = v[k];
+                        else {
+                            const uint8_t* vb = reinterpret_cast<const uint8_t*>(&v[k]);
+                            uint8_t* d = s_ref + (size_t)y * wpitch + c * 16 - back[k];
+#pragma unroll
+                            for (int b = 0; b < 16; b++) d[b] = vb[b];
+                        }
+                    }
                 }
             }
     }

@@ -301,15 +301,23 @@ __global__ __launch_bounds__(256) void sad_search_q_kernel(
             for (uint32_t r0 = ly; r0 < nrows; r0 += 4 * lys)
                 for (uint32_t c = lx; c < cpr; c += rxs) {
                     uint4 v[4];
+                    uint32_t back[4];       // a chunk that would end past the footprint is fetched `back` bytes earlier
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const uint32_t rr = r0 + k * lys;
                         v[k] = make_uint4(0, 0, 0, 0);
+                        back[k] = 0;
                         if (rr < nrows) {
                             const size_t off = (plain ? (size_t)rr * ref_stride_raw
                                                       : (size_t)(rr / height) * ref_stride_raw + (size_t)(rr % height) * ref_stride) + c * 16;
                             if (off + 16 <= span) {
                                 __builtin_memcpy(&v[k], gr + off, 16);
+                            } else if (span >= 16 && off < span && (plain || off - (span - 16) <= c * 16)) {
+                                // the last 16 bytes of the footprint, stored shifted: the bytes re-written before
+                                // the chunk are the same data (or row slack); byte-wise global loads here cost one
+                                // memory latency EACH and ran for every block of a dense window array
+                                back[k] = (uint32_t)(off - (span - 16));
+                                __builtin_memcpy(&v[k], gr + (span - 16), 16);
                             } else {
                                 uint8_t* vb = reinterpret_cast<uint8_t*>(&v[k]);
                                 for (uint32_t b = 0; b < 16; b++) if (off + b < span) vb[b] = gr[off + b];
@@ -319,7 +327,15 @@ __global__ __launch_bounds__(256) void sad_search_q_kernel(
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const uint32_t rr = r0 + k * lys;
-                        if (rr < nrows) *reinterpret_cast<uint4*>(s_ref + rr * wpitch + c * 16) = v[k];
+                        if (rr < nrows) {
+                            if (back[k] == 0) *reinterpret_cast<uint4*>(s_ref + rr * wpitch + c * 16) = v[k];
+                            else {
+                                const uint8_t* vb = reinterpret_cast<const uint8_t*>(&v[k]);
+                                uint8_t* d = s_ref + rr * wpitch + c * 16 - back[k];
+#pragma unroll
+                                for (int b = 0; b < 16; b++) d[b] = vb[b];
+                            }
+                        }
                     }
                 }
         }
@@ -382,6 +398,180 @@ __global__ __launch_bounds__(256) void sad_search_q_kernel(
             const int cand = (int)(key & 0xffffffffu);
             // reference initialises best_sad = 0xffffff and only updates on strict '<'
             if (sadv < 0xffffffu) {
+                best_sad[ob] = sadv;
+                best_x[ob] = (int16_t)(cand % search_w);
+                best_y[ob] = (int16_t)(cand / search_w);
+            } else {
+                best_sad[ob] = 0xffffffu;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// SAD search for small blocks (CW*CH <= 256 pixels: the whole source block fits in 64 VGPRs), plain
+// reference window.  A lane owns FOUR horizontally adjacent candidates of TWO vertically adjacent
+// search rows: every reference row it reads from LDS (CW/4+1 dwords) feeds 2*CW/4 v_qsad_pk_u16_u8
+// against two source rows held in registers, instead of CW/4 qsads per CW/4+1 reference and CW/4
+// source dwords in sad_search_q_kernel - the LDS pipe, not v_qsad, was that kernel's limiter at
+// 16x16 (profiles/r01_valu_issue_cost_2.txt: v_qsad costs 6 plain instructions, a ds_read_b32 two
+// LDS cycles).  A candidate's whole SAD fits its packed u16 accumulator (256 * 255 < 2^16).
+// Argmin key and outputs as in sad_search_q_kernel.
+// ---------------------------------------------------------------------------
+template <int CW, int CH>
+__global__ __launch_bounds__(256) void sad_search_q2_kernel(
+    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
+    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
+    unsigned long long* __restrict__ best_sad, int16_t* __restrict__ best_x, int16_t* __restrict__ best_y,
+    uint32_t ref_lds_bytes, uint32_t lpb, uint32_t cpr_magic, uint32_t nblocks) {
+    static_assert(CW % 4 == 0 && CW * CH <= 256, "source block must fit 64 VGPRs");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int WQ = CW / 4;
+    constexpr uint32_t SRC_BYTES = (CW * CH + 15) & ~15;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lsh = __builtin_ctz(lpb);
+    const uint32_t slot = tid >> lsh, l = tid & (lpb - 1);
+    const uint32_t slots = blockDim.x >> lsh;
+    const uint32_t blk = blockIdx.x * slots + slot;
+    const bool valid = blk < nblocks;
+    const uint32_t win_w = CW + search_w - 1;
+    const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+    const uint32_t nrows = (uint32_t)(search_h + CH - 1);
+    // LDS: all source blocks first (16-B aligned), then the windows at a pitch of ref_lds_bytes == 8 (mod 32)
+    // bytes: with the 48-B row pitch of a 23-wide window the 32 lanes of a ds_read_b32 group (4 blocks x
+    // 4 row pairs x 2 column groups) then hit 32 different banks (measured before: 56 % of the LDS
+    // cycles were bank conflicts).  Window chunks are therefore written as two 8-B halves.
+    uint8_t* s_src = smem + (size_t)slot * SRC_BYTES;
+    uint8_t* s_ref = smem + (size_t)slots * SRC_BYTES + (size_t)slot * ref_lds_bytes;
+    if (valid) {
+        const uint8_t* gs = src + (size_t)blk * src_block_pitch;
+        const uint8_t* gr = ref + (size_t)blk * ref_block_pitch;
+        // ---- stage the source block and the window.  One flat list of 16-B chunks (source rows first,
+        // then window rows of cpr chunks); a lane issues up to SU loads back to back and only then
+        // writes LDS, so the block costs ONE memory latency (three dependent load -> LDS phases made a
+        // wave live 9 us for 1 us of arithmetic).  Chunks are loaded whole when they end inside the
+        // window's own footprint (row tails over-read into the next row: harmless, only excluded
+        // candidates can touch those bytes); the few that do not are fetched byte-wise afterwards.
+        constexpr uint32_t CS = CW % 16 == 0 ? 16 : (CW % 8 == 0 ? 8 : 4);
+        constexpr uint32_t NSRC = CW * CH / CS;
+        constexpr int SU = 4;
+        const uint32_t cpr = (win_w + 15) >> 4;
+        const uint32_t nref = nrows * cpr;
+        const size_t span = (size_t)(nrows - 1) * ref_stride + win_w;
+        // every load below is unconditional (clamped index / clamped offset), so nothing separates them
+        for (uint32_t i0 = l; i0 < NSRC || i0 < nref; i0 += SU * lpb) {
+            uint4 vs[SU], vr[SU];
+            uint32_t rdst[SU], tdst[SU];
+#pragma unroll
+            for (int k = 0; k < SU; k++) {
+                const uint32_t i = min(i0 + k * lpb, NSRC - 1);
+                vs[k] = make_uint4(0, 0, 0, 0);
+                __builtin_memcpy(&vs[k], gs + (size_t)(i / (CW / CS)) * src_stride + (i % (CW / CS)) * CS, CS);
+            }
+#pragma unroll
+            for (int k = 0; k < SU; k++) {
+                const uint32_t j = min(i0 + k * lpb, nref - 1);
+                const uint32_t rr = cpr == 1 ? j : __umulhi(j, cpr_magic), c = j - rr * cpr;     // j / cpr, j % cpr
+                const size_t off = (size_t)rr * ref_stride + c * 16;
+                // a chunk that would end past the window's footprint is fetched as the LAST 16 bytes of the
+                // footprint instead and stored `delta` bytes earlier (the bytes it re-writes are the same data)
+                const size_t offc = off + 16 <= span ? off : span - 16;
+                __builtin_memcpy(&vr[k], gr + offc, 16);
+                const bool want = i0 + k * lpb < nref;
+                rdst[k] = (want && off == offc) ? rr * wpitch + c * 16 : ~0u;
+                tdst[k] = (want && off != offc) ? rr * wpitch + c * 16 - (uint32_t)(off - offc) : ~0u;
+            }
+            // All loads are consumed here, so they are issued above and waited for once; without this the
+            // predicated LDS writes below let LLVM sink each load into its branch (one latency per chunk).
+            static_assert(SU == 4, "operand list below");
+            asm volatile("" ::"v"(vs[0].x), "v"(vs[1].x), "v"(vs[2].x), "v"(vs[3].x), "v"(vr[0].x), "v"(vr[1].x), "v"(vr[2].x), "v"(vr[3].x));
+#pragma unroll
+            for (int k = 0; k < SU; k++) {
+                const uint32_t i = i0 + k * lpb;
+                if (i < NSRC) __builtin_memcpy(s_src + i * CS, &vs[k], CS);
+                if (rdst[k] != ~0u) {
+                    uint2* rd = reinterpret_cast<uint2*>(s_ref + rdst[k]);
+                    rd[0] = make_uint2(vr[k].x, vr[k].y); rd[1] = make_uint2(vr[k].z, vr[k].w);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < SU; k++)
+                if (tdst[k] != ~0u) {                      // footprint tail: byte-granular LDS store, no global access
+                    const uint8_t* vb = reinterpret_cast<const uint8_t*>(&vr[k]);
+                    for (int bb = 0; bb < 16; bb++) s_ref[tdst[k] + bb] = vb[bb];
+                }
+        }
+    }
+    __syncthreads();
+    unsigned long long best = ~0ull;
+    if (valid) {
+        // the whole source block into registers (broadcast reads: the lanes of a block share addresses)
+        uint32_t sreg[CH][WQ];
+#pragma unroll
+        for (int y = 0; y < CH; y++) {
+            if constexpr (WQ % 4 == 0) {
+#pragma unroll
+                for (int i = 0; i < WQ / 4; i++) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(s_src + y * CW + 16 * i);
+                    sreg[y][4 * i] = a.x; sreg[y][4 * i + 1] = a.y; sreg[y][4 * i + 2] = a.z; sreg[y][4 * i + 3] = a.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < WQ; q++) sreg[y][q] = *reinterpret_cast<const uint32_t*>(s_src + y * CW + 4 * q);
+            }
+        }
+        const int gx = (search_w + 3) >> 2, gy = (search_h + 1) >> 1;
+        const int ngroups = gx * gy;
+        for (int g = (int)l; g < ngroups; g += (int)lpb) {
+            const int yp = g / gx, xg = g - yp * gx;
+            const int ysA = 2 * yp;
+            const bool hasB = ysA + 1 < search_h;
+            unsigned long long accA = 0, accB = 0;
+            const uint8_t* rbase = s_ref + (size_t)ysA * wpitch + xg * 4;
+#pragma unroll
+            for (int r = 0; r <= CH; r++) {
+                // row ysA + CH is past the window when the pair has no second row: re-read the last one
+                const uint32_t* rrow = reinterpret_cast<const uint32_t*>(rbase + (size_t)((r == CH && !hasB) ? CH - 1 : r) * wpitch);
+                uint32_t rw[WQ + 1];
+#pragma unroll
+                for (int q = 0; q <= WQ; q++) rw[q] = rrow[q];
+#pragma unroll
+                for (int q = 0; q < WQ; q++) {
+                    const unsigned long long pr = ((unsigned long long)rw[q + 1] << 32) | rw[q];
+                    if (r < CH) accA = __builtin_amdgcn_qsad_pk_u16_u8(pr, sreg[r < CH ? r : 0][q], accA);
+                    if (r >= 1) accB = __builtin_amdgcn_qsad_pk_u16_u8(pr, sreg[r >= 1 ? r - 1 : 0][q], accB);
+                }
+            }
+            const int xs0 = xg * 4;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                if (xs0 + jj < search_w) {
+                    const unsigned sa = (unsigned)((accA >> (16 * jj)) & 0xffffu), sb = (unsigned)((accB >> (16 * jj)) & 0xffffu);
+                    const unsigned long long ka = ((unsigned long long)sa << 32) | (unsigned)(ysA * search_w + xs0 + jj);
+                    best = ka < best ? ka : best;
+                    if (hasB) {
+                        const unsigned long long kb = ((unsigned long long)sb << 32) | (unsigned)((ysA + 1) * search_w + xs0 + jj);
+                        best = kb < best ? kb : best;
+                    }
+                }
+            }
+        }
+    }
+    for (uint32_t m = lpb >> 1; m >= 1; m >>= 1) {
+        const unsigned long long o = __shfl_xor(best, (int)m, 64);
+        best = o < best ? o : best;
+    }
+    __syncthreads();
+    unsigned long long* s_out = reinterpret_cast<unsigned long long*>(smem);     // staging is dead
+    if (l == 0) s_out[slot] = valid ? best : ~0ull;
+    __syncthreads();
+    if (tid < slots) {
+        const uint32_t ob = blockIdx.x * slots + tid;
+        if (ob < nblocks) {
+            const unsigned long long key = s_out[tid];
+            const unsigned sadv = (unsigned)(key >> 32);
+            const int cand = (int)(key & 0xffffffffu);
+            if (sadv < 0xffffffu) {          // reference initialises best_sad = 0xffffff, strict '<'
                 best_sad[ob] = sadv;
                 best_x[ob] = (int16_t)(cand % search_w);
                 best_y[ob] = (int16_t)(cand / search_w);

@@ -36,6 +36,7 @@ int g_tune_f32_nt = 0;
 int g_tune_f32_qmode1 = 0;
 int g_tune_no_staged = 0;
 int g_tune_no_qsad = 0;
+int g_tune_no_q2 = 0;
 int g_tune_inv32_waves = 4;
 int g_tune_inv32_var = 0;
 
@@ -277,6 +278,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "f32_qmode1")) { g_tune_f32_qmode1 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_staged")) { g_tune_no_staged = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_qsad")) { g_tune_no_qsad = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_q2")) { g_tune_no_q2 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "inv32_waves")) { g_tune_inv32_waves = value; return SVT_HIP_OK; }
     if (!strcmp(key, "inv32_var")) { g_tune_inv32_var = value; return SVT_HIP_OK; }
     return set_err(SVT_HIP_ERR_INVALID, "unknown tuning key %s", key);
@@ -652,6 +654,35 @@ extern "C" int svt_hip_sad_search_batch(const uint8_t* d_src, uint32_t src_strid
     const uint32_t win_w = width + search_area_width - 1;
     const bool plain = ref_stride == ref_stride_raw;
     const uint32_t nrows = plain ? (uint32_t)(search_area_height + height - 1) : (uint32_t)search_area_height * height;
+    if (plain && !g_tune_no_qsad && !g_tune_no_q2 && ((width == 16 && height == 16) || (width == 8 && height == 8)) &&
+        (uint32_t)search_area_width * (uint32_t)search_area_height > 0) {
+        // small blocks: source block in registers, 4 x 2 candidates per lane
+        const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+        const uint32_t src_bytes = (width * height + 15) & ~15u;
+        const uint32_t groups = (uint32_t)((search_area_width + 3) / 4) * (uint32_t)((search_area_height + 1) / 2);
+        uint32_t lpb = 1;
+        while (lpb < groups && lpb < 64) lpb <<= 1;
+        // window + one spare row + 16 spare bytes per lane, padded to 8 (mod 32) bytes (LDS bank spread, see the kernel)
+        uint32_t ref_bytes = wpitch * (nrows + 1) + 16 * lpb;
+        ref_bytes = ((ref_bytes + 31) & ~31u) + 8;
+        const uint32_t per_blk = src_bytes + ref_bytes;
+        if (per_blk <= 64 * 1024) {
+            uint32_t threads = 256;
+            while (threads > lpb && (size_t)(threads / lpb) * per_blk > 64 * 1024) threads >>= 1;
+            const uint32_t slots = threads / lpb;
+            const uint32_t grid = (uint32_t)((nblocks + slots - 1) / slots);
+#define SSQ2(CW, CH)                                                                                                    \
+    hipLaunchKernelGGL((sad_search_q2_kernel<CW, CH>), dim3(grid), dim3(threads), (size_t)slots * per_blk, (hipStream_t)stream, \
+                       d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, (int)search_area_width,         \
+                       (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, ref_bytes, lpb, cpr_magic,           \
+                       (uint32_t)nblocks)
+            // exact j / cpr for j < 2^16 chunks (cpr <= 8): floor(2^32 / cpr) + 1
+            const uint32_t cpr_magic = (uint32_t)(0x100000000ull / ((win_w + 15) >> 4)) + 1u;
+            if (width == 16) SSQ2(16, 16); else SSQ2(8, 8);
+#undef SSQ2
+            return launch_status("sad_search_q2");
+        }
+    }
     if ((width & 3) == 0 && !g_tune_no_qsad) {
         // quad-SAD kernel: 4 candidates per lane
         const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;

@@ -104,8 +104,9 @@ if want("intra"):
     del ab, lf, out
 # ME 85-PU search, 1080p worth of SBs
 if want("me_sb"):
-    n = 510
-    src = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 127, 128), dtype=torch.uint8, device=dev)
-    ms = timeit(lambda: dsp.me_sb_search(src, ref, 64, 64), iters=4)
-    rec("me_sb_search_64x64area", n, 4096 + 127 * 127 + 680, ms, {"search_points_per_s_G": round(n * 4096 / ms / 1e6, 3)})
+    for n, label in ((510, "1 ref"), (2040, "4 refs")):      # 510 SBs of a 1080p frame x reference pictures
+        src = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 127, 128), dtype=torch.uint8, device=dev)
+        ms = timeit(lambda: dsp.me_sb_search(src, ref, 64, 64), iters=4)
+        rec(f"me_sb_search_64x64area_{n}SBs({label})", n, 4096 + 127 * 127 + 680, ms, {"search_points_per_s_G": round(n * 4096 / ms / 1e6, 3)})
+        del src, ref
 json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "kernels.json"), "w"), indent=1)
