@@ -198,4 +198,224 @@ __global__ __launch_bounds__(ME_THREADS) void me_sb_search_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// me_sb_search16_kernel — the same search for search areas whose width is a multiple of 16 (the
+// encoder's 64x64 default), written against the measured gfx950 costs.
+//
+// A lane owns SIXTEEN horizontally adjacent search points of one search row (xs0 % 16 == 0): the 20
+// reference dwords it needs per SB row are five ALIGNED ds_read_b128, the source row is four
+// broadcast ds_read_b128, and they feed 64 v_qsad_pk_u16_u8 (4 point groups x 16 dwords) - 9 wide LDS
+// reads per 64 qsads instead of 33 dword reads per 16.  With 256 lanes one pass covers 64 x 64
+// points, so no per-lane running best survives a pass: the 8x8 / 16x16 SADs stay PACKED (4 x u16 per
+// 64-bit accumulator, sums fit: 16x16 on even rows <= 32 640), a PU's 16 keys are built straight from
+// the packed words (v_lshl_or / v_and_or + v_add: key = sad << 16 | point) and min-reduced with
+// v_min3, then over the wave, and lane 0 folds the result into the workgroup's LDS table.  32x32 sums
+// are kept as two packed 16-row halves (each <= 65 280) and widened once per 32-row half.
+// Register budget ~200 VGPRs: two workgroups per CU (the first kernel: 256 VGPRs + 256 AGPRs + scratch,
+// one wave per SIMD, an s_waitcnt after almost every LDS read).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned me_key16_min(const unsigned long long (&a)[4], unsigned idb) {
+    // a[g] = packed SADs of points 4g .. 4g+3; returns min over the 16 points of (sad << 16 | idb + point)
+    unsigned best = 0xffffffffu;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const unsigned lo = (unsigned)a[g], hi = (unsigned)(a[g] >> 32);
+        const unsigned k0 = ((lo << 16) | idb) + (4 * g + 0), k1 = ((lo & 0xffff0000u) | idb) + (4 * g + 1);
+        const unsigned k2 = ((hi << 16) | idb) + (4 * g + 2), k3 = ((hi & 0xffff0000u) | idb) + (4 * g + 3);
+        best = min(best, min(k0, k1));
+        best = min(best, min(k2, k3));
+    }
+    return best;
+}
+__device__ __forceinline__ unsigned long long me_pk_add(unsigned long long a, unsigned long long b) {
+    // lane-wise u16 add of two packed words whose lane sums stay below 2^16: two independent 32-bit adds
+    const unsigned lo = (unsigned)a + (unsigned)b, hi = (unsigned)(a >> 32) + (unsigned)(b >> 32);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void me_sb_search16_kernel(
+    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
+    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
+    const int16_t* __restrict__ origins /* [n][2] x,y or NULL */, int x_origin, int y_origin,
+    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t wpitch, uint32_t nblocks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* s_src = reinterpret_cast<uint32_t*>(smem);            // [32 even rows][16 dwords]
+    uint8_t* s_ref = smem + 32 * 64;                                // [(64+sh-1)][wpitch], wpitch % 16 == 0
+    __shared__ unsigned s_red[4][ME_PUS];
+    const uint32_t blk = blockIdx.x;
+    if (blk >= nblocks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t* gs = src + (size_t)blk * src_block_pitch;
+    const uint8_t* gr = ref + (size_t)blk * ref_block_pitch;
+    // ---- stage the even source rows and the reference window (16-B unaligned loads, 4 in flight) ----
+    if (tid < 128) {
+        const int r = tid >> 2, c = tid & 3;
+        uint4 v;
+        __builtin_memcpy(&v, gs + (size_t)(2 * r) * src_stride + c * 16, 16);
+        reinterpret_cast<uint4*>(s_src)[tid] = v;
+    }
+    for (int i = tid; i < 4 * ME_PUS; i += ME_THREADS) (&s_red[0][0])[i] = 0xffffffffu;
+    const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
+    {
+        const uint32_t cpr = (win_w + 15) >> 4;
+        const size_t span = (size_t)(win_h - 1) * ref_stride + win_w;
+        for (uint32_t c = tid & 15; c < cpr; c += 16)
+            for (uint32_t y0 = tid >> 4; y0 < win_h; y0 += 64) {
+                uint4 v[4];
+                uint32_t back[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t y = y0 + 16 * k;
+                    v[k] = make_uint4(0, 0, 0, 0);
+                    back[k] = 0;
+                    if (y < win_h) {
+                        const size_t off = (size_t)y * ref_stride + c * 16;
+                        if (off + 16 <= span) __builtin_memcpy(&v[k], gr + off, 16);
+                        else if (off < span) {           // footprint tail: see me_sb_search_kernel
+                            back[k] = (uint32_t)(off - (span - 16));
+                            __builtin_memcpy(&v[k], gr + (span - 16), 16);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t y = y0 + 16 * k;
+                    if (y < win_h) {
+                        if (back[k] == 0) *reinterpret_cast<uint4*>(s_ref + (size_t)y * wpitch + c * 16) = v[k];
+                        else {
+                            const uint8_t* vb = reinterpret_cast<const uint8_t*>(&v[k]);
+                            uint8_t* d = s_ref + (size_t)y * wpitch + c * 16 - back[k];
+#pragma unroll
+                            for (int b = 0; b < 16; b++) d[b] = vb[b];
+                        }
+                    }
+                }
+            }
+    }
+    __syncthreads();
+
+    const int xqn = search_w >> 4;
+    const int ntasks = xqn * search_h;
+    for (int t0 = 0; t0 < ntasks; t0 += ME_THREADS) {
+        const int t = t0 + tid;
+        const bool act = t < ntasks;
+        const int tc = act ? t : 0;
+        const int ys = tc / xqn, xs0 = (tc - ys * xqn) * 16;
+        const unsigned idb = (unsigned)(ys * search_w + xs0);         // point index of the lane's first point (< 4096)
+        const unsigned dead = act ? 0u : 0xffffffffu;
+        const uint8_t* rbase = s_ref + (size_t)ys * wpitch + xs0;
+        unsigned s64[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) s64[i] = 0;
+#pragma unroll 1
+        for (int h32 = 0; h32 < 2; h32++) {                           // top / bottom 32 rows of the SB
+            unsigned long long PA[2][4], PB[2][4];                    // 32x32 column c32, 16-row half A / B, point group
+#pragma unroll
+            for (int h16 = 0; h16 < 2; h16++) {
+                unsigned long long s16[4][4];                         // [point group][16x16 column]
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++) {
+                    const int band_in = h16 * 2 + kb;                 // band inside the 32-row half (compile time)
+                    unsigned long long acc[4][8];
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+#pragma unroll
+                        for (int bx = 0; bx < 8; bx++) acc[g][bx] = 0;
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        const int row = band_in * 8 + rr * 2;         // SB row inside the half
+                        const uint4* sp = reinterpret_cast<const uint4*>(s_src + (h32 * 16 + (row >> 1)) * 16);
+                        const uint4* rp = reinterpret_cast<const uint4*>(rbase + (size_t)(h32 * 32 + row) * wpitch);
+                        uint32_t sw[16], rw[20];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { const uint4 a = sp[i]; sw[4 * i] = a.x; sw[4 * i + 1] = a.y; sw[4 * i + 2] = a.z; sw[4 * i + 3] = a.w; }
+#pragma unroll
+                        for (int i = 0; i < 5; i++) { const uint4 a = rp[i]; rw[4 * i] = a.x; rw[4 * i + 1] = a.y; rw[4 * i + 2] = a.z; rw[4 * i + 3] = a.w; }
+                        unsigned long long pr[19];                    // dword pairs (d, d+1): odd d costs one register copy, shared by 4 qsads
+#pragma unroll
+                        for (int d = 0; d < 19; d++) pr[d] = ((unsigned long long)rw[d + 1] << 32) | rw[d];
+#pragma unroll
+                        for (int g = 0; g < 4; g++)
+#pragma unroll
+                            for (int q = 0; q < 16; q++)
+                                acc[g][q >> 1] = __builtin_amdgcn_qsad_pk_u16_u8(pr[g + q], sw[q], acc[g][q >> 1]);
+                    }
+                    // ---- 8x8 PUs of this band: 16 points -> one key per PU -> wave -> LDS table ----
+#pragma unroll
+                    for (int bx = 0; bx < 8; bx++) {
+                        const unsigned long long a4[4] = {acc[0][bx], acc[1][bx], acc[2][bx], acc[3][bx]};
+                        const unsigned k = wave_min_u32(me_key16_min(a4, idb) | dead);
+                        const int bx16 = bx >> 1;
+                        const int zc = (bx16 >> 1) * 4 + h16 * 2 + (bx16 & 1);           // z-order inside the half
+                        const int idx = 32 * h32 + 4 * zc + kb * 2 + (bx & 1);
+                        if (lane == 0) s_red[wave][idx] = min(s_red[wave][idx], k);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+#pragma unroll
+                        for (int c16 = 0; c16 < 4; c16++) {
+                            const unsigned long long v = me_pk_add(acc[g][2 * c16], acc[g][2 * c16 + 1]);
+                            s16[g][c16] = kb == 0 ? v : me_pk_add(s16[g][c16], v);
+                        }
+                }
+                // ---- 16x16 PUs of this 16-row band ----
+#pragma unroll
+                for (int c16 = 0; c16 < 4; c16++) {
+                    const unsigned long long a4[4] = {s16[0][c16], s16[1][c16], s16[2][c16], s16[3][c16]};
+                    const unsigned k = wave_min_u32(me_key16_min(a4, idb) | dead);
+                    const int zc = (c16 >> 1) * 4 + h16 * 2 + (c16 & 1);
+                    const int idx = 64 + 8 * h32 + zc;
+                    if (lane == 0) s_red[wave][idx] = min(s_red[wave][idx], k);
+                }
+#pragma unroll
+                for (int c32 = 0; c32 < 2; c32++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const unsigned long long v = me_pk_add(s16[g][2 * c32], s16[g][2 * c32 + 1]);     // <= 65 280 per lane
+                        if (h16 == 0) PA[c32][g] = v; else PB[c32][g] = v;
+                    }
+            }
+            // ---- 32x32 PUs of this half: widen, double (SADs are on every other row), key = sad << 12 | point ----
+#pragma unroll
+            for (int c32 = 0; c32 < 2; c32++) {
+                unsigned best = 0xffffffffu;
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const unsigned a = (unsigned)((PA[c32][g] >> (16 * jj)) & 0xffffu), b = (unsigned)((PB[c32][g] >> (16 * jj)) & 0xffffu);
+                        const unsigned s = (a + b) << 1;
+                        s64[4 * g + jj] += s;
+                        best = min(best, (s << 12) | (idb + 4 * g + jj));
+                    }
+                const unsigned k = wave_min_u32(best | dead);
+                const int idx = 80 + 2 * h32 + c32;
+                if (lane == 0) s_red[wave][idx] = min(s_red[wave][idx], k);
+            }
+        }
+        {
+            unsigned best = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < 16; i++) best = min(best, (s64[i] << 12) | (idb + i));
+            const unsigned k = wave_min_u32(best | dead);
+            if (lane == 0) s_red[wave][84] = min(s_red[wave][84], k);
+        }
+    }
+    __syncthreads();
+    if (tid < ME_PUS) {
+        const unsigned key = min(min(s_red[0][tid], s_red[1][tid]), min(s_red[2][tid], s_red[3][tid]));
+        // PUs 0..79 (8x8, 16x16): sad16 << 16 | point, SAD still to be doubled; 80..84: (2*sad) << 12 | point
+        const unsigned sad = tid < 80 ? (key >> 16) << 1 : key >> 12;
+        const unsigned cand = key & 0xfffu;
+        const int ys = (int)cand / search_w, xs = (int)cand - ys * search_w;
+        const int ox = origins ? origins[2 * blk] : x_origin, oy = origins ? origins[2 * blk + 1] : y_origin;
+        uint32_t* bs = best_sad + (size_t)blk * ME_PUS;
+        uint32_t* bm = best_mv + (size_t)blk * ME_PUS;
+        if (sad < bs[tid]) {
+            bs[tid] = sad;
+            bm[tid] = (((uint32_t)(uint16_t)(ys + oy)) << 18) | (uint32_t)(uint16_t)((xs + ox) << 2);
+        }
+    }
+}
+
 }  // namespace svtdev

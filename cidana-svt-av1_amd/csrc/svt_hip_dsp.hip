@@ -37,6 +37,7 @@ int g_tune_f32_qmode1 = 0;
 int g_tune_no_staged = 0;
 int g_tune_no_qsad = 0;
 int g_tune_no_q2 = 0;
+int g_tune_no_me16 = 0;
 int g_tune_inv32_waves = 4;
 int g_tune_inv32_var = 0;
 
@@ -279,6 +280,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "no_staged")) { g_tune_no_staged = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_qsad")) { g_tune_no_qsad = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_q2")) { g_tune_no_q2 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_me16")) { g_tune_no_me16 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "inv32_waves")) { g_tune_inv32_waves = value; return SVT_HIP_OK; }
     if (!strcmp(key, "inv32_var")) { g_tune_inv32_var = value; return SVT_HIP_OK; }
     return set_err(SVT_HIP_ERR_INVALID, "unknown tuning key %s", key);
@@ -740,6 +742,12 @@ extern "C" int svt_hip_me_sb_search_batch(const uint8_t* d_src, uint32_t src_str
     const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
     const size_t lds = 32 * 64 + (size_t)wpitch * win_h;
     if (lds > 60 * 1024) return set_err(SVT_HIP_ERR_INVALID, "search window needs %zu B of LDS (> 60 KiB)", lds);
+    if ((search_w & 15) == 0 && !g_tune_no_me16) {
+        hipLaunchKernelGGL(me_sb_search16_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
+                           src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
+                           x_origin, y_origin, d_best_sad, d_best_mv, wpitch, (uint32_t)nblocks);
+        return launch_status("me_sb_search16");
+    }
     hipLaunchKernelGGL(me_sb_search_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
                        src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
                        x_origin, y_origin, d_best_sad, d_best_mv, wpitch, (uint32_t)nblocks);

@@ -435,7 +435,7 @@ def test_full_distortion32(dsp, w, h):
         assert (int(got0[i, 0]), int(got0[i, 1])) == (int(out[1]), int(out[1]))
 
 
-@pytest.mark.parametrize("sw,sh", [(1, 1), (8, 8), (13, 7), (64, 64), (48, 16), (5, 33)])
+@pytest.mark.parametrize("sw,sh", [(1, 1), (8, 8), (13, 7), (64, 64), (48, 16), (5, 33), (16, 1), (32, 40), (64, 3), (20, 20)])
 def test_me_sb_search_85_pus(dsp, sw, sh):
     """K6: all 85 PU bests + packed MVs of FullPelSearch_LCU, incl. ties (first in raster order)."""
     O = svtlibs.oracle()
@@ -445,6 +445,7 @@ def test_me_sb_search_85_pus(dsp, sw, sh):
     src = rng.integers(0, 256, size=(n, 64, 64), dtype=np.uint8)
     ref = rng.integers(0, 256, size=(n, rh, rw), dtype=np.uint8)
     ref[0] = 100; src[0] = 101                      # every point ties -> first point wins everywhere
+    ref[3] = 255; src[3] = 0                        # largest possible SADs (packed 16-bit partial sums at their limit)
     if sw > 4 and sh > 3:
         ref[1, 2:66, 3:67] = src[1]                 # exact match at (3, 2)
         ref[2, 0:64, 1:65] = src[2]; ref[2, 1:65, 0:64] = src[2]   # two exact matches: (1,0) before (0,1)
