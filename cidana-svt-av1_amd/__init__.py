@@ -82,6 +82,11 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
                                                  c_int, c_int] + [c_void_p] * 5 + [c_void_p] * 7 + [c_void_p]
     L.svt_hip_me_sb_search_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t, c_int, c_int,
                                              c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    L.svt_hip_me_sb_search_planes_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p, c_int, c_int,
+                                                    c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    L.svt_hip_sad_search_planes_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_void_p, c_uint32, c_uint32, c_void_p,
+                                                  c_uint32, c_uint32, c_int16, c_int16, c_void_p, c_void_p, c_void_p,
+                                                  c_size_t, c_void_p]
     return L
 
 
@@ -257,6 +262,39 @@ class SvtHipDsp:
                                                        search_w, search_h, self._p(best), self._p(x), self._p(y), n,
                                                        self._stream()), "svt_hip_sad_search_batch")
         return best, x, y
+
+    def sad_search_planes(self, src_plane, src_stride, src_offsets, ref_plane, ref_stride, ref_offsets, width, height,
+                          search_w, search_h, ref_stride_raw=None):
+        """Frame-level form (HME): uint8 planes + int32 (uint32 values) per-block byte offsets of the source
+        block and of the search window origin. -> best_sad int64, x int16, y int16"""
+        t = self.torch
+        n = src_offsets.shape[0]
+        best = t.zeros(n, dtype=t.int64, device=src_plane.device)
+        x = t.zeros(n, dtype=t.int16, device=src_plane.device)
+        y = t.zeros(n, dtype=t.int16, device=src_plane.device)
+        self._check(self.lib.svt_hip_sad_search_planes_batch(self._p(src_plane), src_stride, self._p(src_offsets),
+                                                              self._p(ref_plane), ref_stride,
+                                                              ref_stride if ref_stride_raw is None else ref_stride_raw,
+                                                              self._p(ref_offsets), width, height, search_w, search_h,
+                                                              self._p(best), self._p(x), self._p(y), n, self._stream()),
+                    "svt_hip_sad_search_planes_batch")
+        return best, x, y
+
+    def me_sb_search_planes(self, src_plane, src_stride, src_offsets, ref_plane, ref_stride, ref_offsets, search_w, search_h,
+                            origins=None, x_origin=0, y_origin=0, best_sad=None, best_mv=None):
+        """Frame-level K6: all SBs (x reference pictures) of a segment in one launch, addressed by byte offsets."""
+        t = self.torch
+        n = src_offsets.shape[0]
+        if best_sad is None:
+            best_sad = t.full((n, 85), self.MAX_SAD_VALUE, dtype=t.int32, device=src_plane.device)
+            best_mv = t.zeros((n, 85), dtype=t.int32, device=src_plane.device)
+        self._check(self.lib.svt_hip_me_sb_search_planes_batch(self._p(src_plane), src_stride, self._p(src_offsets),
+                                                                self._p(ref_plane), ref_stride, self._p(ref_offsets),
+                                                                search_w, search_h,
+                                                                self._p(origins) if origins is not None else None,
+                                                                x_origin, y_origin, self._p(best_sad), self._p(best_mv), n,
+                                                                self._stream()), "svt_hip_me_sb_search_planes_batch")
+        return best_sad, best_mv
 
     # -- K7 coefficient domain ---------------------------------------------------------
     def full_distortion32(self, coeff, recon, width, height, cbf_zero=False):

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(ME_THREADS) void me_sb_search_kernel(
     const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
     const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
     const int16_t* __restrict__ origins /* [n][2] x,y or NULL */, int x_origin, int y_origin,
-    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t wpitch, uint32_t nblocks) {
+    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t wpitch,
+    const uint32_t* __restrict__ src_offs, const uint32_t* __restrict__ ref_offs, uint32_t nblocks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_src = reinterpret_cast<uint32_t*>(smem);            // [32 even rows][16 dwords]
     uint8_t* s_ref = smem + 32 * 64;                                // [(64+sh-1)][wpitch]
@@ -43,8 +44,8 @@ __global__ __launch_bounds__(ME_THREADS) void me_sb_search_kernel(
     const uint32_t blk = blockIdx.x;
     if (blk >= nblocks) return;
     const int tid = threadIdx.x;
-    const uint8_t* gs = src + (size_t)blk * src_block_pitch;
-    const uint8_t* gr = ref + (size_t)blk * ref_block_pitch;
+    const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
+    const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
     // stage the even source rows and the reference window with 16-B unaligned loads
     if (tid < 128) {
         const int r = tid >> 2, c = tid & 3;
@@ -214,6 +215,19 @@ __global__ __launch_bounds__(ME_THREADS) void me_sb_search_kernel(
 // Register budget ~200 VGPRs: two workgroups per CU (the first kernel: 256 VGPRs + 256 AGPRs + scratch,
 // one wave per SIMD, an s_waitcnt after almost every LDS read).
 // ---------------------------------------------------------------------------
+// Wave-wide unsigned minimum on the VALU cross-lane (DPP) path: quad swaps, row half-mirror / mirror,
+// then the gfx9 row broadcasts; no LDS round trip (a ds_bpermute chain is six dependent LDS latencies
+// per PU, and there are 85 PUs).  The result is valid in LANE 63 only.
+__device__ __forceinline__ unsigned wave_min_u32_to_lane63(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast15 -> rows 1, 3
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast31 -> rows 2, 3
+    return v;
+}
+
 __device__ __forceinline__ unsigned me_key16_min(const unsigned long long (&a)[4], unsigned idb) {
     // a[g] = packed SADs of points 4g .. 4g+3; returns min over the 16 points of (sad << 16 | idb + point)
     unsigned best = 0xffffffffu;
@@ -237,7 +251,8 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
     const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
     const int16_t* __restrict__ origins /* [n][2] x,y or NULL */, int x_origin, int y_origin,
-    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t wpitch, uint32_t nblocks) {
+    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t wpitch,
+    const uint32_t* __restrict__ src_offs, const uint32_t* __restrict__ ref_offs, uint32_t nblocks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_src = reinterpret_cast<uint32_t*>(smem);            // [32 even rows][16 dwords]
     uint8_t* s_ref = smem + 32 * 64;                                // [(64+sh-1)][wpitch], wpitch % 16 == 0
@@ -245,8 +260,8 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const uint32_t blk = blockIdx.x;
     if (blk >= nblocks) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint8_t* gs = src + (size_t)blk * src_block_pitch;
-    const uint8_t* gr = ref + (size_t)blk * ref_block_pitch;
+    const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
+    const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
     // ---- stage the even source rows and the reference window (16-B unaligned loads, 4 in flight) ----
     if (tid < 128) {
         const int r = tid >> 2, c = tid & 3;
@@ -344,11 +359,11 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                     for (int bx = 0; bx < 8; bx++) {
                         const unsigned long long a4[4] = {acc[0][bx], acc[1][bx], acc[2][bx], acc[3][bx]};
-                        const unsigned k = wave_min_u32(me_key16_min(a4, idb) | dead);
+                        const unsigned k = wave_min_u32_to_lane63(me_key16_min(a4, idb) | dead);
                         const int bx16 = bx >> 1;
                         const int zc = (bx16 >> 1) * 4 + h16 * 2 + (bx16 & 1);           // z-order inside the half
                         const int idx = 32 * h32 + 4 * zc + kb * 2 + (bx & 1);
-                        if (lane == 0) s_red[wave][idx] = min(s_red[wave][idx], k);
+                        if (lane == 63) s_red[wave][idx] = min(s_red[wave][idx], k);
                     }
 #pragma unroll
                     for (int g = 0; g < 4; g++)
@@ -362,10 +377,10 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                 for (int c16 = 0; c16 < 4; c16++) {
                     const unsigned long long a4[4] = {s16[0][c16], s16[1][c16], s16[2][c16], s16[3][c16]};
-                    const unsigned k = wave_min_u32(me_key16_min(a4, idb) | dead);
+                    const unsigned k = wave_min_u32_to_lane63(me_key16_min(a4, idb) | dead);
                     const int zc = (c16 >> 1) * 4 + h16 * 2 + (c16 & 1);
                     const int idx = 64 + 8 * h32 + zc;
-                    if (lane == 0) s_red[wave][idx] = min(s_red[wave][idx], k);
+                    if (lane == 63) s_red[wave][idx] = min(s_red[wave][idx], k);
                 }
 #pragma unroll
                 for (int c32 = 0; c32 < 2; c32++)
@@ -388,17 +403,17 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         s64[4 * g + jj] += s;
                         best = min(best, (s << 12) | (idb + 4 * g + jj));
                     }
-                const unsigned k = wave_min_u32(best | dead);
+                const unsigned k = wave_min_u32_to_lane63(best | dead);
                 const int idx = 80 + 2 * h32 + c32;
-                if (lane == 0) s_red[wave][idx] = min(s_red[wave][idx], k);
+                if (lane == 63) s_red[wave][idx] = min(s_red[wave][idx], k);
             }
         }
         {
             unsigned best = 0xffffffffu;
 #pragma unroll
             for (int i = 0; i < 16; i++) best = min(best, (s64[i] << 12) | (idb + i));
-            const unsigned k = wave_min_u32(best | dead);
-            if (lane == 0) s_red[wave][84] = min(s_red[wave][84], k);
+            const unsigned k = wave_min_u32_to_lane63(best | dead);
+            if (lane == 63) s_red[wave][84] = min(s_red[wave][84], k);
         }
     }
     __syncthreads();

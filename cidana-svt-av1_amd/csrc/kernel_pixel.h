@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void sad_search_kernel(
     const uint8_t* __restrict__ ref, uint32_t ref_stride, uint32_t ref_stride_raw, size_t ref_block_pitch,
     uint32_t width, uint32_t height, int search_w, int search_h,
     unsigned long long* __restrict__ best_sad, int16_t* __restrict__ best_x, int16_t* __restrict__ best_y,
-    uint32_t src_lds_bytes, uint32_t ref_lds_bytes, uint32_t nblocks) {
+    uint32_t src_lds_bytes, uint32_t ref_lds_bytes, const uint32_t* __restrict__ src_offs,
+    const uint32_t* __restrict__ ref_offs, uint32_t nblocks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t blk = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(256) void sad_search_kernel(
     uint8_t* s_src = smem + (size_t)wave * (src_lds_bytes + ref_lds_bytes);
     uint8_t* s_ref = s_src + src_lds_bytes;
     if (blk >= nblocks) return;   // whole wave exits together (blk is wave-uniform)
-    const uint8_t* gs = src + (size_t)blk * src_block_pitch;
-    const uint8_t* gr = ref + (size_t)blk * ref_block_pitch;
+    const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
+    const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
     // stage the source block
     for (uint32_t i = lane; i < spitch * height; i += 64) {
         const uint32_t y = i / spitch, x = i - y * spitch;
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(256) void sad_search_q_kernel(
     const uint8_t* __restrict__ ref, uint32_t ref_stride, uint32_t ref_stride_raw, size_t ref_block_pitch,
     uint32_t width_rt, uint32_t height_rt, int search_w, int search_h,
     unsigned long long* __restrict__ best_sad, int16_t* __restrict__ best_x, int16_t* __restrict__ best_y,
-    uint32_t src_lds_bytes, uint32_t ref_lds_bytes, uint32_t lpb, uint32_t nblocks) {
+    uint32_t src_lds_bytes, uint32_t ref_lds_bytes, uint32_t lpb, const uint32_t* __restrict__ src_offs,
+    const uint32_t* __restrict__ ref_offs, uint32_t nblocks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t width = CW ? (uint32_t)CW : width_rt, height = CH ? (uint32_t)CH : height_rt;   // compile-time when specialised
     const uint32_t tid = threadIdx.x;
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(256) void sad_search_q_kernel(
     uint8_t* s_ref = s_src + src_lds_bytes;
     const uint32_t wq = width >> 2;
     if (valid) {
-        const uint8_t* gs = src + (size_t)blk * src_block_pitch;
-        const uint8_t* gr = ref + (size_t)blk * ref_block_pitch;
+        const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
+        const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
         // Staging: 2-D lane arrangement (power-of-two row length: no divisions), up to 4 wide
         // unaligned loads in flight per lane (a one-load-per-iteration loop is latency-bound).
         {   // source block: rows of `width` bytes in chunks of cs = 16 / 8 / 4 bytes
@@ -423,7 +425,8 @@ __global__ __launch_bounds__(256) void sad_search_q2_kernel(
     const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
     const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
     unsigned long long* __restrict__ best_sad, int16_t* __restrict__ best_x, int16_t* __restrict__ best_y,
-    uint32_t ref_lds_bytes, uint32_t lpb, uint32_t cpr_magic, uint32_t nblocks) {
+    uint32_t ref_lds_bytes, uint32_t lpb, uint32_t cpr_magic, const uint32_t* __restrict__ src_offs,
+    const uint32_t* __restrict__ ref_offs, uint32_t nblocks) {
     static_assert(CW % 4 == 0 && CW * CH <= 256, "source block must fit 64 VGPRs");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int WQ = CW / 4;
@@ -444,8 +447,8 @@ __global__ __launch_bounds__(256) void sad_search_q2_kernel(
     uint8_t* s_src = smem + (size_t)slot * SRC_BYTES;
     uint8_t* s_ref = smem + (size_t)slots * SRC_BYTES + (size_t)slot * ref_lds_bytes;
     if (valid) {
-        const uint8_t* gs = src + (size_t)blk * src_block_pitch;
-        const uint8_t* gr = ref + (size_t)blk * ref_block_pitch;
+        const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
+        const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
         // ---- stage the source block and the window.  One flat list of 16-B chunks (source rows first,
         // then window rows of cpr chunks); a lane issues up to SU loads back to back and only then
         // writes LDS, so the block costs ONE memory latency (three dependent load -> LDS phases made a

@@ -641,12 +641,12 @@ extern "C" int svt_hip_residual_batch(const uint8_t* d_src, uint32_t src_stride,
     return launch_status("residual");
 }
 
-extern "C" int svt_hip_sad_search_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
-                                        const uint8_t* d_ref, uint32_t ref_stride, uint32_t ref_stride_raw,
-                                        size_t ref_block_pitch, uint32_t width, uint32_t height,
-                                        int16_t search_area_width, int16_t search_area_height,
-                                        uint64_t* d_best_sad, int16_t* d_x, int16_t* d_y, size_t nblocks,
-                                        void* stream) {
+static int sad_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch, const uint32_t* d_src_offs,
+                           const uint8_t* d_ref, uint32_t ref_stride, uint32_t ref_stride_raw,
+                           size_t ref_block_pitch, const uint32_t* d_ref_offs, uint32_t width, uint32_t height,
+                           int16_t search_area_width, int16_t search_area_height,
+                           uint64_t* d_best_sad, int16_t* d_x, int16_t* d_y, size_t nblocks,
+                           void* stream) {
     if (int rc = require_init()) return rc;
     if (nblocks == 0) return SVT_HIP_OK;
     if (!d_src || !d_ref || !d_best_sad || !d_x || !d_y) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
@@ -677,7 +677,7 @@ extern "C" int svt_hip_sad_search_batch(const uint8_t* d_src, uint32_t src_strid
     hipLaunchKernelGGL((sad_search_q2_kernel<CW, CH>), dim3(grid), dim3(threads), (size_t)slots * per_blk, (hipStream_t)stream, \
                        d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, (int)search_area_width,         \
                        (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, ref_bytes, lpb, cpr_magic,           \
-                       (uint32_t)nblocks)
+                       d_src_offs, d_ref_offs, (uint32_t)nblocks)
             // exact j / cpr for j < 2^16 chunks (cpr <= 8): floor(2^32 / cpr) + 1
             const uint32_t cpr_magic = (uint32_t)(0x100000000ull / ((win_w + 15) >> 4)) + 1u;
             if (width == 16) SSQ2(16, 16); else SSQ2(8, 8);
@@ -703,7 +703,7 @@ extern "C" int svt_hip_sad_search_batch(const uint8_t* d_src, uint32_t src_strid
     hipLaunchKernelGGL((sad_search_q_kernel<CW, CH>), dim3(grid), dim3(threads), (size_t)slots * per_blk, (hipStream_t)stream, \
                        d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_stride_raw, ref_block_pitch, width, height,  \
                        (int)search_area_width, (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, src_bytes, \
-                       ref_bytes, lpb, (uint32_t)nblocks)
+                       ref_bytes, lpb, d_src_offs, d_ref_offs, (uint32_t)nblocks)
         if (width == 16 && height == 16) SSQ(16, 16);
         else if (width == 8 && height == 8) SSQ(8, 8);
         else if (width == 32 && height == 32) SSQ(32, 32);
@@ -724,15 +724,35 @@ extern "C" int svt_hip_sad_search_batch(const uint8_t* d_src, uint32_t src_strid
     hipLaunchKernelGGL(sad_search_kernel, dim3(grid), dim3(waves * 64), waves * per_wave, (hipStream_t)stream, d_src,
                        src_stride, src_block_pitch, d_ref, ref_stride, ref_stride_raw, ref_block_pitch, width, height,
                        (int)search_area_width, (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y,
-                       src_bytes, ref_bytes, (uint32_t)nblocks);
+                       src_bytes, ref_bytes, d_src_offs, d_ref_offs, (uint32_t)nblocks);
     return launch_status("sad_search");
 }
 
-extern "C" int svt_hip_me_sb_search_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
-                                          const uint8_t* d_ref, uint32_t ref_stride, size_t ref_block_pitch,
-                                          int search_w, int search_h, const int16_t* d_origins, int x_origin,
-                                          int y_origin, uint32_t* d_best_sad, uint32_t* d_best_mv, size_t nblocks,
-                                          void* stream) {
+extern "C" int svt_hip_sad_search_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                        const uint8_t* d_ref, uint32_t ref_stride, uint32_t ref_stride_raw,
+                                        size_t ref_block_pitch, uint32_t width, uint32_t height,
+                                        int16_t search_area_width, int16_t search_area_height,
+                                        uint64_t* d_best_sad, int16_t* d_x, int16_t* d_y, size_t nblocks,
+                                        void* stream) {
+    return sad_search_impl(d_src, src_stride, src_block_pitch, nullptr, d_ref, ref_stride, ref_stride_raw, ref_block_pitch,
+                           nullptr, width, height, search_area_width, search_area_height, d_best_sad, d_x, d_y, nblocks, stream);
+}
+extern "C" int svt_hip_sad_search_planes_batch(const uint8_t* d_src_plane, uint32_t src_stride, const uint32_t* d_src_offsets,
+                                               const uint8_t* d_ref_plane, uint32_t ref_stride, uint32_t ref_stride_raw,
+                                               const uint32_t* d_ref_offsets, uint32_t width, uint32_t height,
+                                               int16_t search_area_width, int16_t search_area_height,
+                                               uint64_t* d_best_sad, int16_t* d_x, int16_t* d_y, size_t nblocks,
+                                               void* stream) {
+    if (nblocks && (!d_src_offsets || !d_ref_offsets)) { if (int rc = require_init()) return rc; return set_err(SVT_HIP_ERR_INVALID, "NULL offset table"); }
+    return sad_search_impl(d_src_plane, src_stride, 0, d_src_offsets, d_ref_plane, ref_stride, ref_stride_raw, 0, d_ref_offsets,
+                           width, height, search_area_width, search_area_height, d_best_sad, d_x, d_y, nblocks, stream);
+}
+
+static int me_sb_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch, const uint32_t* d_src_offs,
+                             const uint8_t* d_ref, uint32_t ref_stride, size_t ref_block_pitch, const uint32_t* d_ref_offs,
+                             int search_w, int search_h, const int16_t* d_origins, int x_origin,
+                             int y_origin, uint32_t* d_best_sad, uint32_t* d_best_mv, size_t nblocks,
+                             void* stream) {
     if (int rc = require_init()) return rc;
     if (nblocks == 0) return SVT_HIP_OK;
     if (!d_src || !d_ref || !d_best_sad || !d_best_mv) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
@@ -745,13 +765,31 @@ extern "C" int svt_hip_me_sb_search_batch(const uint8_t* d_src, uint32_t src_str
     if ((search_w & 15) == 0 && !g_tune_no_me16) {
         hipLaunchKernelGGL(me_sb_search16_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
                            src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
-                           x_origin, y_origin, d_best_sad, d_best_mv, wpitch, (uint32_t)nblocks);
+                           x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offs, d_ref_offs, (uint32_t)nblocks);
         return launch_status("me_sb_search16");
     }
     hipLaunchKernelGGL(me_sb_search_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
                        src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
-                       x_origin, y_origin, d_best_sad, d_best_mv, wpitch, (uint32_t)nblocks);
+                       x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offs, d_ref_offs, (uint32_t)nblocks);
     return launch_status("me_sb_search");
+}
+
+extern "C" int svt_hip_me_sb_search_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                          const uint8_t* d_ref, uint32_t ref_stride, size_t ref_block_pitch,
+                                          int search_w, int search_h, const int16_t* d_origins, int x_origin,
+                                          int y_origin, uint32_t* d_best_sad, uint32_t* d_best_mv, size_t nblocks,
+                                          void* stream) {
+    return me_sb_search_impl(d_src, src_stride, src_block_pitch, nullptr, d_ref, ref_stride, ref_block_pitch, nullptr, search_w,
+                             search_h, d_origins, x_origin, y_origin, d_best_sad, d_best_mv, nblocks, stream);
+}
+extern "C" int svt_hip_me_sb_search_planes_batch(const uint8_t* d_src_plane, uint32_t src_stride, const uint32_t* d_src_offsets,
+                                                 const uint8_t* d_ref_plane, uint32_t ref_stride, const uint32_t* d_ref_offsets,
+                                                 int search_w, int search_h, const int16_t* d_origins, int x_origin,
+                                                 int y_origin, uint32_t* d_best_sad, uint32_t* d_best_mv, size_t nblocks,
+                                                 void* stream) {
+    if (nblocks && (!d_src_offsets || !d_ref_offsets)) { if (int rc = require_init()) return rc; return set_err(SVT_HIP_ERR_INVALID, "NULL offset table"); }
+    return me_sb_search_impl(d_src_plane, src_stride, 0, d_src_offsets, d_ref_plane, ref_stride, 0, d_ref_offsets, search_w,
+                             search_h, d_origins, x_origin, y_origin, d_best_sad, d_best_mv, nblocks, stream);
 }
 
 extern "C" int svt_hip_full_distortion32_batch(const int32_t* d_coeff, uint32_t coeff_stride, size_t coeff_block_pitch,

@@ -220,6 +220,18 @@ int svt_hip_sad_search_batch(const uint8_t *d_src, uint32_t src_stride, size_t s
                              uint64_t *d_best_sad, int16_t *d_x, int16_t *d_y, size_t nblocks,
                              void *stream);
 
+/* The same search addressed on picture planes (frame-level HME): block b's source
+ * block starts at d_src_plane + d_src_offsets[b] and its search window at d_ref_plane +
+ * d_ref_offsets[b] (uint32 byte offsets; the caller clips windows to the padded picture exactly as
+ * HmeLevel0 does, EbMotionEstimation.c:5720-5798). */
+int svt_hip_sad_search_planes_batch(const uint8_t *d_src_plane, uint32_t src_stride,
+                                    const uint32_t *d_src_offsets, const uint8_t *d_ref_plane,
+                                    uint32_t ref_stride, uint32_t ref_stride_raw,
+                                    const uint32_t *d_ref_offsets, uint32_t width, uint32_t height,
+                                    int16_t search_area_width, int16_t search_area_height,
+                                    uint64_t *d_best_sad, int16_t *d_x, int16_t *d_y, size_t nblocks,
+                                    void *stream);
+
 /* K6 ME multi-size SAD: full-pel search of 64x64 superblocks for all 85 PUs.
  * Replaces FullPelSearch_LCU's inner calls (EbMotionEstimation.c:3199-3247 ->
  * GetSearchPointResults :2932 -> SadCalculation_8x8_16x16 / _32x32_64x64 tables :145-199;
@@ -236,6 +248,16 @@ int svt_hip_me_sb_search_batch(const uint8_t *d_src, uint32_t src_stride, size_t
                                int search_w, int search_h, const int16_t *d_origins, int x_origin,
                                int y_origin, uint32_t *d_best_sad, uint32_t *d_best_mv,
                                size_t nblocks, void *stream);
+
+/* K6 on picture planes: SB b's source at d_src_plane + d_src_offsets[b], window origin at d_ref_plane +
+ * d_ref_offsets[b] (all SBs x reference pictures of a segment in one launch; FullPelSearch_LCU's
+ * pointer arithmetic, EbMotionEstimation.c:3210-3225, done once on the host). */
+int svt_hip_me_sb_search_planes_batch(const uint8_t *d_src_plane, uint32_t src_stride,
+                                      const uint32_t *d_src_offsets, const uint8_t *d_ref_plane,
+                                      uint32_t ref_stride, const uint32_t *d_ref_offsets, int search_w,
+                                      int search_h, const int16_t *d_origins, int x_origin, int y_origin,
+                                      uint32_t *d_best_sad, uint32_t *d_best_mv, size_t nblocks,
+                                      void *stream);
 
 /* K7 coefficient-domain distortion (full_distortion_kernel32_bits_func_ptr_array /
  * full_distortion_kernel_cbf_zero32_bits_func_ptr_array, EbPictureOperators.h:268-280;
