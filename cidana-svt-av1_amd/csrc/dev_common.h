@@ -110,4 +110,21 @@ __device__ __forceinline__ unsigned long long group_sum64(unsigned long long v) 
     return v;
 }
 
+// packed 16-bit helpers of the reconstruction stages (v_pk_add_i16, v_pk_max/min_i16, v_sat_pk_u8_i16)
+typedef short svt_v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add_i16(uint32_t a, uint32_t b) {
+    union { uint32_t u; svt_v2s v; } x, y, z; x.u = a; y.u = b; z.v = x.v + y.v; return z.u;
+}
+__device__ __forceinline__ uint32_t pk_clamp_i16(uint32_t a, int hi) {     // lanes clamped to [0, hi]
+    union { uint32_t u; svt_v2s v; } x, z; x.u = a;
+    const svt_v2s zero = {0, 0}, top = {(short)hi, (short)hi};
+    z.v = __builtin_elementwise_min(__builtin_elementwise_max(x.v, zero), top);
+    return z.u;
+}
+__device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t a) {             // {sat_u8(a.lo), sat_u8(a.hi)} in bits 15:0
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+
 }  // namespace svtdev

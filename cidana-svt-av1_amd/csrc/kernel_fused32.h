@@ -226,22 +226,6 @@ __global__ __launch_bounds__(F32_WAVES * 64, MIN_WAVES_PER_SIMD) void fwd32_kern
 // All LDS accesses are conflict-free under the lane-group rules of MI355X_MICROARCH.md
 // (ds_read_b128: 4 x 16 lanes over 64 banks; ds_write_b128: 8 x 8 lanes over 32 banks).
 // ---------------------------------------------------------------------------
-typedef short svt_v2s __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_add_i16(uint32_t a, uint32_t b) {
-    union { uint32_t u; svt_v2s v; } x, y, z; x.u = a; y.u = b; z.v = x.v + y.v; return z.u;
-}
-__device__ __forceinline__ uint32_t pk_clamp_i16(uint32_t a, int hi) {     // lanes clamped to [0, hi]
-    union { uint32_t u; svt_v2s v; } x, z; x.u = a;
-    const svt_v2s zero = {0, 0}, top = {(short)hi, (short)hi};
-    z.v = __builtin_elementwise_min(__builtin_elementwise_max(x.v, zero), top);
-    return z.u;
-}
-__device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t a) {             // {sat_u8(a.lo), sat_u8(a.hi)} in bits 15:0
-    uint32_t r;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(a));
-    return r;
-}
-
 // WAVES / VAR are tuning knobs (tools/tune_inv32.py): VAR bit0 = no destination prefetch,
 // bit1 = skip the transforms (memory-only probe), bit2 = skip the global loads (compute-only probe).
 // (A persistent, software-pipelined variant - next pair's coefficients fetched into registers during

@@ -296,12 +296,29 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
         for (int q0 = 0; q0 < NCH; q0 += 64) {
             const int q = q0 + lane;
             if ((NCH % 64 == 0 || q < NCH) && (first + q / CPB < nblocks)) {
-                const short* rs = reinterpret_cast<const short*>(wl) + (size_t)q * PPL;
-                uint4 pv = d4[q];
-                PixT* px = reinterpret_cast<PixT*>(&pv);
+                // residuals arrive as packed int16 pairs; the add / clip runs on 16-bit lanes (v_pk_add_i16,
+                // v_sat_pk_u8_i16 or v_pk_max/min_i16) — SDWA / bfe byte arithmetic costs ~4x as much
+                const uint4* rs4 = reinterpret_cast<const uint4*>(reinterpret_cast<const short*>(wl) + (size_t)q * PPL);
+                const uint4 pv = d4[q];
+                const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w};
+                uint32_t ow[4];
+                if (sizeof(PixT) == 1) {
+                    const uint4 ra = rs4[0], rb = rs4[1];
+                    const uint32_t rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};     // (r0,r1) (r2,r3) ...
 #pragma unroll
-                for (int j = 0; j < PPL; j++) px[j] = (PixT)min(max((int)px[j] + (int)rs[j], 0), maxpix);
-                d4[q] = pv;
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t p01 = __builtin_amdgcn_perm(0u, pw[k], 0x0c010c00u);       // bytes 0,1 -> 16-bit lanes
+                        const uint32_t p23 = __builtin_amdgcn_perm(0u, pw[k], 0x0c030c02u);       // bytes 2,3
+                        const uint32_t u01 = sat_pk_u8_i16(pk_add_i16(p01, rw[2 * k])), u23 = sat_pk_u8_i16(pk_add_i16(p23, rw[2 * k + 1]));
+                        ow[k] = (u23 << 16) | (u01 & 0xffffu);
+                    }
+                } else {
+                    const uint4 ra = rs4[0];
+                    const uint32_t rw[4] = {ra.x, ra.y, ra.z, ra.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) ow[k] = pk_clamp_i16(pk_add_i16(pw[k], rw[k]), maxpix);
+                }
+                d4[q] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             }
         }
     }
