@@ -115,6 +115,12 @@ typedef short svt_v2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_add_i16(uint32_t a, uint32_t b) {
     union { uint32_t u; svt_v2s v; } x, y, z; x.u = a; y.u = b; z.v = x.v + y.v; return z.u;
 }
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) {
+    union { uint32_t u; svt_v2s v; } x, y, z; x.u = a; y.u = b; z.v = x.v - y.v; return z.u;
+}
+__device__ __forceinline__ uint32_t pk_shl2_i16(uint32_t a) {                // both lanes << 2
+    union { uint32_t u; svt_v2s v; } x, z; x.u = a; z.v = x.v << 2; return z.u;
+}
 __device__ __forceinline__ uint32_t pk_clamp_i16(uint32_t a, int hi) {     // lanes clamped to [0, hi]
     union { uint32_t u; svt_v2s v; } x, z; x.u = a;
     const svt_v2s zero = {0, 0}, top = {(short)hi, (short)hi};

@@ -39,11 +39,17 @@ constexpr int F32_COS_BIT = 12;              // fwd_cos_bit_col/row[3][3] (EbTra
 // slots are XOR-swizzled by f: conflict-free for the access pairs used below.
 __device__ __forceinline__ int tile_slot(int r, int s, int f) { return r * 128 + ((s ^ f) << 4); }
 
-template <bool IN_U8, bool QUANT, bool WITH_SAD, int MIN_WAVES_PER_SIMD = 1, bool NT = false, int QMODE = 2>
+// IN: 0 = int16 residual (dense), 1 = uint8 src / pred, 2 = uint16 src / pred (10-bit).
+// PLANES: blocks are addressed on picture planes: origin (x, y) = (xy[b] & 0xffff, xy[b] >> 16), row strides
+// src_stride / pred_stride in samples; otherwise dense 32x32 blocks back to back (the strides fold to 32).
+template <int IN, bool QUANT, bool WITH_SAD, int MIN_WAVES_PER_SIMD = 1, bool NT = false, int QMODE = 2, bool PLANES = false>
 __global__ __launch_bounds__(F32_WAVES * 64, MIN_WAVES_PER_SIMD) void fwd32_kernel(
-    const void* __restrict__ src_v, const uint8_t* __restrict__ pred, int32_t* __restrict__ coeff,
+    const void* __restrict__ src_v, const void* __restrict__ pred_v, int32_t* __restrict__ coeff,
     int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff, uint16_t* __restrict__ eob,
-    uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp, int is_idtx, uint32_t nblocks) {
+    uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp, int is_idtx, uint32_t nblocks,
+    uint32_t src_stride_rt = 32, uint32_t pred_stride_rt = 32, const uint32_t* __restrict__ xy = nullptr) {
+    constexpr bool IN_U8 = IN == 1;
+    const uint8_t* pred = static_cast<const uint8_t*>(pred_v);
     __shared__ __attribute__((aligned(16))) int32_t lds[F32_WAVES * 2 * F32_TILE_WORDS];
 
     const int lane = threadIdx.x & 63;
@@ -72,15 +78,30 @@ __global__ __launch_bounds__(F32_WAVES * 64, MIN_WAVES_PER_SIMD) void fwd32_kern
         const size_t pix_off = (size_t)blk * 1024;
         unsigned sad_acc = 0;
         int x[32];
+        // sample offsets of the block in the source / prediction arrays and their row strides
+        const uint32_t sstr = PLANES ? src_stride_rt : 32u, pstr = PLANES ? pred_stride_rt : 32u;
+        size_t sbase = pix_off, pbase = pix_off;
+        if (PLANES) {
+            const uint32_t o = valid ? xy[blk] : 0u;
+            sbase = (size_t)(o >> 16) * sstr + (o & 0xffffu);
+            pbase = (size_t)(o >> 16) * pstr + (o & 0xffffu);
+        }
 
         if (IN_U8) {
-            // ---- load 2 x 1 KB, coalesced 16 B per lane ------------------------------
+            // ---- load 2 x 1 KB, 16 B per lane: rows li/2 and 16 + li/2, columns (li&1)*16 .. +15 -------
             const uint8_t* src = static_cast<const uint8_t*>(src_v);
             uint4 s0 = {0, 0, 0, 0}, s1 = s0, p0 = s0, p1 = s0;
             if (valid) {
-                const uint4* s4 = reinterpret_cast<const uint4*>(src + pix_off);
-                const uint4* p4 = reinterpret_cast<const uint4*>(pred + pix_off);
-                s0 = s4[li]; s1 = s4[li + 32]; p0 = p4[li]; p1 = p4[li + 32];
+                if (PLANES) {
+                    const uint8_t* sp = src + sbase + (size_t)(li >> 1) * sstr + (li & 1) * 16;
+                    const uint8_t* pp = pred + pbase + (size_t)(li >> 1) * pstr + (li & 1) * 16;
+                    __builtin_memcpy(&s0, sp, 16); __builtin_memcpy(&s1, sp + (size_t)16 * sstr, 16);
+                    __builtin_memcpy(&p0, pp, 16); __builtin_memcpy(&p1, pp + (size_t)16 * pstr, 16);
+                } else {
+                    const uint4* s4 = reinterpret_cast<const uint4*>(src + pix_off);
+                    const uint4* p4 = reinterpret_cast<const uint4*>(pred + pix_off);
+                    s0 = s4[li]; s1 = s4[li + 32]; p0 = p4[li]; p1 = p4[li + 32];
+                }
             }
             // ---- SAD on the raw bytes (v_sad_u8: 4 pixels per instruction) -----------
             if (WITH_SAD) {
@@ -100,13 +121,13 @@ __global__ __launch_bounds__(F32_WAVES * 64, MIN_WAVES_PER_SIMD) void fwd32_kern
                 uint32_t r[4];
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++) {
+                    // bytes -> 16-bit lanes with v_perm_b32, then packed subtract and the transform's
+                    // input up-shift (x4) on the packed words: 4 residuals in 8 instructions
                     const uint32_t a = sw[kp * 2 + h2], b = pw[kp * 2 + h2];
-                    const int d0 = (int)(a & 0xff) - (int)(b & 0xff);
-                    const int d1 = (int)((a >> 8) & 0xff) - (int)((b >> 8) & 0xff);
-                    const int d2 = (int)((a >> 16) & 0xff) - (int)((b >> 16) & 0xff);
-                    const int d3 = (int)(a >> 24) - (int)(b >> 24);
-                    r[h2 * 2 + 0] = ((uint32_t)d0 & 0xffffu) | ((uint32_t)d1 << 16);
-                    r[h2 * 2 + 1] = ((uint32_t)d2 & 0xffffu) | ((uint32_t)d3 << 16);
+                    const uint32_t a01 = __builtin_amdgcn_perm(0u, a, 0x0c010c00u), a23 = __builtin_amdgcn_perm(0u, a, 0x0c030c02u);
+                    const uint32_t b01 = __builtin_amdgcn_perm(0u, b, 0x0c010c00u), b23 = __builtin_amdgcn_perm(0u, b, 0x0c030c02u);
+                    r[h2 * 2 + 0] = pk_shl2_i16(pk_sub_i16(a01, b01));
+                    r[h2 * 2 + 1] = pk_shl2_i16(pk_sub_i16(a23, b23));
                 }
                 *reinterpret_cast<uint4*>(tile + kp * 544 + li * 16) = make_uint4(r[0], r[1], r[2], r[3]);
             }
@@ -116,18 +137,45 @@ __global__ __launch_bounds__(F32_WAVES * 64, MIN_WAVES_PER_SIMD) void fwd32_kern
 #pragma unroll
             for (int r = 0; r < 32; r++) {
                 const short v = *reinterpret_cast<const short*>(colbase + (r >> 4) * 1088 + (r & 15) * 32);
-                x[r] = (int)v * 4;                                   // shift[0] = 2 (fwd_shift_32x32)
+                x[r] = (int)v;                                       // shift[0] = 2 (fwd_shift_32x32) already applied
             }
         } else {
             // ---- int16 residual, 2 KB per block: chunk k (0..3) of lane li = row k*8 + li/4,
             // columns (li&3)*8 .. +7, stored linearly at k*512 + li*16; column c of row r is
             // then at (r>>3)*512 + (r&7)*64 + c*2 : a 64-B contiguous run per row (no conflicts)
             const int16_t* res = static_cast<const int16_t*>(src_v);
-            const uint4* r4 = reinterpret_cast<const uint4*>(res + pix_off);
+            if (IN == 2) {
+                // 10-bit: the same chunks of the uint16 source and prediction, residual by v_pk_sub_i16
+                // (|s - p| <= 1023 fits int16), SAD by v_sad_u16
+                const uint16_t* s16 = static_cast<const uint16_t*>(src_v);
+                const uint16_t* p16 = static_cast<const uint16_t*>(pred_v);
+                uint4 sv[4], pv[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint4 v = valid ? r4[k * 32 + li] : make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(tile + k * 512 + li * 16) = v;
+                for (int k = 0; k < 4; k++) {
+                    sv[k] = make_uint4(0, 0, 0, 0); pv[k] = sv[k];
+                    if (valid) {
+                        __builtin_memcpy(&sv[k], s16 + sbase + (size_t)(k * 8 + (li >> 2)) * sstr + (li & 3) * 8, 16);
+                        __builtin_memcpy(&pv[k], p16 + pbase + (size_t)(k * 8 + (li >> 2)) * pstr + (li & 3) * 8, 16);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t a[4] = {sv[k].x, sv[k].y, sv[k].z, sv[k].w}, b[4] = {pv[k].x, pv[k].y, pv[k].z, pv[k].w};
+                    uint32_t d[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        d[j] = pk_sub_i16(a[j], b[j]);
+                        if (WITH_SAD) sad_acc = __builtin_amdgcn_sad_u16(a[j], b[j], sad_acc);
+                    }
+                    *reinterpret_cast<uint4*>(tile + k * 512 + li * 16) = make_uint4(d[0], d[1], d[2], d[3]);
+                }
+            } else {
+                const uint4* r4 = reinterpret_cast<const uint4*>(res + pix_off);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint4 v = valid ? r4[k * 32 + li] : make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(tile + k * 512 + li * 16) = v;
+                }
             }
             wave_lds_fence();
 #pragma unroll
@@ -416,12 +464,10 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int h2 = 0; h2 < 2; h2++) {
                 const uint32_t a = sw[kp * 2 + h2], b = pw[kp * 2 + h2];
-                const int d0 = (int)(a & 0xff) - (int)(b & 0xff);
-                const int d1 = (int)((a >> 8) & 0xff) - (int)((b >> 8) & 0xff);
-                const int d2 = (int)((a >> 16) & 0xff) - (int)((b >> 16) & 0xff);
-                const int d3 = (int)(a >> 24) - (int)(b >> 24);
-                r[h2 * 2 + 0] = ((uint32_t)d0 & 0xffffu) | ((uint32_t)d1 << 16);
-                r[h2 * 2 + 1] = ((uint32_t)d2 & 0xffffu) | ((uint32_t)d3 << 16);
+                const uint32_t a01 = __builtin_amdgcn_perm(0u, a, 0x0c010c00u), a23 = __builtin_amdgcn_perm(0u, a, 0x0c030c02u);
+                const uint32_t b01 = __builtin_amdgcn_perm(0u, b, 0x0c010c00u), b23 = __builtin_amdgcn_perm(0u, b, 0x0c030c02u);
+                r[h2 * 2 + 0] = pk_shl2_i16(pk_sub_i16(a01, b01));      // residual x 4 (fwd_shift_32x32[0] = 2), packed
+                r[h2 * 2 + 1] = pk_shl2_i16(pk_sub_i16(a23, b23));
             }
             *reinterpret_cast<uint4*>(tile + kp * 544 + li * 16) = make_uint4(r[0], r[1], r[2], r[3]);
         }
@@ -430,7 +476,7 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             const short v = *reinterpret_cast<const short*>(colbase + (r >> 4) * 1088 + (r & 15) * 32);
-            x[r] = (int)v * 4;                                   // shift[0] = 2 (fwd_shift_32x32)
+            x[r] = (int)v;                                       // shift[0] = 2 already applied
         }
     }
     // ---- forward: column pass, transpose, row pass, re-order to linear ------------------------

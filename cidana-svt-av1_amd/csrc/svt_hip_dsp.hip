@@ -38,6 +38,7 @@ int g_tune_no_staged = 0;
 int g_tune_no_qsad = 0;
 int g_tune_no_q2 = 0;
 int g_tune_no_me16 = 0;
+int g_tune_no_f32p = 0;
 int g_tune_inv32_waves = 4;
 int g_tune_inv32_var = 0;
 
@@ -281,6 +282,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "no_qsad")) { g_tune_no_qsad = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_q2")) { g_tune_no_q2 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_me16")) { g_tune_no_me16 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_f32p")) { g_tune_no_f32p = value; return SVT_HIP_OK; }
     if (!strcmp(key, "inv32_waves")) { g_tune_inv32_waves = value; return SVT_HIP_OK; }
     if (!strcmp(key, "inv32_var")) { g_tune_inv32_var = value; return SVT_HIP_OK; }
     return set_err(SVT_HIP_ERR_INVALID, "unknown tuning key %s", key);
@@ -325,7 +327,7 @@ extern "C" int svt_hip_fwd_txfm2d_batch(const int16_t* d_in, uint32_t in_stride,
         ((uintptr_t)d_out & 15) == 0 && (tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX)) {
         const uint32_t npairs = (uint32_t)((nblocks + 1) / 2);
         QParams qp = {};
-        hipLaunchKernelGGL((fwd32_kernel<false, false, false>), dim3((npairs + F32_WAVES - 1) / F32_WAVES), dim3(F32_WAVES * 64), 0,
+        hipLaunchKernelGGL((fwd32_kernel<0, false, false>), dim3((npairs + F32_WAVES - 1) / F32_WAVES), dim3(F32_WAVES * 64), 0,
                            s, (const void*)d_in, (const uint8_t*)nullptr, d_out, (int32_t*)nullptr, (int32_t*)nullptr,
                            (uint16_t*)nullptr, (uint32_t*)nullptr, (const int16_t*)nullptr, qp, tx_type == SVT_IDTX ? 1 : 0,
                            (uint32_t)nblocks);
@@ -457,7 +459,7 @@ extern "C" int svt_hip_fwd_quant_sad_batch(const uint8_t* d_src, const uint8_t* 
     hipStream_t s = (hipStream_t)stream;
     // QMODE 2 needs power-of-two quant_shift (every av1_build_quantizer table); else the 24-bit general form
 #define F32_LAUNCH_Q(SAD, MW, NT, QM)                                                                              \
-    hipLaunchKernelGGL((fwd32_kernel<true, true, SAD, MW, NT, QM>), dim3(grid), dim3(F32_WAVES * 64), 0, s,           \
+    hipLaunchKernelGGL((fwd32_kernel<1, true, SAD, MW, NT, QM>), dim3(grid), dim3(F32_WAVES * 64), 0, s,           \
                        (const void*)d_src, d_pred, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp,           \
                        tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks)
     const bool fastq = qp.fast_ok && !g_tune_f32_qmode1;
@@ -550,6 +552,19 @@ extern "C" int svt_hip_fwd_quant_planes_batch(const void* d_src, uint32_t src_st
     for (int i = 0; i < 2; i++)
         if (qp.quant_shift[i] < 0 || qp.dequant[i] < 0 || qp.round[i] < 0) return set_err(SVT_HIP_ERR_INVALID, "negative quantizer table entry");
     hipStream_t s = (hipStream_t)stream;
+    if (tx_size == SVT_TX_32X32 && (tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX) && qp.fast_ok && !d_energy && !g_tune_no_f32p &&
+        (d_xy || is_16bit) && ((uintptr_t)d_coeff & 15) == 0 && ((uintptr_t)d_qcoeff & 15) == 0 && ((uintptr_t)d_dqcoeff & 15) == 0) {
+        // the tuned 32x32 kernel on planes / 10-bit samples (dense 16-bit batches are "planes" of stride 32 with a NULL table)
+        const uint32_t npairs = (uint32_t)((nblocks + 1) / 2);
+        const uint32_t grid = (npairs + F32_WAVES - 1) / F32_WAVES;
+        const int idtx = tx_type == SVT_IDTX ? 1 : 0;
+#define F32P(INM, SAD, PL) hipLaunchKernelGGL((fwd32_kernel<INM, true, SAD, 1, false, 2, PL>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, d_pred, \
+                                          d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, idtx, (uint32_t)nblocks, src_stride, pred_stride, d_xy)
+        if (is_16bit) { if (d_xy) F32P(2, false, true); else F32P(2, false, false); }
+        else { if (d_sad) F32P(1, true, true); else F32P(1, false, true); }
+#undef F32P
+        return launch_status("fwd_quant_32x32_planes");
+    }
     if (!g_tune_no_staged && qp.fast_ok && pels > 16 && !d_xy && !is_16bit && ((uintptr_t)d_src & 15) == 0 && ((uintptr_t)d_pred & 15) == 0 &&
         ((uintptr_t)d_coeff & 15) == 0 && ((uintptr_t)d_qcoeff & 15) == 0 && ((uintptr_t)d_dqcoeff & 15) == 0) {
 #define CALLS(W, H) launch_fq_staged<W, H>((const uint8_t*)d_src, (const uint8_t*)d_pred, nblocks, tx_type, qp, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_energy, s)
@@ -579,7 +594,7 @@ extern "C" int svt_hip_fwd_quant_batch(const int16_t* d_residual, size_t nblocks
         (tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX)) {
         // 24-bit quantiser arithmetic needs 8-bit-range residuals (|coeff| < 2^17)
         const uint32_t npairs = (uint32_t)((nblocks + 1) / 2);
-        hipLaunchKernelGGL((fwd32_kernel<false, true, false>), dim3((npairs + F32_WAVES - 1) / F32_WAVES), dim3(F32_WAVES * 64), 0, s,
+        hipLaunchKernelGGL((fwd32_kernel<0, true, false>), dim3((npairs + F32_WAVES - 1) / F32_WAVES), dim3(F32_WAVES * 64), 0, s,
                            (const void*)d_residual, (const uint8_t*)nullptr, d_coeff, d_qcoeff, d_dqcoeff, d_eob,
                            (uint32_t*)nullptr, d_iscan, qp, tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks);
         return launch_status("fwd32_quant");

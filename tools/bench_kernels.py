@@ -84,6 +84,22 @@ if want("pixel"):
     rec("sse_32x32", n, 2056, timeit(lambda: dsp.sse(a, b)))
     rec("residual_32x32", n, 4096, timeit(lambda: dsp.residual(a, b)))
     del a, b
+# 10-bit (BASELINE configs[4]): fused chain and inverse on dense 16-bit blocks
+if want("bd10"):
+    qt10 = svtlibs.quant_tables(10); qrow10 = {k: v[100].copy() for k, v in qt10.items()}
+    for s, n in ((3, 1 << 20), (2, 1 << 21)):
+        w, h = TW[s], TH[s]
+        src = torch.randint(0, 1024, (n, h, w), dtype=torch.int16, device=dev); pred = torch.randint(0, 1024, (n, h, w), dtype=torch.int16, device=dev)
+        _, isc = svtlibs.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
+        xy = None
+        ms = timeit(lambda: dsp.fwd_quant_planes(src.view(n * h, w), w, pred.view(n * h, w), w,
+                                                 torch.arange(n, dtype=torch.int32, device=dev) * (h << 16), s, 0, qrow10, iscan, bd=10), iters=4)
+        rec(f"fused_generic_bd10_{w}x{h}", n, 4 * w * h + 12 * w * h + 2, ms)
+        co = torch.randint(-2000, 2001, (n, w * h), dtype=torch.int32, device=dev)
+        d = torch.randint(0, 1024, (n, h, w), dtype=torch.int16, device=dev)
+        ms = timeit(lambda: dsp.inv_txfm2d_add(co, d, s, 0, 10))
+        rec(f"inv_txfm2d_add_u16_bd10_{w}x{h}", n, 4 * w * h + 4 * w * h, ms)
+        del src, pred, co, d
 # fused encode-pass chain (residual -> fwd -> quant/dequant -> inverse -> recon), 32x32
 if want("encode_recon"):
     n = 1 << 20
