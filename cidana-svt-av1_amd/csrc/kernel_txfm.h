@@ -247,7 +247,10 @@ __global__ __launch_bounds__(TX_WAVES * 64) void fwd_quant_generic_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     cp[j] = y[c + j];
-                    quant_one<FAST>(y[c + j], (l == 0 && c + j == 0) ? 0 : 1, qp, qp4[j], dp[j]);
+                    // power-of-two quant_shift (every av1_build_quantizer table): the one-product form is exact for
+                    // |coeff| + round < 2^24, i.e. for 8- and 10-bit transform output alike; otherwise the general forms
+                    if (qp.fast_ok) quant_one<2>(y[c + j], (l == 0 && c + j == 0) ? 0 : 1, qp, qp4[j], dp[j]);
+                    else quant_one<FAST>(y[c + j], (l == 0 && c + j == 0) ? 0 : 1, qp, qp4[j], dp[j]);
                     eob_acc = max(eob_acc, qp4[j] ? (int)isv[j] + 1 : 0);
                 }
                 *reinterpret_cast<int4*>(coeff + o + c) = cv;
