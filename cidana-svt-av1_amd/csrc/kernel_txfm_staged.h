@@ -28,16 +28,20 @@ struct StagedGeom {
     }
 };
 
-template <int W, int H, int MODE>
+// PixT: sample type of src / pred in MODE 1 (uint8_t, or uint16_t for 10-bit).  xy != NULL: the blocks are
+// addressed on picture planes (origin (x, y) = (xy[b] & 0xffff, xy[b] >> 16), row strides in samples) and are
+// fetched row segment by row segment into the same linear staging image; NULL: dense batches.
+template <int W, int H, int MODE, typename PixT = uint8_t>
 __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void fwd_staged_kernel(
-    const void* __restrict__ in0, const uint8_t* __restrict__ pred, int32_t* __restrict__ coeff,
+    const void* __restrict__ in0, const void* __restrict__ pred, int32_t* __restrict__ coeff,
     int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff, uint16_t* __restrict__ eob,
     uint32_t* __restrict__ sad, unsigned long long* __restrict__ energy, const int16_t* __restrict__ iscan,
-    QParams qp, int tx_type, uint32_t nblocks) {
+    QParams qp, int tx_type, uint32_t nblocks, const uint32_t* __restrict__ xy = nullptr, uint32_t src_stride = 0,
+    uint32_t pred_stride = 0) {
     using S = StagedGeom<W, H>;
     using G = TxGeom<W, H>;
     constexpr bool FUSED = MODE == 1;
-    constexpr int ES = FUSED ? 1 : 2;
+    constexpr int ES = FUSED ? (int)sizeof(PixT) : 2;
     constexpr int BB = W * H * ES;                       // input bytes per block and array
     constexpr int PADI = (W * ES >= 32) ? 32 : 16;       // staging pad per block
     constexpr int IN_ONE = G::BPW * (BB + PADI);
@@ -59,8 +63,39 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void fwd_staged_kernel(
     constexpr int CBC = fwd_cos_col(W, H), CBR = fwd_cos_row(W, H);
     constexpr int S0 = fwd_shift(W, H, 0), S1 = fwd_shift(W, H, 1), S2 = fwd_shift(W, H, 2);
 
-    // ---- stage the wave's input: linear 16-B chunks ---------------------------------------
-    {
+    // ---- stage the wave's input -------------------------------------------------------------
+    if (FUSED && xy) {
+        // planes: chunks of CS bytes that never cross a block row; every offset-table and sample load of a
+        // lane is issued before the first LDS write
+        constexpr int ROWB = W * ES, CS = ROWB >= 16 ? 16 : ROWB;
+        constexpr int CPR = ROWB / CS, CPBP = BB / CS, NCHP = G::BPW * CPBP, NIT = (NCHP + 63) / 64;
+        uint32_t org[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * 64 + lane, b = q / CPBP;
+            org[it] = (q < NCHP && first + b < nblocks) ? xy[first + b] : 0xffffffffu;
+        }
+        uint4 v0[NIT], v1[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * 64 + lane, w = q % CPBP;
+            const int row = w / CPR, cb = (w % CPR) * CS;
+            v0[it] = make_uint4(0, 0, 0, 0); v1[it] = v0[it];
+            if (org[it] != 0xffffffffu) {
+                const size_t y = (org[it] >> 16) + row, x = org[it] & 0xffffu;
+                __builtin_memcpy(&v0[it], static_cast<const char*>(in0) + (y * src_stride + x) * ES + cb, CS);
+                __builtin_memcpy(&v1[it], static_cast<const char*>(pred) + (y * pred_stride + x) * ES + cb, CS);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * 64 + lane, b = q / CPBP;
+            if (NCHP % 64 == 0 || q < NCHP) {
+                __builtin_memcpy(wl + q * CS + b * PADI, &v0[it], CS);
+                __builtin_memcpy(wl + IN_ONE + q * CS + b * PADI, &v1[it], CS);
+            }
+        }
+    } else {
         constexpr int NCH = G::BPW * BB / 16;
         const char* g0 = static_cast<const char*>(in0) + (size_t)first * BB;
         const char* g1 = FUSED ? reinterpret_cast<const char*>(pred) + (size_t)first * BB : nullptr;
@@ -88,7 +123,7 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void fwd_staged_kernel(
             const int idx = (ud ? H - 1 - r : r) * W + l;
             int d;
             if (FUSED) {
-                d = (int)*reinterpret_cast<const uint8_t*>(bs + idx) - (int)*reinterpret_cast<const uint8_t*>(bs + IN_ONE + idx);
+                d = (int)*reinterpret_cast<const PixT*>(bs + idx * ES) - (int)*reinterpret_cast<const PixT*>(bs + IN_ONE + idx * ES);
                 sad_acc += (unsigned)(d < 0 ? -d : d);
             } else {
                 d = *reinterpret_cast<const short*>(bs + idx * 2);

@@ -152,12 +152,18 @@ int launch_fwd_staged(const int16_t* in, int32_t* out, size_t n, int tx_type, hi
     return launch_status("fwd_staged");
 }
 template <int W, int H>
-int launch_fq_staged(const uint8_t* src, const uint8_t* pred, size_t n, int tx_type, const QParams& qp, const int16_t* iscan,
-                     int32_t* co, int32_t* q, int32_t* dq, uint16_t* eob, uint32_t* sad, uint64_t* energy, hipStream_t s) {
+int launch_fq_staged(const void* src, const void* pred, int is16, const uint32_t* xy, uint32_t ss, uint32_t ps, size_t n, int tx_type,
+                     const QParams& qp, const int16_t* iscan, int32_t* co, int32_t* q, int32_t* dq, uint16_t* eob, uint32_t* sad,
+                     uint64_t* energy, hipStream_t s) {
     using SG = StagedGeom<W, H>;
     const uint32_t per_wg = SG::WAVES * TxGeom<W, H>::BPW;
-    hipLaunchKernelGGL((fwd_staged_kernel<W, H, 1>), dim3((uint32_t)((n + per_wg - 1) / per_wg)), dim3(SG::WAVES * 64), 0, s,
-                       (const void*)src, pred, co, q, dq, eob, sad, (unsigned long long*)energy, iscan, qp, tx_type, (uint32_t)n);
+    const dim3 grid((uint32_t)((n + per_wg - 1) / per_wg)), block(SG::WAVES * 64);
+    if (is16)
+        hipLaunchKernelGGL((fwd_staged_kernel<W, H, 1, uint16_t>), grid, block, 0, s, src, pred, co, q, dq, eob, sad,
+                           (unsigned long long*)energy, iscan, qp, tx_type, (uint32_t)n, xy, ss, ps);
+    else
+        hipLaunchKernelGGL((fwd_staged_kernel<W, H, 1, uint8_t>), grid, block, 0, s, src, pred, co, q, dq, eob, sad,
+                           (unsigned long long*)energy, iscan, qp, tx_type, (uint32_t)n, xy, ss, ps);
     return launch_status("fwd_quant_staged");
 }
 template <int W, int H>
@@ -565,9 +571,10 @@ extern "C" int svt_hip_fwd_quant_planes_batch(const void* d_src, uint32_t src_st
 #undef F32P
         return launch_status("fwd_quant_32x32_planes");
     }
-    if (!g_tune_no_staged && qp.fast_ok && pels > 16 && !d_xy && !is_16bit && ((uintptr_t)d_src & 15) == 0 && ((uintptr_t)d_pred & 15) == 0 &&
+    // staged (coalesced) kernels: dense batches need 16-B aligned inputs, plane-addressed blocks do not
+    if (!g_tune_no_staged && qp.fast_ok && pels > 16 && (d_xy || (((uintptr_t)d_src & 15) == 0 && ((uintptr_t)d_pred & 15) == 0)) &&
         ((uintptr_t)d_coeff & 15) == 0 && ((uintptr_t)d_qcoeff & 15) == 0 && ((uintptr_t)d_dqcoeff & 15) == 0) {
-#define CALLS(W, H) launch_fq_staged<W, H>((const uint8_t*)d_src, (const uint8_t*)d_pred, nblocks, tx_type, qp, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_energy, s)
+#define CALLS(W, H) launch_fq_staged<W, H>(d_src, d_pred, is_16bit, d_xy, src_stride, pred_stride, nblocks, tx_type, qp, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_energy, s)
         TX_SWITCH(tx_size, CALLS)
 #undef CALLS
     }
