@@ -237,9 +237,12 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void fwd_staged_kernel(
 // destination read / add / clip / write in linear 16-B chunks.
 // Math == inv_txfm2d_add_kernel (kernel_txfm.h) == inv_txfm2d_add_c (EbTransforms.c:8180).
 // ---------------------------------------------------------------------------
+// dst_offsets != NULL: destination block b starts at dst + dst_offsets[b] (samples) with row stride dst_stride
+// (reconstruction written in place into a picture plane); NULL: dense W*H blocks back to back.
 template <int W, int H, typename PixT>
 __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
-    const int32_t* __restrict__ in, PixT* __restrict__ dst, int tx_type, int bd, uint32_t nblocks) {
+    const int32_t* __restrict__ in, PixT* __restrict__ dst, int tx_type, int bd, uint32_t nblocks,
+    const uint32_t* __restrict__ dst_offsets = nullptr, int32_t dst_stride = 0) {
     using S = StagedGeom<W, H>;
     using G = TxGeom<W, H>;
     constexpr int KW = S::KW, KH = S::KH, NC = S::NC;
@@ -320,6 +323,49 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
         for (int r = 0; r < H; r++) res[r * W + l] = (short)round_shift_c<4>(y[ud ? H - 1 - r : r]);
     }
     wave_lds_fence();
+    // ---- destination on a plane: chunks of CS bytes that never cross a block row ---------------------
+    if (dst_offsets) {
+        constexpr int ES = (int)sizeof(PixT);
+        constexpr int ROWB = W * ES, CS = ROWB >= 16 ? 16 : ROWB, PPC = CS / ES;
+        constexpr int CPR = ROWB / CS, CPBP = W * H * ES / CS, NCHP = G::BPW * CPBP, NIT = (NCHP + 63) / 64;
+        const int maxpix = (1 << bd) - 1;
+        uint32_t org[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * 64 + lane, b = q / CPBP;
+            org[it] = (q < NCHP && first + b < nblocks) ? dst_offsets[first + b] : 0xffffffffu;
+        }
+        uint4 pvv[NIT];
+        PixT* dp[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * 64 + lane, w = q % CPBP;
+            pvv[it] = make_uint4(0, 0, 0, 0);
+            dp[it] = dst + (size_t)(org[it] == 0xffffffffu ? 0u : org[it]) + (size_t)(w / CPR) * dst_stride + (w % CPR) * PPC;
+            if (org[it] != 0xffffffffu) __builtin_memcpy(&pvv[it], dp[it], CS);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * 64 + lane;
+            if (org[it] != 0xffffffffu) {
+                // q-th chunk of the wave = PPC consecutive residuals of the row-major int16 tile
+                const uint32_t* rs = reinterpret_cast<const uint32_t*>(reinterpret_cast<const short*>(wl) + (size_t)q * PPC);
+                const uint32_t pw[4] = {pvv[it].x, pvv[it].y, pvv[it].z, pvv[it].w};
+                uint32_t ow[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < CS / 4; k++) {
+                    if (ES == 1) {
+                        const uint32_t p01 = __builtin_amdgcn_perm(0u, pw[k], 0x0c010c00u), p23 = __builtin_amdgcn_perm(0u, pw[k], 0x0c030c02u);
+                        const uint32_t u01 = sat_pk_u8_i16(pk_add_i16(p01, rs[2 * k])), u23 = sat_pk_u8_i16(pk_add_i16(p23, rs[2 * k + 1]));
+                        ow[k] = (u23 << 16) | (u01 & 0xffffu);
+                    } else {
+                        ow[k] = pk_clamp_i16(pk_add_i16(pw[k], rs[k]), maxpix);
+                    }
+                }
+                __builtin_memcpy(dp[it], ow, CS);
+            }
+        }
+    } else
     // ---- destination: linear 16-B chunks --------------------------------------------------------
     {
         constexpr int PPL = 16 / (int)sizeof(PixT);

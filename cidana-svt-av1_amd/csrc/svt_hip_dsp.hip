@@ -39,6 +39,7 @@ int g_tune_no_qsad = 0;
 int g_tune_no_q2 = 0;
 int g_tune_no_me16 = 0;
 int g_tune_no_f32p = 0;
+int g_tune_no_inv_planes = 0;
 int g_tune_inv32_waves = 4;
 int g_tune_inv32_var = 0;
 
@@ -167,12 +168,13 @@ int launch_fq_staged(const void* src, const void* pred, int is16, const uint32_t
     return launch_status("fwd_quant_staged");
 }
 template <int W, int H>
-int launch_inv_staged(const int32_t* in, void* dst, int is16, size_t n, int tx_type, int bd, hipStream_t s) {
+int launch_inv_staged(const int32_t* in, void* dst, int is16, size_t n, int tx_type, int bd, const uint32_t* offs, int32_t stride,
+                      hipStream_t s) {
     using SG = StagedGeom<W, H>;
     const uint32_t per_wg = SG::WAVES * TxGeom<W, H>::BPW;
     const uint32_t grid = (uint32_t)((n + per_wg - 1) / per_wg);
-    if (is16) hipLaunchKernelGGL((inv_staged_kernel<W, H, uint16_t>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint16_t*)dst, tx_type, bd, (uint32_t)n);
-    else hipLaunchKernelGGL((inv_staged_kernel<W, H, uint8_t>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint8_t*)dst, tx_type, bd, (uint32_t)n);
+    if (is16) hipLaunchKernelGGL((inv_staged_kernel<W, H, uint16_t>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint16_t*)dst, tx_type, bd, (uint32_t)n, offs, stride);
+    else hipLaunchKernelGGL((inv_staged_kernel<W, H, uint8_t>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint8_t*)dst, tx_type, bd, (uint32_t)n, offs, stride);
     return launch_status("inv_staged");
 }
 template <int W, int H>
@@ -289,6 +291,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "no_q2")) { g_tune_no_q2 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_me16")) { g_tune_no_me16 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_f32p")) { g_tune_no_f32p = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_inv_planes")) { g_tune_no_inv_planes = value; return SVT_HIP_OK; }
     if (!strcmp(key, "inv32_waves")) { g_tune_inv32_waves = value; return SVT_HIP_OK; }
     if (!strcmp(key, "inv32_var")) { g_tune_inv32_var = value; return SVT_HIP_OK; }
     return set_err(SVT_HIP_ERR_INVALID, "unknown tuning key %s", key);
@@ -396,9 +399,12 @@ extern "C" int svt_hip_inv_txfm2d_add_batch(const int32_t* d_coeff, void* d_dst,
 #undef INV32
         return launch_status("inv32");
     }
-    if (!g_tune_no_staged && !d_dst_offsets && dst_stride == kTxW[tx_size] && dst_block_pitch == (size_t)kTxW[tx_size] * kTxH[tx_size] &&
-        ((uintptr_t)d_coeff & 15) == 0 && ((uintptr_t)d_dst & 15) == 0 && (kTxW[tx_size] * kTxH[tx_size] * (dst_is_16bit ? 2 : 1)) % 16 == 0) {
-#define CALLS(W, H) launch_inv_staged<W, H>(d_coeff, d_dst, dst_is_16bit, nblocks, tx_type, bd, s)
+    const bool dense_dst = !d_dst_offsets && dst_stride == kTxW[tx_size] && dst_block_pitch == (size_t)kTxW[tx_size] * kTxH[tx_size] &&
+                           ((uintptr_t)d_dst & 15) == 0 && (kTxW[tx_size] * kTxH[tx_size] * (dst_is_16bit ? 2 : 1)) % 16 == 0;
+    // 4-sample-wide 8-bit rows would be 4-B chunks of an unaligned plane: leave those to the general kernel
+    const bool plane_dst = d_dst_offsets && kTxW[tx_size] * (dst_is_16bit ? 2 : 1) >= 8 && !g_tune_no_inv_planes;
+    if (!g_tune_no_staged && (dense_dst || plane_dst) && ((uintptr_t)d_coeff & 15) == 0) {
+#define CALLS(W, H) launch_inv_staged<W, H>(d_coeff, d_dst, dst_is_16bit, nblocks, tx_type, bd, d_dst_offsets, dst_stride, s)
         TX_SWITCH(tx_size, CALLS)
 #undef CALLS
     }
