@@ -100,6 +100,28 @@ if want("bd10"):
         ms = timeit(lambda: dsp.inv_txfm2d_add(co, d, s, 0, 10))
         rec(f"inv_txfm2d_add_u16_bd10_{w}x{h}", n, 4 * w * h + 4 * w * h, ms)
         del src, pred, co, d
+# BASELINE configs[4] shape: a shard of a 10-bit GOP, 16 luma frames of 1080p stacked in one plane, blocks addressed by
+# origin tables; forward+quant on planes, then inverse + reconstruction in place (15 B/px at 8-bit, 18 B/px at 10-bit)
+if want("gop"):
+    qt10 = svtlibs.quant_tables(10); qrow10 = {k: v[100].copy() for k, v in qt10.items()}
+    FR, PH, PW = 16, 1080, 1920
+    srcp = torch.randint(0, 1024, (FR * PH, PW), dtype=torch.int16, device=dev)
+    predp = (srcp + torch.randint(-12, 13, (FR * PH, PW), dtype=torch.int16, device=dev)).clamp(0, 1023)
+    for s in (3, 2, 1):
+        S = TW[s]
+        xs = np.arange(0, PW - S + 1, S); ys = np.concatenate([f * PH + np.arange(0, PH - S + 1, S) for f in range(FR)])
+        xy = torch.from_numpy(np.array([(y << 16) | x for y in ys for x in xs], np.uint32).view(np.int32)).to(dev)
+        offs = torch.from_numpy(np.array([y * PW + x for y in ys for x in xs], np.uint32).view(np.int32)).to(dev)
+        _, isc = svtlibs.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
+        recon = predp.clone()
+        def gop():
+            co, q, dq, eob, _, _ = dsp.fwd_quant_planes(srcp, PW, predp, PW, xy, s, 0, qrow10, iscan, bd=10)
+            dsp.inv_txfm2d_add(dq, recon, s, 0, 10, dst_stride=PW, dst_block_pitch=0, offsets=offs)
+        ms = timeit(gop, iters=4)
+        n = xy.numel()
+        rec(f"gop16_1080p_bd10_planes_fwd+quant+inv_{S}x{S}", n, 18 * S * S, ms, {"ms_per_frame": round(ms / FR, 4), "Mpx_per_s": round(n * S * S / ms / 1e3, 1)})
+        del recon, xy, offs
+    del srcp, predp
 # fused encode-pass chain (residual -> fwd -> quant/dequant -> inverse -> recon), 32x32
 if want("encode_recon"):
     n = 1 << 20
