@@ -405,4 +405,232 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// enc_staged_kernel<W, H, KEEP> — the encode-pass chain (see enc32_kernel in kernel_fused32.h) for every
+// other size, 8-bit dense batches: fwd_staged_kernel<W, H, 1> up to the quantiser, whose dequantised 16-B
+// chunks are written straight into the coefficient rows inv_staged_kernel starts from; the prediction
+// chunks loaded for the residual stay in registers and are the destination of the reconstruction.
+// HBM traffic: 2*W*H in + 4*KW*KH (qcoeff) + W*H (recon) + 6 B out (+ coeff, dqcoeff when KEEP).
+// ---------------------------------------------------------------------------
+template <int W, int H, bool KEEP>
+__global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
+    const uint8_t* __restrict__ src, const uint8_t* __restrict__ pred, uint8_t* __restrict__ recon,
+    int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
+    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
+    int tx_type, uint32_t nblocks) {
+    using S = StagedGeom<W, H>;
+    using G = TxGeom<W, H>;
+    constexpr int KW = S::KW, KH = S::KH, NC = S::NC;
+    constexpr int BB = W * H;                            // input bytes per block and array
+    constexpr int PADI = (W >= 32) ? 32 : 16;
+    constexpr int IN_ONE = G::BPW * (BB + PADI);
+    constexpr int PQ = (KW == 4) ? 3 : KW / 4 + 1;
+    constexpr int WAVE_LDS = (cmax(cmax(cmax(IN_ONE * 2, G::BPW * G::TILE * 4), G::BPW * W * H * 4), G::BPW * KH * PQ * 16) + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) char lds[S::WAVES * WAVE_LDS];
+    static_assert(W * H % 16 == 0, "block must be a whole number of 16-B chunks");
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* wl = lds + wave * WAVE_LDS;
+    const uint32_t first = (blockIdx.x * S::WAVES + wave) * G::BPW;
+    if (first >= nblocks) return;                         // wave-uniform
+    const int sub = lane / G::LPB, l = lane % G::LPB;
+    const uint32_t blk = first + sub;
+    const bool valid = blk < nblocks;
+    const int vk = kVKind[tx_type], hk = kHKind[tx_type];
+    const bool ud = vk == K1D_FLIPADST, lr = hk == K1D_FLIPADST;
+    constexpr int CBC = fwd_cos_col(W, H), CBR = fwd_cos_row(W, H);
+    constexpr int S0 = fwd_shift(W, H, 0), S1 = fwd_shift(W, H, 1), S2 = fwd_shift(W, H, 2);
+
+    // ---- stage the wave's input: linear 16-B chunks; the prediction chunks stay in registers ----
+    constexpr int NCH = G::BPW * BB / 16, NCHI = (NCH + 63) / 64;
+    uint4 pk[NCHI];
+    {
+        const char* g0 = reinterpret_cast<const char*>(src) + (size_t)first * BB;
+        const char* g1 = reinterpret_cast<const char*>(pred) + (size_t)first * BB;
+#pragma unroll
+        for (int it = 0; it < NCHI; it++) {
+            const int q = it * 64 + lane;
+            pk[it] = make_uint4(0, 0, 0, 0);
+            if (NCH % 64 == 0 || q < NCH) {
+                const int b = (q * 16) / BB;
+                const bool ok = first + b < nblocks;
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                if (ok) pk[it] = *reinterpret_cast<const uint4*>(g1 + (size_t)q * 16);
+                *reinterpret_cast<uint4*>(wl + q * 16 + b * PADI) = ok ? *reinterpret_cast<const uint4*>(g0 + (size_t)q * 16) : z;
+                *reinterpret_cast<uint4*>(wl + IN_ONE + q * 16 + b * PADI) = pk[it];
+            }
+        }
+    }
+    wave_lds_fence();
+    // ---- forward: column pass ------------------------------------------------------------------
+    unsigned sad_acc = 0;
+    {
+        int x[H];
+        if (l < W) {
+            const char* bs = wl + sub * (BB + PADI);
+#pragma unroll
+            for (int r = 0; r < H; r++) {
+                const int idx = (ud ? H - 1 - r : r) * W + l;
+                const int d = (int)*reinterpret_cast<const uint8_t*>(bs + idx) - (int)*reinterpret_cast<const uint8_t*>(bs + IN_ONE + idx);
+                sad_acc += (unsigned)(d < 0 ? -d : d);
+                x[r] = round_shift_c<-S0>(d);
+            }
+            fwd1d<H, CBC>(vk, x);
+        }
+        wave_lds_fence();                                 // staging is dead: the tile may overwrite it
+        int32_t* tile = reinterpret_cast<int32_t*>(wl) + sub * G::TILE;
+        if (l < W) {
+            const int cdst = lr ? W - 1 - l : l;
+#pragma unroll
+            for (int r = 0; r < H; r++) tile[r * G::PITCH + cdst] = round_shift_c<-S1>(x[r]);
+        }
+    }
+    wave_lds_fence();
+    // ---- forward: row pass ----------------------------------------------------------------------
+    {
+        int32_t* tile = reinterpret_cast<int32_t*>(wl) + sub * G::TILE;
+        int y[W];
+        if (l < H) {
+#pragma unroll
+            for (int c = 0; c < W; c++) y[c] = tile[l * G::PITCH + c];
+            fwd1d<W, CBR>(hk, y);
+#pragma unroll
+            for (int c = 0; c < W; c++) {
+                int t = round_shift_c<-S2>(y[c]);
+                if (G::RECT2) t = mul_q12(t, 5793);
+                y[c] = t;
+            }
+        }
+        wave_lds_fence();                                 // tile is dead: the out tile may overwrite it
+        if (l < H) {
+#pragma unroll
+            for (int s = 0; s < W / 4; s++)
+                *reinterpret_cast<int4*>(wl + S::out_addr(sub, l, s)) = make_int4(y[4 * s], y[4 * s + 1], y[4 * s + 2], y[4 * s + 3]);
+        }
+    }
+    wave_lds_fence();
+    sad_acc = group_sum<G::LPB>(sad_acc);
+    if (valid && l == 0 && sad) sad[blk] = sad_acc;
+    // ---- quantise in linear chunk order; dequantised chunks stay in registers ----------------------
+    constexpr int CPB = NC / 4, NOUT = G::BPW * CPB, NOUTI = (NOUT + 63) / 64;
+    int4 dvs[NOUTI];
+    {
+        int eob_acc = 0;
+#pragma unroll
+        for (int it = 0; it < NOUTI; it++) {
+            const int q = it * 64 + lane;
+            const bool act = (NOUT % 64 == 0) || q < NOUT;
+            const int b = act ? q / CPB : 0, w4 = act ? q % CPB : 0;
+            const bool ok = act && (first + b < nblocks);
+            const int4 c = *reinterpret_cast<const int4*>(wl + S::out_addr(b, w4 / (KW / 4), w4 % (KW / 4)));
+            int4 qv, dv;
+            quant_one<2>(c.x, w4 == 0 ? 0 : 1, qp, qv.x, dv.x);     // the host only takes this kernel for power-of-two quant_shift
+            quant_one<2>(c.y, 1, qp, qv.y, dv.y);
+            quant_one<2>(c.z, 1, qp, qv.z, dv.z);
+            quant_one<2>(c.w, 1, qp, qv.w, dv.w);
+            dvs[it] = dv;
+            const uint2 is = *reinterpret_cast<const uint2*>(iscan + w4 * 4);
+            int e = max(max(qv.x ? (int)(is.x & 0xffffu) + 1 : 0, qv.y ? (int)(is.x >> 16) + 1 : 0),
+                        max(qv.z ? (int)(is.y & 0xffffu) + 1 : 0, qv.w ? (int)(is.y >> 16) + 1 : 0));
+            if (!act) e = 0;
+            if (ok) {
+                const size_t o = (size_t)(first + b) * NC + (size_t)w4 * 4;
+                *reinterpret_cast<int4*>(qcoeff + o) = qv;
+                if (KEEP) { *reinterpret_cast<int4*>(coeff + o) = c; *reinterpret_cast<int4*>(dqcoeff + o) = dv; }
+            }
+            if constexpr (CPB >= 64) {
+                eob_acc = max(eob_acc, e);
+                if ((it + 1) % (CPB / 64) == 0) {
+                    const int m = group_max<64>(eob_acc);
+                    if (lane == 0 && ok) eob[first + b] = (uint16_t)m;
+                    eob_acc = 0;
+                }
+            } else {
+                const int m = group_max<(CPB < 64 ? CPB : 64)>(e);
+                if (ok && w4 == 0) eob[first + b] = (uint16_t)m;
+            }
+        }
+    }
+    wave_lds_fence();                                     // the out tile is dead: coefficient rows may overwrite it
+#pragma unroll
+    for (int it = 0; it < NOUTI; it++) {
+        const int q = it * 64 + lane;
+        if (NOUT % 64 == 0 || q < NOUT) {
+            const int b = q / CPB, w4 = q % CPB;
+            *reinterpret_cast<int4*>(wl + ((b * KH + w4 / (KW / 4)) * PQ + w4 % (KW / 4)) * 16) = dvs[it];
+        }
+    }
+    wave_lds_fence();
+    // ---- inverse (inv_staged_kernel<W, H, uint8_t>, bd = 8) -------------------------------------
+    constexpr int IS0 = inv_shift0(W, H);
+    {
+        int x[W];
+        if (l < H) {
+            if (l < KH) {
+#pragma unroll
+                for (int s = 0; s < KW / 4; s++) {
+                    const int4 v = *reinterpret_cast<const int4*>(wl + ((sub * KH + l) * PQ + s) * 16);
+                    x[4 * s] = v.x; x[4 * s + 1] = v.y; x[4 * s + 2] = v.z; x[4 * s + 3] = v.w;
+                }
+#pragma unroll
+                for (int c = 0; c < W; c++) {
+                    int v = c < KW ? x[c] : 0;
+                    if (G::RECT2) v = mul_q12(v, 2896);
+                    x[c] = svtgen::svt_clamp(v, -(1 << 15), (1 << 15) - 1);
+                }
+                inv1d<W>(hk, x, -(1 << 15), (1 << 15) - 1);
+            } else {
+#pragma unroll
+                for (int c = 0; c < W; c++) x[c] = 0;
+            }
+        }
+        wave_lds_fence();
+        int32_t* tile = reinterpret_cast<int32_t*>(wl) + sub * G::TILE;
+        if (l < H) {
+#pragma unroll
+            for (int c = 0; c < W; c++) tile[l * G::PITCH + c] = round_shift_c<-IS0>(x[c]);
+        }
+    }
+    wave_lds_fence();
+    {
+        int32_t* tile = reinterpret_cast<int32_t*>(wl) + sub * G::TILE;
+        int y[H];
+        if (l < W) {
+            const int csrc = lr ? W - 1 - l : l;
+#pragma unroll
+            for (int r = 0; r < H; r++) y[r] = svtgen::svt_clamp(tile[r * G::PITCH + csrc], -(1 << 15), (1 << 15) - 1);
+            inv1d<H>(vk, y, -(1 << 15), (1 << 15) - 1);
+        }
+        wave_lds_fence();
+        if (l < W) {
+            short* res = reinterpret_cast<short*>(wl) + sub * (W * H);
+#pragma unroll
+            for (int r = 0; r < H; r++) res[r * W + l] = (short)round_shift_c<4>(y[ud ? H - 1 - r : r]);
+        }
+    }
+    wave_lds_fence();
+    // ---- reconstruction = prediction (still in registers) + residual, linear 16-B chunks ----------
+    {
+        uint4* d4 = reinterpret_cast<uint4*>(recon + (size_t)first * BB);
+#pragma unroll
+        for (int it = 0; it < NCHI; it++) {
+            const int q = it * 64 + lane;
+            if ((NCH % 64 == 0 || q < NCH) && (first + (q * 16) / BB < nblocks)) {
+                const uint4* rs4 = reinterpret_cast<const uint4*>(reinterpret_cast<const short*>(wl) + (size_t)q * 16);
+                const uint4 ra = rs4[0], rb = rs4[1];
+                const uint32_t rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                const uint32_t pw[4] = {pk[it].x, pk[it].y, pk[it].z, pk[it].w};
+                uint32_t ow[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t p01 = __builtin_amdgcn_perm(0u, pw[k], 0x0c010c00u), p23 = __builtin_amdgcn_perm(0u, pw[k], 0x0c030c02u);
+                    const uint32_t u01 = sat_pk_u8_i16(pk_add_i16(p01, rw[2 * k])), u23 = sat_pk_u8_i16(pk_add_i16(p23, rw[2 * k + 1]));
+                    ow[k] = (u23 << 16) | (u01 & 0xffffu);
+                }
+                d4[q] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            }
+        }
+    }
+}
+
 }  // namespace svtdev

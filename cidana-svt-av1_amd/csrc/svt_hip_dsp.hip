@@ -40,6 +40,7 @@ int g_tune_no_q2 = 0;
 int g_tune_no_me16 = 0;
 int g_tune_no_f32p = 0;
 int g_tune_no_inv_planes = 0;
+int g_tune_no_enc_staged = 0;
 int g_tune_inv32_waves = 4;
 int g_tune_inv32_var = 0;
 
@@ -168,6 +169,16 @@ int launch_fq_staged(const void* src, const void* pred, int is16, const uint32_t
     return launch_status("fwd_quant_staged");
 }
 template <int W, int H>
+int launch_enc_staged(const uint8_t* src, const uint8_t* pred, uint8_t* recon, int32_t* co, int32_t* q, int32_t* dq, uint16_t* eob,
+                      uint32_t* sad, const int16_t* iscan, const QParams& qp, int tx_type, size_t n, hipStream_t s) {
+    using SG = StagedGeom<W, H>;
+    const uint32_t per_wg = SG::WAVES * TxGeom<W, H>::BPW;
+    const dim3 grid((uint32_t)((n + per_wg - 1) / per_wg)), block(SG::WAVES * 64);
+    if (co) hipLaunchKernelGGL((enc_staged_kernel<W, H, true>), grid, block, 0, s, src, pred, recon, co, q, dq, eob, sad, iscan, qp, tx_type, (uint32_t)n);
+    else hipLaunchKernelGGL((enc_staged_kernel<W, H, false>), grid, block, 0, s, src, pred, recon, co, q, dq, eob, sad, iscan, qp, tx_type, (uint32_t)n);
+    return launch_status("encode_recon_staged");
+}
+template <int W, int H>
 int launch_inv_staged(const int32_t* in, void* dst, int is16, size_t n, int tx_type, int bd, const uint32_t* offs, int32_t stride,
                       hipStream_t s) {
     using SG = StagedGeom<W, H>;
@@ -292,6 +303,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "no_me16")) { g_tune_no_me16 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_f32p")) { g_tune_no_f32p = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_inv_planes")) { g_tune_no_inv_planes = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_enc_staged")) { g_tune_no_enc_staged = value; return SVT_HIP_OK; }
     if (!strcmp(key, "inv32_waves")) { g_tune_inv32_waves = value; return SVT_HIP_OK; }
     if (!strcmp(key, "inv32_var")) { g_tune_inv32_var = value; return SVT_HIP_OK; }
     return set_err(SVT_HIP_ERR_INVALID, "unknown tuning key %s", key);
@@ -514,6 +526,18 @@ extern "C" int svt_hip_encode_recon_batch(const uint8_t* d_src, const uint8_t* d
             else { if (d_sad) ENC32(false, true); else ENC32(false, false); }
 #undef ENC32
             return launch_status("encode_recon_32x32");
+        }
+    }
+    {   // every other size: the staged fused kernel (dense 8-bit batches, power-of-two quant_shift tables)
+        const int pels = kTxW[tx_size] * kTxH[tx_size];
+        const QParams qp = make_qparams(zbin, round, quant, quant_shift, dequant, pels > 1024 ? 2 : (pels > 256 ? 1 : 0));
+        bool ok = qp.fast_ok && pels > 16 && !g_tune_no_enc_staged && ((d_coeff != nullptr) == (d_dqcoeff != nullptr));
+        for (int i = 0; i < 2; i++) ok = ok && qp.quant_shift[i] >= 0 && qp.dequant[i] >= 0 && qp.round[i] >= 0;
+        ok = ok && (((uintptr_t)d_src | (uintptr_t)d_pred | (uintptr_t)d_recon | (uintptr_t)d_qcoeff | (uintptr_t)d_coeff | (uintptr_t)d_dqcoeff) & 15) == 0;
+        if (ok) {
+#define ENCS(W, H) launch_enc_staged<W, H>(d_src, d_pred, d_recon, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, tx_type, nblocks, s)
+            TX_SWITCH(tx_size, ENCS)
+#undef ENCS
         }
     }
     // composed path: the two batched stages around a device copy of the prediction

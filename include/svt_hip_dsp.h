@@ -157,9 +157,11 @@ int svt_hip_fwd_quant_sad_batch(const uint8_t *d_src, const uint8_t *d_pred, siz
  *   recon    = pred + InvTxfm2d(dq)    av1_inv_transform_recon8bit    (EbCodingLoop.c:753)
  * (+ sad = SAD(src, pred) when d_sad != NULL).  8-bit, dense W*H blocks; d_recon must not alias
  * d_src / d_pred.  TX_32X32 with DCT_DCT or IDTX runs ONE fused kernel in which coefficients and
- * residual never leave the CU (7 174 B of HBM traffic per block instead of 20 486); d_coeff and
- * d_dqcoeff are optional there (NULL = not written).  Every other size/type runs
- * svt_hip_fwd_quant_planes_batch + a device copy + svt_hip_inv_txfm2d_add_batch and needs both buffers. */
+ * residual never leave the CU (7 174 B of HBM traffic per block instead of 20 486); every other size
+ * except 4x4 runs the generic fused kernel of the same structure.  d_coeff and d_dqcoeff are optional in
+ * the fused kernels (both NULL = not written).  4x4 blocks, quantiser tables whose quant_shift is not a
+ * power of two and buffers that are not 16-B aligned run svt_hip_fwd_quant_sad_batch + a device copy +
+ * svt_hip_inv_txfm2d_add_batch and need both buffers. */
 int svt_hip_encode_recon_batch(const uint8_t *d_src, const uint8_t *d_pred, size_t nblocks, int tx_size,
                                int tx_type, const int16_t *zbin, const int16_t *round,
                                const int16_t *quant, const int16_t *quant_shift, const int16_t *dequant,

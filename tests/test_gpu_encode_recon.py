@@ -57,23 +57,29 @@ def test_fused_encode_recon_32x32_idtx(dsp):
     check(dsp, src, pred, 3, 9, 100, False)                     # IDTX
 
 
-@pytest.mark.parametrize("tx_size,tx_type", [(0, 0), (1, 5), (2, 1), (4, 0), (9, 0), (12, 0), (16, 10)])
-def test_composed_encode_recon_other_sizes(dsp, tx_size, tx_type):
+@pytest.mark.parametrize("keep", [True, False])
+@pytest.mark.parametrize("tx_size,tx_type", [(0, 0), (1, 5), (1, 0), (2, 1), (2, 6), (4, 0), (5, 3), (6, 0), (7, 8), (9, 0), (10, 9),
+                                             (11, 0), (12, 0), (13, 1), (14, 0), (15, 0), (16, 10), (17, 0), (18, 0)])
+def test_encode_recon_other_sizes(dsp, tx_size, tx_type, keep):
+    """enc_staged_kernel (every size but 4x4 and 32x32) and, for 4x4, the composed two-kernel path."""
     if not svtlibs.txfm_allowed(tx_size, tx_type):
         pytest.skip("type not defined for this size")
+    if tx_size == 0 and not keep:
+        pytest.skip("4x4 runs the composed path, which needs the coefficient buffers")
     rng = np.random.default_rng(7 + tx_size)
-    src, pred = make_pixels(rng, 11, TX_H[tx_size], TX_W[tx_size], "smooth")
-    check(dsp, src, pred, tx_size, tx_type, 60, True)
+    for kind, n in (("smooth", 11), ("extreme", 7), ("random", 70)):       # 70: more than one wave of small blocks
+        src, pred = make_pixels(rng, n, TX_H[tx_size], TX_W[tx_size], kind)
+        check(dsp, src, pred, tx_size, tx_type, 60, keep)
 
 
 def test_encode_recon_argument_errors(dsp, pkg):
     qt = svtlibs.quant_tables(8)
     qrow = {k: v[100].copy() for k, v in qt.items()}
-    _, iscan = svtlibs.scan_tables(2, 0)
-    src = torch.zeros((3, 16, 16), dtype=torch.uint8, device="cuda:0")
-    with pytest.raises(RuntimeError):                           # composed path needs coeff / dqcoeff buffers
-        dsp.encode_recon(src, src.clone(), 2, 0, qrow, dev(iscan), keep_coeff=False)
-    out = dsp.encode_recon(src[:0], src[:0].clone(), 2, 0, qrow, dev(iscan))     # empty batch is a no-op
+    _, iscan = svtlibs.scan_tables(0, 0)
+    src = torch.zeros((3, 4, 4), dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(RuntimeError):                           # composed path (4x4) needs coeff / dqcoeff buffers
+        dsp.encode_recon(src, src.clone(), 0, 0, qrow, dev(iscan), keep_coeff=False)
+    out = dsp.encode_recon(src[:0], src[:0].clone(), 0, 0, qrow, dev(iscan))     # empty batch is a no-op
     assert out["recon"].shape[0] == 0
 
 

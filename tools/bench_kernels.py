@@ -131,6 +131,14 @@ if want("encode_recon"):
     rec(f"encode_recon_32x32_fused(qcoeff+recon)", n, 2048 + 4096 + 1024 + 6, timeit(lambda: dsp.encode_recon(src, pred, 3, 0, qrow, iscan, keep_coeff=False)))
     rec(f"encode_recon_32x32_fused(+coeff,dqcoeff)", n, 2048 + 3 * 4096 + 1024 + 6, timeit(lambda: dsp.encode_recon(src, pred, 3, 0, qrow, iscan, keep_coeff=True)))
     del src, pred
+    for s_, n in ((1, 1 << 22), (2, 1 << 21), (4, 1 << 18)):
+        w, h = TW[s_], TH[s_]
+        src = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=dev)
+        pred = (src.to(torch.int16) + torch.randint(-20, 21, (n, h, w), dtype=torch.int16, device=dev)).clamp(0, 255).to(torch.uint8)
+        _, isc = svtlibs.scan_tables(s_, 0); iscan = torch.from_numpy(isc).to(dev)
+        kc = min(w, 32) * min(h, 32)
+        rec(f"encode_recon_{w}x{h}_fused(qcoeff+recon)", n, 2 * w * h + 4 * kc + w * h + 6, timeit(lambda: dsp.encode_recon(src, pred, s_, 0, qrow, iscan, keep_coeff=False)))
+        del src, pred
 # intra
 if want("intra"):
     n = 1 << 21
