@@ -431,7 +431,10 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     const uint8_t* __restrict__ src, const uint8_t* __restrict__ pred, uint8_t* __restrict__ recon,
     int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
     uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
-    int is_idtx, uint32_t nblocks) {
+    int is_idtx, uint32_t nblocks, const uint32_t* __restrict__ xy = nullptr, uint32_t src_stride = 32,
+    uint32_t pred_stride = 32, uint32_t recon_stride = 32) {
+    // xy != NULL: blocks addressed on picture planes (origin (x, y) = (xy[b] & 0xffff, xy[b] >> 16), row strides
+    // in samples; recon may be the prediction plane itself); NULL: dense 32x32 blocks.
     __shared__ __attribute__((aligned(16))) int32_t lds[F32_WAVES * 2 * F32_TILE_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, li = lane & 31;
@@ -442,10 +445,22 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 
     // ---- load 2 x 1 KB, coalesced 16 B per lane; SAD on the raw bytes ----------------------
     uint4 s0 = {0, 0, 0, 0}, s1 = s0, p0 = s0, p1 = s0;
+    size_t rbase = pix_off;                                  // recon sample offset of the block
+    uint32_t rstr = 32;
     if (valid) {
-        const uint4* s4 = reinterpret_cast<const uint4*>(src + pix_off);
-        const uint4* p4 = reinterpret_cast<const uint4*>(pred + pix_off);
-        s0 = s4[li]; s1 = s4[li + 32]; p0 = p4[li]; p1 = p4[li + 32];
+        if (xy) {
+            const uint32_t o = xy[blk];
+            const size_t by = o >> 16, bx = o & 0xffffu;
+            const uint8_t* sp = src + (by + (li >> 1)) * src_stride + bx + (li & 1) * 16;
+            const uint8_t* pp = pred + (by + (li >> 1)) * pred_stride + bx + (li & 1) * 16;
+            __builtin_memcpy(&s0, sp, 16); __builtin_memcpy(&s1, sp + (size_t)16 * src_stride, 16);
+            __builtin_memcpy(&p0, pp, 16); __builtin_memcpy(&p1, pp + (size_t)16 * pred_stride, 16);
+            rbase = by * recon_stride + bx; rstr = recon_stride;
+        } else {
+            const uint4* s4 = reinterpret_cast<const uint4*>(src + pix_off);
+            const uint4* p4 = reinterpret_cast<const uint4*>(pred + pix_off);
+            s0 = s4[li]; s1 = s4[li + 32]; p0 = p4[li]; p1 = p4[li + 32];
+        }
     }
     unsigned sad_acc = 0;
     if (WITH_SAD) {
@@ -592,7 +607,10 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
                 const uint32_t ue = sat_pk_u8_i16(pk_add_i16(pe, re)), uo = sat_pk_u8_i16(pk_add_i16(po, ro));
                 ow[q] = __builtin_amdgcn_perm(uo, ue, 0x05010400u);
             }
-            reinterpret_cast<uint4*>(recon + pix_off)[L] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            // chunk L = row L/2, columns (L&1)*16 .. +15
+            const uint4 ov = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            if (xy) __builtin_memcpy(recon + rbase + (size_t)(L >> 1) * rstr + (L & 1) * 16, &ov, 16);
+            else reinterpret_cast<uint4*>(recon + pix_off)[L] = ov;
         }
     }
 }

@@ -417,7 +417,10 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
     const uint8_t* __restrict__ src, const uint8_t* __restrict__ pred, uint8_t* __restrict__ recon,
     int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
     uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
-    int tx_type, uint32_t nblocks) {
+    int tx_type, uint32_t nblocks, const uint32_t* __restrict__ xy = nullptr, uint32_t src_stride = 0,
+    uint32_t pred_stride = 0, uint32_t recon_stride = 0) {
+    // xy != NULL: blocks addressed on picture planes (origin (x, y) = (xy[b] & 0xffff, xy[b] >> 16), row strides
+    // in samples; recon may be the prediction plane itself); NULL: dense batches.
     using S = StagedGeom<W, H>;
     using G = TxGeom<W, H>;
     constexpr int KW = S::KW, KH = S::KH, NC = S::NC;
@@ -443,8 +446,36 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
 
     // ---- stage the wave's input: linear 16-B chunks; the prediction chunks stay in registers ----
     constexpr int NCH = G::BPW * BB / 16, NCHI = (NCH + 63) / 64;
-    uint4 pk[NCHI];
-    {
+    // plane mode: chunks of CS bytes that never cross a block row (same linear LDS image)
+    constexpr int CS = W >= 16 ? 16 : W, CPR = W / CS, CPBP = BB / CS, NCHP = G::BPW * CPBP, NIT = (NCHP + 63) / 64;
+    uint4 pk[NIT > NCHI ? NIT : NCHI];
+    uint32_t org[NIT];
+    if (xy) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * 64 + lane, b = q / CPBP;
+            org[it] = (q < NCHP && first + b < nblocks) ? xy[first + b] : 0xffffffffu;
+        }
+        uint4 v0[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * 64 + lane, w = q % CPBP;
+            v0[it] = make_uint4(0, 0, 0, 0); pk[it] = v0[it];
+            if (org[it] != 0xffffffffu) {
+                const size_t y = (org[it] >> 16) + w / CPR, x = (org[it] & 0xffffu) + (w % CPR) * CS;
+                __builtin_memcpy(&v0[it], src + y * src_stride + x, CS);
+                __builtin_memcpy(&pk[it], pred + y * pred_stride + x, CS);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * 64 + lane, b = q / CPBP;
+            if (NCHP % 64 == 0 || q < NCHP) {
+                __builtin_memcpy(wl + q * CS + b * PADI, &v0[it], CS);
+                __builtin_memcpy(wl + IN_ONE + q * CS + b * PADI, &pk[it], CS);
+            }
+        }
+    } else {
         const char* g0 = reinterpret_cast<const char*>(src) + (size_t)first * BB;
         const char* g1 = reinterpret_cast<const char*>(pred) + (size_t)first * BB;
 #pragma unroll
@@ -609,8 +640,27 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
         }
     }
     wave_lds_fence();
-    // ---- reconstruction = prediction (still in registers) + residual, linear 16-B chunks ----------
-    {
+    // ---- reconstruction = prediction (still in registers) + residual ---------------------------------
+    if (xy) {
+        constexpr int PPC = CS;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * 64 + lane, w = q % CPBP;
+            if (org[it] != 0xffffffffu) {
+                const uint32_t* rs = reinterpret_cast<const uint32_t*>(reinterpret_cast<const short*>(wl) + (size_t)q * PPC);
+                const uint32_t pw[4] = {pk[it].x, pk[it].y, pk[it].z, pk[it].w};
+                uint32_t ow[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < CS / 4; k++) {
+                    const uint32_t p01 = __builtin_amdgcn_perm(0u, pw[k], 0x0c010c00u), p23 = __builtin_amdgcn_perm(0u, pw[k], 0x0c030c02u);
+                    const uint32_t u01 = sat_pk_u8_i16(pk_add_i16(p01, rs[2 * k])), u23 = sat_pk_u8_i16(pk_add_i16(p23, rs[2 * k + 1]));
+                    ow[k] = (u23 << 16) | (u01 & 0xffffu);
+                }
+                const size_t y = (org[it] >> 16) + w / CPR, x = (org[it] & 0xffffu) + (w % CPR) * CS;
+                __builtin_memcpy(recon + y * recon_stride + x, ow, CS);
+            }
+        }
+    } else {
         uint4* d4 = reinterpret_cast<uint4*>(recon + (size_t)first * BB);
 #pragma unroll
         for (int it = 0; it < NCHI; it++) {

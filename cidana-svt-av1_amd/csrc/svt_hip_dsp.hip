@@ -170,12 +170,13 @@ int launch_fq_staged(const void* src, const void* pred, int is16, const uint32_t
 }
 template <int W, int H>
 int launch_enc_staged(const uint8_t* src, const uint8_t* pred, uint8_t* recon, int32_t* co, int32_t* q, int32_t* dq, uint16_t* eob,
-                      uint32_t* sad, const int16_t* iscan, const QParams& qp, int tx_type, size_t n, hipStream_t s) {
+                      uint32_t* sad, const int16_t* iscan, const QParams& qp, int tx_type, size_t n, const uint32_t* xy, uint32_t ss,
+                      uint32_t ps, uint32_t rs, hipStream_t s) {
     using SG = StagedGeom<W, H>;
     const uint32_t per_wg = SG::WAVES * TxGeom<W, H>::BPW;
     const dim3 grid((uint32_t)((n + per_wg - 1) / per_wg)), block(SG::WAVES * 64);
-    if (co) hipLaunchKernelGGL((enc_staged_kernel<W, H, true>), grid, block, 0, s, src, pred, recon, co, q, dq, eob, sad, iscan, qp, tx_type, (uint32_t)n);
-    else hipLaunchKernelGGL((enc_staged_kernel<W, H, false>), grid, block, 0, s, src, pred, recon, co, q, dq, eob, sad, iscan, qp, tx_type, (uint32_t)n);
+    if (co) hipLaunchKernelGGL((enc_staged_kernel<W, H, true>), grid, block, 0, s, src, pred, recon, co, q, dq, eob, sad, iscan, qp, tx_type, (uint32_t)n, xy, ss, ps, rs);
+    else hipLaunchKernelGGL((enc_staged_kernel<W, H, false>), grid, block, 0, s, src, pred, recon, co, q, dq, eob, sad, iscan, qp, tx_type, (uint32_t)n, xy, ss, ps, rs);
     return launch_status("encode_recon_staged");
 }
 template <int W, int H>
@@ -501,17 +502,18 @@ extern "C" int svt_hip_fwd_quant_sad_batch(const uint8_t* d_src, const uint8_t* 
     return launch_status("fwd_quant_sad_32x32");
 }
 
-extern "C" int svt_hip_encode_recon_batch(const uint8_t* d_src, const uint8_t* d_pred, size_t nblocks, int tx_size,
-                                          int tx_type, const int16_t* zbin, const int16_t* round, const int16_t* quant,
-                                          const int16_t* quant_shift, const int16_t* dequant, const int16_t* d_iscan,
-                                          int32_t* d_coeff, int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob,
-                                          uint32_t* d_sad, uint8_t* d_recon, void* stream) {
+static int encode_recon_impl(const uint8_t* d_src, uint32_t src_stride, const uint8_t* d_pred, uint32_t pred_stride,
+                             uint8_t* d_recon, uint32_t recon_stride, const uint32_t* d_xy, size_t nblocks, int tx_size,
+                             int tx_type, const int16_t* zbin, const int16_t* round, const int16_t* quant,
+                             const int16_t* quant_shift, const int16_t* dequant, const int16_t* d_iscan,
+                             int32_t* d_coeff, int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob,
+                             uint32_t* d_sad, void* stream) {
     if (int rc = require_init()) return rc;
     if (nblocks == 0) return SVT_HIP_OK;
     if (!d_src || !d_pred || !d_qcoeff || !d_eob || !d_recon || !d_iscan || !zbin || !round || !quant || !quant_shift || !dequant)
         return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
     if (!txfm_allowed(tx_size, tx_type)) return set_err(SVT_HIP_ERR_INVALID, "tx_size %d / tx_type %d not defined by the reference", tx_size, tx_type);
-    if (d_recon == d_src || d_recon == d_pred) return set_err(SVT_HIP_ERR_INVALID, "d_recon must not alias d_src / d_pred");
+    if (d_recon == d_src || (!d_xy && d_recon == d_pred)) return set_err(SVT_HIP_ERR_INVALID, "d_recon must not alias d_src (or, for dense batches, d_pred)");
     if (nblocks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "nblocks too large");
     hipStream_t s = (hipStream_t)stream;
     if (tx_size == SVT_TX_32X32 && (tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX)) {
@@ -521,7 +523,8 @@ extern "C" int svt_hip_encode_recon_batch(const uint8_t* d_src, const uint8_t* d
         if (ok && ((d_coeff != nullptr) == (d_dqcoeff != nullptr))) {
             const uint32_t grid = (uint32_t)((nblocks + 2 * F32_WAVES - 1) / (2 * F32_WAVES));
 #define ENC32(KEEP, SAD) hipLaunchKernelGGL((enc32_kernel<KEEP, SAD>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, d_pred, d_recon, \
-                                         d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks)
+                                         d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks, \
+                                         d_xy, src_stride, pred_stride, recon_stride)
             if (d_coeff) { if (d_sad) ENC32(true, true); else ENC32(true, false); }
             else { if (d_sad) ENC32(false, true); else ENC32(false, false); }
 #undef ENC32
@@ -533,20 +536,42 @@ extern "C" int svt_hip_encode_recon_batch(const uint8_t* d_src, const uint8_t* d
         const QParams qp = make_qparams(zbin, round, quant, quant_shift, dequant, pels > 1024 ? 2 : (pels > 256 ? 1 : 0));
         bool ok = qp.fast_ok && pels > 16 && !g_tune_no_enc_staged && ((d_coeff != nullptr) == (d_dqcoeff != nullptr));
         for (int i = 0; i < 2; i++) ok = ok && qp.quant_shift[i] >= 0 && qp.dequant[i] >= 0 && qp.round[i] >= 0;
-        ok = ok && (((uintptr_t)d_src | (uintptr_t)d_pred | (uintptr_t)d_recon | (uintptr_t)d_qcoeff | (uintptr_t)d_coeff | (uintptr_t)d_dqcoeff) & 15) == 0;
+        ok = ok && (((uintptr_t)d_qcoeff | (uintptr_t)d_coeff | (uintptr_t)d_dqcoeff) & 15) == 0;
+        ok = ok && (d_xy || (((uintptr_t)d_src | (uintptr_t)d_pred | (uintptr_t)d_recon) & 15) == 0);
         if (ok) {
-#define ENCS(W, H) launch_enc_staged<W, H>(d_src, d_pred, d_recon, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, tx_type, nblocks, s)
+#define ENCS(W, H) launch_enc_staged<W, H>(d_src, d_pred, d_recon, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, tx_type, nblocks, d_xy, src_stride, pred_stride, recon_stride, s)
             TX_SWITCH(tx_size, ENCS)
 #undef ENCS
         }
     }
     // composed path: the two batched stages around a device copy of the prediction
     if (!d_coeff || !d_dqcoeff) return set_err(SVT_HIP_ERR_INVALID, "this size/type/quantizer needs d_coeff and d_dqcoeff");
+    if (d_xy) return set_err(SVT_HIP_ERR_INVALID, "plane-addressed encode_recon needs a fused kernel (not 4x4, power-of-two quant_shift, 16-B aligned coefficient buffers); use svt_hip_fwd_quant_planes_batch + svt_hip_inv_txfm2d_add_batch");
     if (int rc = svt_hip_fwd_quant_sad_batch(d_src, d_pred, nblocks, tx_size, tx_type, zbin, round, quant, quant_shift, dequant,
                                              d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, stream)) return rc;
     const size_t pels = (size_t)kTxW[tx_size] * kTxH[tx_size];
     HIP_TRY(hipMemcpyAsync(d_recon, d_pred, pels * nblocks, hipMemcpyDeviceToDevice, s));
     return svt_hip_inv_txfm2d_add_batch(d_dqcoeff, d_recon, 0, kTxW[tx_size], pels, nullptr, nblocks, tx_size, tx_type, 8, stream);
+}
+
+extern "C" int svt_hip_encode_recon_batch(const uint8_t* d_src, const uint8_t* d_pred, size_t nblocks, int tx_size,
+                                          int tx_type, const int16_t* zbin, const int16_t* round, const int16_t* quant,
+                                          const int16_t* quant_shift, const int16_t* dequant, const int16_t* d_iscan,
+                                          int32_t* d_coeff, int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob,
+                                          uint32_t* d_sad, uint8_t* d_recon, void* stream) {
+    return encode_recon_impl(d_src, 0, d_pred, 0, d_recon, 0, nullptr, nblocks, tx_size, tx_type, zbin, round, quant, quant_shift,
+                             dequant, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, stream);
+}
+extern "C" int svt_hip_encode_recon_planes_batch(const uint8_t* d_src, uint32_t src_stride, const uint8_t* d_pred,
+                                                 uint32_t pred_stride, uint8_t* d_recon, uint32_t recon_stride,
+                                                 const uint32_t* d_xy, size_t nblocks, int tx_size, int tx_type,
+                                                 const int16_t* zbin, const int16_t* round, const int16_t* quant,
+                                                 const int16_t* quant_shift, const int16_t* dequant, const int16_t* d_iscan,
+                                                 int32_t* d_coeff, int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob,
+                                                 uint32_t* d_sad, void* stream) {
+    if (nblocks && !d_xy) { if (int rc = require_init()) return rc; return set_err(SVT_HIP_ERR_INVALID, "NULL origin table"); }
+    return encode_recon_impl(d_src, src_stride, d_pred, pred_stride, d_recon, recon_stride, d_xy, nblocks, tx_size, tx_type, zbin,
+                             round, quant, quant_shift, dequant, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, stream);
 }
 
 template <int W, int H>

@@ -103,3 +103,39 @@ def test_encode_recon_full_size_round_trip_property(dsp):
     assert torch.equal(a["recon"], rec2) and torch.equal(a["qcoeff"], q) and torch.equal(a["eob"], eob) and torch.equal(a["sad"], sad)
     err = (a["recon"].to(torch.int16) - src.to(torch.int16)).abs().max().item()
     assert err <= 24, err
+
+
+@pytest.mark.parametrize("tx_size,tx_type", [(3, 0), (3, 9), (2, 0), (2, 5), (1, 0), (4, 0), (9, 0), (7, 3), (5, 0), (13, 0), (17, 0)])
+@pytest.mark.parametrize("inplace", [False, True])
+def test_encode_recon_on_planes(dsp, tx_size, tx_type, inplace):
+    """Plane-addressed chain (svt_hip_encode_recon_planes_batch) on a frame whose size is not a multiple of the block:
+    every block against the oracle stages, untouched margin == prediction, in-place reconstruction allowed."""
+    if not svtlibs.txfm_allowed(tx_size, tx_type):
+        pytest.skip("type not defined for this size")
+    w, h = TX_W[tx_size], TX_H[tx_size]
+    rng = np.random.default_rng(31 * tx_size + tx_type)
+    PH, PW = 200, 328
+    src = rng.integers(0, 256, size=(PH, PW), dtype=np.uint8)
+    pred = np.clip(src.astype(int) + rng.integers(-9, 10, size=src.shape), 0, 255).astype(np.uint8)
+    xs = np.arange(3, PW - w + 1, w); ys = np.arange(1, PH - h + 1, h)          # unaligned origins on purpose
+    xy = np.array([(y << 16) | x for y in ys for x in xs], np.uint32)
+    qt = svtlibs.quant_tables(8)
+    qrow = {k: v[80].copy() for k, v in qt.items()}
+    _, iscan = svtlibs.scan_tables(tx_size, tx_type)
+    d_pred = dev(pred)
+    d_recon = d_pred if inplace else torch.full_like(d_pred, 7)
+    out = dsp.encode_recon_planes(dev(src), PW, d_pred, PW, d_recon, PW, dev(xy.view(np.int32)), tx_size, tx_type, qrow, dev(iscan),
+                                  keep_coeff=True, want_sad=True)
+    torch.cuda.synchronize()
+    rec = d_recon.cpu().numpy()
+    sb = np.stack([src[y:y + h, x:x + w] for y in ys for x in xs]); pb = np.stack([pred[y:y + h, x:x + w] for y in ys for x in xs])
+    rco, rq, rdq, reob, rsad = oracle_chain(sb, pb, tx_size, tx_type, qrow)
+    assert np.array_equal(out["qcoeff"].cpu().numpy(), rq) and np.array_equal(out["coeff"].cpu().numpy(), rco)
+    assert np.array_equal(out["dqcoeff"].cpu().numpy(), rdq)
+    assert np.array_equal(out["eob"].cpu().numpy().view(np.uint16), reob)
+    assert np.array_equal(out["sad"].cpu().numpy().view(np.uint32), rsad)
+    rrec = oracle_recon(pb, rdq, tx_size, tx_type)
+    expect = pred.copy() if inplace else np.full_like(pred, 7)
+    for i, (y, x) in enumerate([(y, x) for y in ys for x in xs]):
+        expect[y:y + h, x:x + w] = rrec[i]
+    assert np.array_equal(rec, expect)
