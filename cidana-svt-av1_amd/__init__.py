@@ -61,7 +61,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_quantize_b_batch.argtypes = [c_void_p, c_size_t, c_int] + [c_void_p] * 4 + [c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_int, c_size_t, c_void_p]
     L.svt_hip_encode_recon_planes_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_size_t,
-                                                    c_int, c_int] + [c_void_p] * 5 + [c_void_p] * 7
+                                                    c_int, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p] * 7
     L.svt_hip_encode_recon_batch.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_int] + [c_void_p] * 5 + [c_void_p] * 8
     L.svt_hip_fwd_quant_sad_batch.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_int] + [c_void_p] * 5 + \
                                              [c_void_p] * 6 + [c_void_p]
@@ -224,11 +224,12 @@ class SvtHipDsp:
         return {"coeff": co, "qcoeff": q, "dqcoeff": dq, "eob": eob, "sad": sad, "recon": recon}
 
     def encode_recon_planes(self, src, src_stride, pred, pred_stride, recon, recon_stride, xy, tx_size, tx_type, qrow, iscan,
-                            keep_coeff=False, want_sad=False):
-        """The encode-pass chain on uint8 planes: xy = int32 tensor of (y << 16) | x block origins; recon (may be pred
-        itself) is written in place.  -> dict(coeff, qcoeff, dqcoeff, eob, sad)"""
+                            keep_coeff=False, want_sad=False, bd=8):
+        """The encode-pass chain on uint8 (bd 8) or int16-as-uint16 (bd 10) planes: xy = int32 tensor of (y << 16) | x
+        block origins; recon (may be pred itself) is written in place.  -> dict(coeff, qcoeff, dqcoeff, eob, sad)"""
         t = self.torch
         n = xy.shape[0]
+        is16 = 0 if src.dtype == t.uint8 else 1
         nc = min(TX_W[tx_size], 32) * min(TX_H[tx_size], 32)
         mk = lambda: t.empty((n, nc), dtype=t.int32, device=src.device)
         co, dq = (mk(), mk()) if keep_coeff else (None, None)
@@ -237,7 +238,7 @@ class SvtHipDsp:
         sad = t.zeros(n, dtype=t.int32, device=src.device) if want_sad else None
         tabs = [_np16(qrow[k]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
         self._check(self.lib.svt_hip_encode_recon_planes_batch(self._p(src), src_stride, self._p(pred), pred_stride, self._p(recon),
-                                                                recon_stride, self._p(xy), n, tx_size, tx_type,
+                                                                recon_stride, self._p(xy), n, is16, bd, tx_size, tx_type,
                                                                 tabs[0].ctypes.data, tabs[1].ctypes.data, tabs[2].ctypes.data,
                                                                 tabs[3].ctypes.data, tabs[4].ctypes.data, self._p(iscan),
                                                                 self._p(co) if keep_coeff else None, self._p(q),

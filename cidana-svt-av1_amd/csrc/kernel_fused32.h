@@ -426,9 +426,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(5)))
 // the linear 16-B chunks inv32_kernel loads, and the prediction samples already sit in registers in
 // the 16-B-per-lane layout of its reconstruction stage.
 // ---------------------------------------------------------------------------
-template <bool KEEP, bool WITH_SAD>
+// PixT / BD: uint8_t / 8 or uint16_t / 10 (BASELINE configs[4]); the 16-bit variant differs only in how the
+// residual is formed (v_pk_sub_i16 on the loaded words), in the inverse's clamp ranges and in the final clip.
+template <typename PixT, int BD, bool KEEP, bool WITH_SAD>
 __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3))) void enc32_kernel(
-    const uint8_t* __restrict__ src, const uint8_t* __restrict__ pred, uint8_t* __restrict__ recon,
+    const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
     int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
     uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
     int is_idtx, uint32_t nblocks, const uint32_t* __restrict__ xy = nullptr, uint32_t src_stride = 32,
@@ -443,34 +445,38 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     const bool valid = blk < nblocks;
     const size_t pix_off = (size_t)blk * 1024;
 
-    // ---- load 2 x 1 KB, coalesced 16 B per lane; SAD on the raw bytes ----------------------
-    uint4 s0 = {0, 0, 0, 0}, s1 = s0, p0 = s0, p1 = s0;
-    size_t rbase = pix_off;                                  // recon sample offset of the block
-    uint32_t rstr = 32;
-    if (valid) {
-        if (xy) {
-            const uint32_t o = xy[blk];
-            const size_t by = o >> 16, bx = o & 0xffffu;
-            const uint8_t* sp = src + (by + (li >> 1)) * src_stride + bx + (li & 1) * 16;
-            const uint8_t* pp = pred + (by + (li >> 1)) * pred_stride + bx + (li & 1) * 16;
-            __builtin_memcpy(&s0, sp, 16); __builtin_memcpy(&s1, sp + (size_t)16 * src_stride, 16);
-            __builtin_memcpy(&p0, pp, 16); __builtin_memcpy(&p1, pp + (size_t)16 * pred_stride, 16);
-            rbase = by * recon_stride + bx; rstr = recon_stride;
-        } else {
-            const uint4* s4 = reinterpret_cast<const uint4*>(src + pix_off);
-            const uint4* p4 = reinterpret_cast<const uint4*>(pred + pix_off);
-            s0 = s4[li]; s1 = s4[li + 32]; p0 = p4[li]; p1 = p4[li + 32];
-        }
+    constexpr bool HBD = sizeof(PixT) == 2;
+    constexpr int NPK = HBD ? 4 : 2;                          // 16-B prediction chunks per lane (= reconstruction steps)
+    uint4 pk[NPK];                                            // chunk k of the lane: pixels (k*32 + li) * (16/sizeof(PixT)) ...
+    size_t rbase = pix_off;                                   // recon sample offset of the block
+    uint32_t rstr = 32, sstr = 32, pstr = 32;
+    size_t sbase = pix_off, pbase = pix_off;
+    if (valid && xy) {
+        const uint32_t o = xy[blk];
+        const size_t by = o >> 16, bx = o & 0xffffu;
+        sstr = src_stride; pstr = pred_stride; rstr = recon_stride;
+        sbase = by * sstr + bx; pbase = by * pstr + bx; rbase = by * rstr + bx;
     }
     unsigned sad_acc = 0;
-    if (WITH_SAD) {
-        sad_acc = __builtin_amdgcn_sad_u8(s0.x, p0.x, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s0.y, p0.y, sad_acc);
-        sad_acc = __builtin_amdgcn_sad_u8(s0.z, p0.z, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s0.w, p0.w, sad_acc);
-        sad_acc = __builtin_amdgcn_sad_u8(s1.x, p1.x, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s1.y, p1.y, sad_acc);
-        sad_acc = __builtin_amdgcn_sad_u8(s1.z, p1.z, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s1.w, p1.w, sad_acc);
-    }
     int x[32];
-    {   // residual as packed int16 pairs -> LDS -> columns (layout: see fwd32_kernel)
+    if constexpr (!HBD) {
+        // ---- 2 x 1 KB, 16 B per lane: rows li/2 and 16 + li/2, columns (li&1)*16 .. +15; SAD on the raw bytes
+        uint4 s0 = {0, 0, 0, 0}, s1 = s0;
+        pk[0] = s0; pk[1] = s0;
+        if (valid) {
+            const PixT* sp = src + sbase + (size_t)(li >> 1) * sstr + (li & 1) * 16;
+            const PixT* pp = pred + pbase + (size_t)(li >> 1) * pstr + (li & 1) * 16;
+            __builtin_memcpy(&s0, sp, 16); __builtin_memcpy(&s1, sp + (size_t)16 * sstr, 16);
+            __builtin_memcpy(&pk[0], pp, 16); __builtin_memcpy(&pk[1], pp + (size_t)16 * pstr, 16);
+        }
+        const uint4 p0 = pk[0], p1 = pk[1];
+        if (WITH_SAD) {
+            sad_acc = __builtin_amdgcn_sad_u8(s0.x, p0.x, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s0.y, p0.y, sad_acc);
+            sad_acc = __builtin_amdgcn_sad_u8(s0.z, p0.z, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s0.w, p0.w, sad_acc);
+            sad_acc = __builtin_amdgcn_sad_u8(s1.x, p1.x, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s1.y, p1.y, sad_acc);
+            sad_acc = __builtin_amdgcn_sad_u8(s1.z, p1.z, sad_acc); sad_acc = __builtin_amdgcn_sad_u8(s1.w, p1.w, sad_acc);
+        }
+        // residual as packed int16 pairs -> LDS -> columns (layout: see fwd32_kernel)
         const uint32_t sw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
         const uint32_t pw[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
 #pragma unroll
@@ -492,6 +498,34 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
         for (int r = 0; r < 32; r++) {
             const short v = *reinterpret_cast<const short*>(colbase + (r >> 4) * 1088 + (r & 15) * 32);
             x[r] = (int)v;                                       // shift[0] = 2 already applied
+        }
+    } else {
+        // ---- 2 x 2 KB: chunk k (0..3) of lane li = row k*8 + li/4, columns (li&3)*8 .. +7 (fwd32_kernel, IN = 2)
+        uint4 sv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            sv[k] = make_uint4(0, 0, 0, 0); pk[k] = sv[k];
+            if (valid) {
+                __builtin_memcpy(&sv[k], src + sbase + (size_t)(k * 8 + (li >> 2)) * sstr + (li & 3) * 8, 16);
+                __builtin_memcpy(&pk[k], pred + pbase + (size_t)(k * 8 + (li >> 2)) * pstr + (li & 3) * 8, 16);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t a[4] = {sv[k].x, sv[k].y, sv[k].z, sv[k].w}, b[4] = {pk[k].x, pk[k].y, pk[k].z, pk[k].w};
+            uint32_t d[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                d[j] = pk_shl2_i16(pk_sub_i16(a[j], b[j]));      // |s - p| * 4 <= 4092 fits int16
+                if (WITH_SAD) sad_acc = __builtin_amdgcn_sad_u16(a[j], b[j], sad_acc);
+            }
+            *reinterpret_cast<uint4*>(tile + k * 512 + li * 16) = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            const short v = *reinterpret_cast<const short*>(tile + (r >> 3) * 512 + (r & 7) * 64 + li * 2);
+            x[r] = (int)v;
         }
     }
     // ---- forward: column pass, transpose, row pass, re-order to linear ------------------------
@@ -553,7 +587,13 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
         }
     }
     // ---- inverse (inv32_kernel<uint8_t, 8> from its tile-A stage on) ---------------------------
-    const int c_hi = svtgen::svt_vgpr(32767), c_lo = ~c_hi;       // bd = 8: every clamp range is 16-bit
+    // clamp ranges (av1_gen_inv_stage_range, :5404-5456): input bd+8, rows 16/18/20, column input max(bd+6,16), columns 16 (18 at bd 12)
+    constexpr int in_bits = BD + 8, row_bits = BD == 8 ? 16 : (BD == 10 ? 18 : 20);
+    constexpr int cin_bits = BD + 6 > 16 ? BD + 6 : 16, col_bits = BD == 12 ? 18 : 16;
+    const int c_hi = svtgen::svt_vgpr((1 << (cin_bits - 1)) - 1), c_lo = ~c_hi;
+    const int i_hi = in_bits == cin_bits ? c_hi : svtgen::svt_vgpr((1 << (in_bits - 1)) - 1), i_lo = ~i_hi;
+    const int r_hi = row_bits == in_bits ? i_hi : svtgen::svt_vgpr((1 << (row_bits - 1)) - 1), r_lo = ~r_hi;
+    const int o_hi = col_bits == cin_bits ? c_hi : svtgen::svt_vgpr((1 << (col_bits - 1)) - 1), o_lo = ~o_hi;
     const int a_w = (li >> 3) * 128 + (((li & 7) ^ (li >> 4)) << 4);
     const int a_r = li * 128 + (((li >> 1) & 7) << 4);
     const int b_w = li * 128 + ((li & 7) << 4);
@@ -564,10 +604,10 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         const int4 v = *reinterpret_cast<const int4*>(tile + (a_r ^ (s << 4)));
-        x[s * 4 + 0] = svtgen::svt_clamp(v.x, c_lo, c_hi); x[s * 4 + 1] = svtgen::svt_clamp(v.y, c_lo, c_hi);
-        x[s * 4 + 2] = svtgen::svt_clamp(v.z, c_lo, c_hi); x[s * 4 + 3] = svtgen::svt_clamp(v.w, c_lo, c_hi);
+        x[s * 4 + 0] = svtgen::svt_clamp(v.x, i_lo, i_hi); x[s * 4 + 1] = svtgen::svt_clamp(v.y, i_lo, i_hi);
+        x[s * 4 + 2] = svtgen::svt_clamp(v.z, i_lo, i_hi); x[s * 4 + 3] = svtgen::svt_clamp(v.w, i_lo, i_hi);
     }
-    if (is_idtx) svtgen::svt_iidentity32<12>(x, 0, 0); else svtgen::svt_idct32<12>(x, c_lo, c_hi);
+    if (is_idtx) svtgen::svt_iidentity32<12>(x, 0, 0); else svtgen::svt_idct32<12>(x, r_lo, r_hi);
     wave_lds_fence();
 #pragma unroll
     for (int s = 0; s < 8; s++)
@@ -579,37 +619,42 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
         const int v = *reinterpret_cast<const int*>(tile + (b_r ^ ((r & 7) << 4)) + r * 128);
         x[r] = svtgen::svt_clamp(v, c_lo, c_hi);
     }
-    if (is_idtx) svtgen::svt_iidentity32<12>(x, 0, 0); else svtgen::svt_idct32<12>(x, c_lo, c_hi);
+    if (is_idtx) svtgen::svt_iidentity32<12>(x, 0, 0); else svtgen::svt_idct32<12>(x, o_lo, o_hi);
     wave_lds_fence();
+    constexpr int PPL = 16 / (int)sizeof(PixT), SPL = PPL / 4, maxpix = (1 << BD) - 1;
 #pragma unroll
     for (int r = 0; r < 32; r++)
-        *reinterpret_cast<int*>(tile + (b_r ^ (((r >> 1) & 3) << 4)) + r * 128) = (x[r] + 8) >> 4;
+        *reinterpret_cast<int*>(tile + (b_r ^ (((r >> 1) & (SPL - 1)) << 4)) + r * 128) = (x[r] + 8) >> 4;
     wave_lds_fence();
     if (valid) {
-        const uint4 pk[2] = {p0, p1};
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int L = k * 32 + li;
-            const int g = (L >> 2) & 3;
-            int rv[16];
+        for (int k = 0; k < NPK; k++) {
+            const int L = k * 32 + li;                            // 16-B unit: pixels L*PPL .. +PPL-1 = the lane's prediction chunk k
+            const int g = ((L * SPL) >> 4) & (SPL - 1);
+            int rv[PPL];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int4 t = *reinterpret_cast<const int4*>(tile + L * 64 + ((j ^ g) << 4));
+            for (int j = 0; j < SPL; j++) {
+                const int4 t = *reinterpret_cast<const int4*>(tile + L * (SPL * 16) + ((j ^ g) << 4));
                 rv[4 * j] = t.x; rv[4 * j + 1] = t.y; rv[4 * j + 2] = t.z; rv[4 * j + 3] = t.w;
             }
             const uint32_t pw[4] = {pk[k].x, pk[k].y, pk[k].z, pk[k].w};
             uint32_t ow[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const uint32_t pe = pw[q] & 0x00ff00ffu, po = (pw[q] >> 8) & 0x00ff00ffu;
-                const uint32_t re = __builtin_amdgcn_perm((uint32_t)rv[4 * q + 2], (uint32_t)rv[4 * q + 0], 0x05040100u);
-                const uint32_t ro = __builtin_amdgcn_perm((uint32_t)rv[4 * q + 3], (uint32_t)rv[4 * q + 1], 0x05040100u);
-                const uint32_t ue = sat_pk_u8_i16(pk_add_i16(pe, re)), uo = sat_pk_u8_i16(pk_add_i16(po, ro));
-                ow[q] = __builtin_amdgcn_perm(uo, ue, 0x05010400u);
+                if constexpr (!HBD) {
+                    const uint32_t pe = pw[q] & 0x00ff00ffu, po = (pw[q] >> 8) & 0x00ff00ffu;
+                    const uint32_t re = __builtin_amdgcn_perm((uint32_t)rv[4 * q + 2], (uint32_t)rv[4 * q + 0], 0x05040100u);
+                    const uint32_t ro = __builtin_amdgcn_perm((uint32_t)rv[4 * q + 3], (uint32_t)rv[4 * q + 1], 0x05040100u);
+                    const uint32_t ue = sat_pk_u8_i16(pk_add_i16(pe, re)), uo = sat_pk_u8_i16(pk_add_i16(po, ro));
+                    ow[q] = __builtin_amdgcn_perm(uo, ue, 0x05010400u);
+                } else {
+                    const uint32_t rr = __builtin_amdgcn_perm((uint32_t)rv[2 * q + 1], (uint32_t)rv[2 * q + 0], 0x05040100u);
+                    ow[q] = pk_clamp_i16(pk_add_i16(pw[q], rr), maxpix);
+                }
             }
-            // chunk L = row L/2, columns (L&1)*16 .. +15
             const uint4 ov = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-            if (xy) __builtin_memcpy(recon + rbase + (size_t)(L >> 1) * rstr + (L & 1) * 16, &ov, 16);
+            const int p = L * PPL;                                // row p/32, column p%32
+            if (xy) __builtin_memcpy(recon + rbase + (size_t)(p >> 5) * rstr + (p & 31), &ov, 16);
             else reinterpret_cast<uint4*>(recon + pix_off)[L] = ov;
         }
     }

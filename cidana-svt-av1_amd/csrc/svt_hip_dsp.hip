@@ -502,18 +502,21 @@ extern "C" int svt_hip_fwd_quant_sad_batch(const uint8_t* d_src, const uint8_t* 
     return launch_status("fwd_quant_sad_32x32");
 }
 
-static int encode_recon_impl(const uint8_t* d_src, uint32_t src_stride, const uint8_t* d_pred, uint32_t pred_stride,
-                             uint8_t* d_recon, uint32_t recon_stride, const uint32_t* d_xy, size_t nblocks, int tx_size,
+static int encode_recon_impl(const void* d_src_v, uint32_t src_stride, const void* d_pred_v, uint32_t pred_stride,
+                             void* d_recon_v, uint32_t recon_stride, const uint32_t* d_xy, int is_16bit, int bd, size_t nblocks, int tx_size,
                              int tx_type, const int16_t* zbin, const int16_t* round, const int16_t* quant,
                              const int16_t* quant_shift, const int16_t* dequant, const int16_t* d_iscan,
                              int32_t* d_coeff, int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob,
                              uint32_t* d_sad, void* stream) {
     if (int rc = require_init()) return rc;
     if (nblocks == 0) return SVT_HIP_OK;
+    const uint8_t* d_src = (const uint8_t*)d_src_v; const uint8_t* d_pred = (const uint8_t*)d_pred_v; uint8_t* d_recon = (uint8_t*)d_recon_v;
     if (!d_src || !d_pred || !d_qcoeff || !d_eob || !d_recon || !d_iscan || !zbin || !round || !quant || !quant_shift || !dequant)
         return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
     if (!txfm_allowed(tx_size, tx_type)) return set_err(SVT_HIP_ERR_INVALID, "tx_size %d / tx_type %d not defined by the reference", tx_size, tx_type);
     if (d_recon == d_src || (!d_xy && d_recon == d_pred)) return set_err(SVT_HIP_ERR_INVALID, "d_recon must not alias d_src (or, for dense batches, d_pred)");
+    if ((is_16bit && bd != 10) || (!is_16bit && bd != 8)) return set_err(SVT_HIP_ERR_INVALID, "bit depth %d (%d-bit samples)", bd, is_16bit ? 16 : 8);
+    if (is_16bit && d_sad) return set_err(SVT_HIP_ERR_INVALID, "SAD is defined for 8-bit planes only (the reference searches on the 8-bit MSB plane)");
     if (nblocks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "nblocks too large");
     hipStream_t s = (hipStream_t)stream;
     if (tx_size == SVT_TX_32X32 && (tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX)) {
@@ -522,11 +525,12 @@ static int encode_recon_impl(const uint8_t* d_src, uint32_t src_stride, const ui
         for (int i = 0; i < 2; i++) ok = ok && qp.quant_shift[i] >= 0 && qp.dequant[i] >= 0 && qp.round[i] >= 0;
         if (ok && ((d_coeff != nullptr) == (d_dqcoeff != nullptr))) {
             const uint32_t grid = (uint32_t)((nblocks + 2 * F32_WAVES - 1) / (2 * F32_WAVES));
-#define ENC32(KEEP, SAD) hipLaunchKernelGGL((enc32_kernel<KEEP, SAD>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_src, d_pred, d_recon, \
-                                         d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks, \
-                                         d_xy, src_stride, pred_stride, recon_stride)
-            if (d_coeff) { if (d_sad) ENC32(true, true); else ENC32(true, false); }
-            else { if (d_sad) ENC32(false, true); else ENC32(false, false); }
+#define ENC32(T, B, KEEP, SAD) hipLaunchKernelGGL((enc32_kernel<T, B, KEEP, SAD>), dim3(grid), dim3(F32_WAVES * 64), 0, s, (const T*)d_src_v, \
+                                         (const T*)d_pred_v, (T*)d_recon_v, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp,          \
+                                         tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks, d_xy, src_stride, pred_stride, recon_stride)
+            if (is_16bit) { if (d_coeff) ENC32(uint16_t, 10, true, false); else ENC32(uint16_t, 10, false, false); }
+            else if (d_coeff) { if (d_sad) ENC32(uint8_t, 8, true, true); else ENC32(uint8_t, 8, true, false); }
+            else { if (d_sad) ENC32(uint8_t, 8, false, true); else ENC32(uint8_t, 8, false, false); }
 #undef ENC32
             return launch_status("encode_recon_32x32");
         }
@@ -534,7 +538,7 @@ static int encode_recon_impl(const uint8_t* d_src, uint32_t src_stride, const ui
     {   // every other size: the staged fused kernel (dense 8-bit batches, power-of-two quant_shift tables)
         const int pels = kTxW[tx_size] * kTxH[tx_size];
         const QParams qp = make_qparams(zbin, round, quant, quant_shift, dequant, pels > 1024 ? 2 : (pels > 256 ? 1 : 0));
-        bool ok = qp.fast_ok && pels > 16 && !g_tune_no_enc_staged && ((d_coeff != nullptr) == (d_dqcoeff != nullptr));
+        bool ok = qp.fast_ok && pels > 16 && !is_16bit && !g_tune_no_enc_staged && ((d_coeff != nullptr) == (d_dqcoeff != nullptr));
         for (int i = 0; i < 2; i++) ok = ok && qp.quant_shift[i] >= 0 && qp.dequant[i] >= 0 && qp.round[i] >= 0;
         ok = ok && (((uintptr_t)d_qcoeff | (uintptr_t)d_coeff | (uintptr_t)d_dqcoeff) & 15) == 0;
         ok = ok && (d_xy || (((uintptr_t)d_src | (uintptr_t)d_pred | (uintptr_t)d_recon) & 15) == 0);
@@ -546,7 +550,7 @@ static int encode_recon_impl(const uint8_t* d_src, uint32_t src_stride, const ui
     }
     // composed path: the two batched stages around a device copy of the prediction
     if (!d_coeff || !d_dqcoeff) return set_err(SVT_HIP_ERR_INVALID, "this size/type/quantizer needs d_coeff and d_dqcoeff");
-    if (d_xy) return set_err(SVT_HIP_ERR_INVALID, "plane-addressed encode_recon needs a fused kernel (not 4x4, power-of-two quant_shift, 16-B aligned coefficient buffers); use svt_hip_fwd_quant_planes_batch + svt_hip_inv_txfm2d_add_batch");
+    if (d_xy || is_16bit) return set_err(SVT_HIP_ERR_INVALID, "no fused kernel for this case (4x4, 16-bit samples other than 32x32, non-power-of-two quant_shift or misaligned coefficient buffers); use svt_hip_fwd_quant_planes_batch + svt_hip_inv_txfm2d_add_batch");
     if (int rc = svt_hip_fwd_quant_sad_batch(d_src, d_pred, nblocks, tx_size, tx_type, zbin, round, quant, quant_shift, dequant,
                                              d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, stream)) return rc;
     const size_t pels = (size_t)kTxW[tx_size] * kTxH[tx_size];
@@ -559,18 +563,18 @@ extern "C" int svt_hip_encode_recon_batch(const uint8_t* d_src, const uint8_t* d
                                           const int16_t* quant_shift, const int16_t* dequant, const int16_t* d_iscan,
                                           int32_t* d_coeff, int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob,
                                           uint32_t* d_sad, uint8_t* d_recon, void* stream) {
-    return encode_recon_impl(d_src, 0, d_pred, 0, d_recon, 0, nullptr, nblocks, tx_size, tx_type, zbin, round, quant, quant_shift,
+    return encode_recon_impl(d_src, 0, d_pred, 0, d_recon, 0, nullptr, 0, 8, nblocks, tx_size, tx_type, zbin, round, quant, quant_shift,
                              dequant, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, stream);
 }
-extern "C" int svt_hip_encode_recon_planes_batch(const uint8_t* d_src, uint32_t src_stride, const uint8_t* d_pred,
-                                                 uint32_t pred_stride, uint8_t* d_recon, uint32_t recon_stride,
-                                                 const uint32_t* d_xy, size_t nblocks, int tx_size, int tx_type,
+extern "C" int svt_hip_encode_recon_planes_batch(const void* d_src, uint32_t src_stride, const void* d_pred,
+                                                 uint32_t pred_stride, void* d_recon, uint32_t recon_stride,
+                                                 const uint32_t* d_xy, size_t nblocks, int is_16bit, int bd, int tx_size, int tx_type,
                                                  const int16_t* zbin, const int16_t* round, const int16_t* quant,
                                                  const int16_t* quant_shift, const int16_t* dequant, const int16_t* d_iscan,
                                                  int32_t* d_coeff, int32_t* d_qcoeff, int32_t* d_dqcoeff, uint16_t* d_eob,
                                                  uint32_t* d_sad, void* stream) {
     if (nblocks && !d_xy) { if (int rc = require_init()) return rc; return set_err(SVT_HIP_ERR_INVALID, "NULL origin table"); }
-    return encode_recon_impl(d_src, src_stride, d_pred, pred_stride, d_recon, recon_stride, d_xy, nblocks, tx_size, tx_type, zbin,
+    return encode_recon_impl(d_src, src_stride, d_pred, pred_stride, d_recon, recon_stride, d_xy, is_16bit, bd, nblocks, tx_size, tx_type, zbin,
                              round, quant, quant_shift, dequant, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, stream);
 }
 

@@ -139,3 +139,40 @@ def test_encode_recon_on_planes(dsp, tx_size, tx_type, inplace):
     for i, (y, x) in enumerate([(y, x) for y in ys for x in xs]):
         expect[y:y + h, x:x + w] = rrec[i]
     assert np.array_equal(rec, expect)
+
+
+@pytest.mark.parametrize("tx_type", [0, 9])
+@pytest.mark.parametrize("inplace", [False, True])
+def test_encode_recon_on_planes_10bit_32x32(dsp, tx_type, inplace):
+    """BASELINE configs[4] shape: the fused chain on 10-bit planes (uint16 samples), 32x32 blocks."""
+    import ctypes
+    O = svtlibs.oracle()
+    tx_size, w, h = 3, 32, 32
+    rng = np.random.default_rng(1010 + tx_type)
+    PH, PW = 136, 200
+    src = rng.integers(0, 1024, size=(PH, PW)).astype(np.uint16)
+    pred = np.clip(src.astype(int) + rng.integers(-30, 31, size=src.shape), 0, 1023).astype(np.uint16)
+    src[0:40, 0:40] = 1023; pred[0:40, 0:40] = 0                   # an extreme block
+    xs = np.arange(5, PW - w + 1, w); ys = np.arange(2, PH - h + 1, h)
+    xy = np.array([(y << 16) | x for y in ys for x in xs], np.uint32)
+    qt = svtlibs.quant_tables(10)
+    qrow = {k: v[120].copy() for k, v in qt.items()}
+    _, iscan = svtlibs.scan_tables(tx_size, tx_type)
+    d_pred = dev(pred.view(np.int16))
+    d_recon = d_pred if inplace else torch.full_like(d_pred, 9)
+    out = dsp.encode_recon_planes(dev(src.view(np.int16)), PW, d_pred, PW, d_recon, PW, dev(xy.view(np.int32)), tx_size, tx_type, qrow,
+                                  dev(iscan), keep_coeff=True, bd=10)
+    torch.cuda.synchronize()
+    rec = d_recon.cpu().numpy().view(np.uint16)
+    expect = pred.copy() if inplace else np.full_like(pred, 9)
+    for i, (y, x) in enumerate([(y, x) for y in ys for x in xs]):
+        rc = np.zeros(1024, np.int32); rq = np.zeros(1024, np.int32); rdq = np.zeros(1024, np.int32); reob = np.zeros(1, np.uint16)
+        sp = ctypes.c_void_p(int(src.ctypes.data) + int(y * PW + x) * 2); pp = ctypes.c_void_p(int(pred.ctypes.data) + int(y * PW + x) * 2)
+        O.svt_oracle_fwd_quant_planes(sp, PW, pp, PW, 1, 10, tx_size, tx_type, ptr(qrow["zbin"]), ptr(qrow["round"]), ptr(qrow["quant"]),
+                                      ptr(qrow["quant_shift"]), ptr(qrow["dequant"]), ptr(rc), ptr(rq), ptr(rdq), ptr(reob), None, None)
+        blk = np.ascontiguousarray(pred[y:y + h, x:x + w])
+        O.svt_oracle_inv_txfm2d_add(ptr(rdq), ptr(blk), w, tx_type, tx_size, 10)
+        expect[y:y + h, x:x + w] = blk
+        assert np.array_equal(out["qcoeff"][i].cpu().numpy(), rq) and np.array_equal(out["coeff"][i].cpu().numpy(), rc), i
+        assert np.array_equal(out["dqcoeff"][i].cpu().numpy(), rdq) and int(out["eob"][i].cpu().numpy().view(np.uint16)) == int(reob[0]), i
+    assert np.array_equal(rec, expect)
