@@ -412,9 +412,9 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
 // chunks loaded for the residual stay in registers and are the destination of the reconstruction.
 // HBM traffic: 2*W*H in + 4*KW*KH (qcoeff) + W*H (recon) + 6 B out (+ coeff, dqcoeff when KEEP).
 // ---------------------------------------------------------------------------
-template <int W, int H, bool KEEP>
+template <int W, int H, bool KEEP, typename PixT = uint8_t, int BD = 8>
 __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
-    const uint8_t* __restrict__ src, const uint8_t* __restrict__ pred, uint8_t* __restrict__ recon,
+    const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
     int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
     uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
     int tx_type, uint32_t nblocks, const uint32_t* __restrict__ xy = nullptr, uint32_t src_stride = 0,
@@ -424,13 +424,16 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
     using S = StagedGeom<W, H>;
     using G = TxGeom<W, H>;
     constexpr int KW = S::KW, KH = S::KH, NC = S::NC;
-    constexpr int BB = W * H;                            // input bytes per block and array
-    constexpr int PADI = (W >= 32) ? 32 : 16;
+    constexpr int ES = (int)sizeof(PixT);                // 1, or 2 for 10-bit samples (BD = 10)
+    constexpr int BB = W * H * ES;                       // input bytes per block and array
+    constexpr int PADI = (W * ES >= 32) ? 32 : 16;
     constexpr int IN_ONE = G::BPW * (BB + PADI);
     constexpr int PQ = (KW == 4) ? 3 : KW / 4 + 1;
     constexpr int WAVE_LDS = (cmax(cmax(cmax(IN_ONE * 2, G::BPW * G::TILE * 4), G::BPW * W * H * 4), G::BPW * KH * PQ * 16) + 15) & ~15;
     __shared__ __attribute__((aligned(16))) char lds[S::WAVES * WAVE_LDS];
     static_assert(W * H % 16 == 0, "block must be a whole number of 16-B chunks");
+    constexpr int in_bits = BD + 8, row_bits = BD == 8 ? 16 : (BD == 10 ? 18 : 20);      // av1_gen_inv_stage_range (:5404-5456)
+    constexpr int cin_bits = BD + 6 > 16 ? BD + 6 : 16, col_bits = BD == 12 ? 18 : 16, maxpix = (1 << BD) - 1;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     char* wl = lds + wave * WAVE_LDS;
@@ -447,7 +450,8 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
     // ---- stage the wave's input: linear 16-B chunks; the prediction chunks stay in registers ----
     constexpr int NCH = G::BPW * BB / 16, NCHI = (NCH + 63) / 64;
     // plane mode: chunks of CS bytes that never cross a block row (same linear LDS image)
-    constexpr int CS = W >= 16 ? 16 : W, CPR = W / CS, CPBP = BB / CS, NCHP = G::BPW * CPBP, NIT = (NCHP + 63) / 64;
+    constexpr int ROWB = W * ES, CS = ROWB >= 16 ? 16 : ROWB, PPC = CS / ES;
+    constexpr int CPR = ROWB / CS, CPBP = BB / CS, NCHP = G::BPW * CPBP, NIT = (NCHP + 63) / 64;
     uint4 pk[NIT > NCHI ? NIT : NCHI];
     uint32_t org[NIT];
     if (xy) {
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
             const int q = it * 64 + lane, w = q % CPBP;
             v0[it] = make_uint4(0, 0, 0, 0); pk[it] = v0[it];
             if (org[it] != 0xffffffffu) {
-                const size_t y = (org[it] >> 16) + w / CPR, x = (org[it] & 0xffffu) + (w % CPR) * CS;
+                const size_t y = (org[it] >> 16) + w / CPR, x = (org[it] & 0xffffu) + (w % CPR) * PPC;
                 __builtin_memcpy(&v0[it], src + y * src_stride + x, CS);
                 __builtin_memcpy(&pk[it], pred + y * pred_stride + x, CS);
             }
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
 #pragma unroll
             for (int r = 0; r < H; r++) {
                 const int idx = (ud ? H - 1 - r : r) * W + l;
-                const int d = (int)*reinterpret_cast<const uint8_t*>(bs + idx) - (int)*reinterpret_cast<const uint8_t*>(bs + IN_ONE + idx);
+                const int d = (int)*reinterpret_cast<const PixT*>(bs + idx * ES) - (int)*reinterpret_cast<const PixT*>(bs + IN_ONE + idx * ES);
                 sad_acc += (unsigned)(d < 0 ? -d : d);
                 x[r] = round_shift_c<-S0>(d);
             }
@@ -607,9 +611,9 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
                 for (int c = 0; c < W; c++) {
                     int v = c < KW ? x[c] : 0;
                     if (G::RECT2) v = mul_q12(v, 2896);
-                    x[c] = svtgen::svt_clamp(v, -(1 << 15), (1 << 15) - 1);
+                    x[c] = svtgen::svt_clamp(v, -(1 << (in_bits - 1)), (1 << (in_bits - 1)) - 1);
                 }
-                inv1d<W>(hk, x, -(1 << 15), (1 << 15) - 1);
+                inv1d<W>(hk, x, -(1 << (row_bits - 1)), (1 << (row_bits - 1)) - 1);
             } else {
 #pragma unroll
                 for (int c = 0; c < W; c++) x[c] = 0;
@@ -629,8 +633,8 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
         if (l < W) {
             const int csrc = lr ? W - 1 - l : l;
 #pragma unroll
-            for (int r = 0; r < H; r++) y[r] = svtgen::svt_clamp(tile[r * G::PITCH + csrc], -(1 << 15), (1 << 15) - 1);
-            inv1d<H>(vk, y, -(1 << 15), (1 << 15) - 1);
+            for (int r = 0; r < H; r++) y[r] = svtgen::svt_clamp(tile[r * G::PITCH + csrc], -(1 << (cin_bits - 1)), (1 << (cin_bits - 1)) - 1);
+            inv1d<H>(vk, y, -(1 << (col_bits - 1)), (1 << (col_bits - 1)) - 1);
         }
         wave_lds_fence();
         if (l < W) {
@@ -642,7 +646,6 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
     wave_lds_fence();
     // ---- reconstruction = prediction (still in registers) + residual ---------------------------------
     if (xy) {
-        constexpr int PPC = CS;
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int q = it * 64 + lane, w = q % CPBP;
@@ -652,30 +655,42 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
                 uint32_t ow[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int k = 0; k < CS / 4; k++) {
-                    const uint32_t p01 = __builtin_amdgcn_perm(0u, pw[k], 0x0c010c00u), p23 = __builtin_amdgcn_perm(0u, pw[k], 0x0c030c02u);
-                    const uint32_t u01 = sat_pk_u8_i16(pk_add_i16(p01, rs[2 * k])), u23 = sat_pk_u8_i16(pk_add_i16(p23, rs[2 * k + 1]));
-                    ow[k] = (u23 << 16) | (u01 & 0xffffu);
+                    if constexpr (ES == 1) {
+                        const uint32_t p01 = __builtin_amdgcn_perm(0u, pw[k], 0x0c010c00u), p23 = __builtin_amdgcn_perm(0u, pw[k], 0x0c030c02u);
+                        const uint32_t u01 = sat_pk_u8_i16(pk_add_i16(p01, rs[2 * k])), u23 = sat_pk_u8_i16(pk_add_i16(p23, rs[2 * k + 1]));
+                        ow[k] = (u23 << 16) | (u01 & 0xffffu);
+                    } else {
+                        ow[k] = pk_clamp_i16(pk_add_i16(pw[k], rs[k]), maxpix);
+                    }
                 }
-                const size_t y = (org[it] >> 16) + w / CPR, x = (org[it] & 0xffffu) + (w % CPR) * CS;
+                const size_t y = (org[it] >> 16) + w / CPR, x = (org[it] & 0xffffu) + (w % CPR) * PPC;
                 __builtin_memcpy(recon + y * recon_stride + x, ow, CS);
             }
         }
     } else {
-        uint4* d4 = reinterpret_cast<uint4*>(recon + (size_t)first * BB);
+        uint4* d4 = reinterpret_cast<uint4*>(reinterpret_cast<char*>(recon) + (size_t)first * BB);
+        constexpr int PP16 = 16 / ES;                     // pixels per 16-B chunk
 #pragma unroll
         for (int it = 0; it < NCHI; it++) {
             const int q = it * 64 + lane;
             if ((NCH % 64 == 0 || q < NCH) && (first + (q * 16) / BB < nblocks)) {
-                const uint4* rs4 = reinterpret_cast<const uint4*>(reinterpret_cast<const short*>(wl) + (size_t)q * 16);
-                const uint4 ra = rs4[0], rb = rs4[1];
-                const uint32_t rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                const uint4* rs4 = reinterpret_cast<const uint4*>(reinterpret_cast<const short*>(wl) + (size_t)q * PP16);
                 const uint32_t pw[4] = {pk[it].x, pk[it].y, pk[it].z, pk[it].w};
                 uint32_t ow[4];
+                if constexpr (ES == 1) {
+                    const uint4 ra = rs4[0], rb = rs4[1];
+                    const uint32_t rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t p01 = __builtin_amdgcn_perm(0u, pw[k], 0x0c010c00u), p23 = __builtin_amdgcn_perm(0u, pw[k], 0x0c030c02u);
-                    const uint32_t u01 = sat_pk_u8_i16(pk_add_i16(p01, rw[2 * k])), u23 = sat_pk_u8_i16(pk_add_i16(p23, rw[2 * k + 1]));
-                    ow[k] = (u23 << 16) | (u01 & 0xffffu);
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t p01 = __builtin_amdgcn_perm(0u, pw[k], 0x0c010c00u), p23 = __builtin_amdgcn_perm(0u, pw[k], 0x0c030c02u);
+                        const uint32_t u01 = sat_pk_u8_i16(pk_add_i16(p01, rw[2 * k])), u23 = sat_pk_u8_i16(pk_add_i16(p23, rw[2 * k + 1]));
+                        ow[k] = (u23 << 16) | (u01 & 0xffffu);
+                    }
+                } else {
+                    const uint4 ra = rs4[0];
+                    const uint32_t rw[4] = {ra.x, ra.y, ra.z, ra.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) ow[k] = pk_clamp_i16(pk_add_i16(pw[k], rw[k]), maxpix);
                 }
                 d4[q] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             }

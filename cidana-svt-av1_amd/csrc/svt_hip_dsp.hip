@@ -169,14 +169,17 @@ int launch_fq_staged(const void* src, const void* pred, int is16, const uint32_t
     return launch_status("fwd_quant_staged");
 }
 template <int W, int H>
-int launch_enc_staged(const uint8_t* src, const uint8_t* pred, uint8_t* recon, int32_t* co, int32_t* q, int32_t* dq, uint16_t* eob,
+int launch_enc_staged(const void* src, const void* pred, void* recon, int is16, int32_t* co, int32_t* q, int32_t* dq, uint16_t* eob,
                       uint32_t* sad, const int16_t* iscan, const QParams& qp, int tx_type, size_t n, const uint32_t* xy, uint32_t ss,
                       uint32_t ps, uint32_t rs, hipStream_t s) {
     using SG = StagedGeom<W, H>;
     const uint32_t per_wg = SG::WAVES * TxGeom<W, H>::BPW;
     const dim3 grid((uint32_t)((n + per_wg - 1) / per_wg)), block(SG::WAVES * 64);
-    if (co) hipLaunchKernelGGL((enc_staged_kernel<W, H, true>), grid, block, 0, s, src, pred, recon, co, q, dq, eob, sad, iscan, qp, tx_type, (uint32_t)n, xy, ss, ps, rs);
-    else hipLaunchKernelGGL((enc_staged_kernel<W, H, false>), grid, block, 0, s, src, pred, recon, co, q, dq, eob, sad, iscan, qp, tx_type, (uint32_t)n, xy, ss, ps, rs);
+#define ENCL(KEEP, T, B) hipLaunchKernelGGL((enc_staged_kernel<W, H, KEEP, T, B>), grid, block, 0, s, (const T*)src, (const T*)pred, (T*)recon, co, q, dq, \
+                                          eob, sad, iscan, qp, tx_type, (uint32_t)n, xy, ss, ps, rs)
+    if (is16) { if (co) ENCL(true, uint16_t, 10); else ENCL(false, uint16_t, 10); }
+    else { if (co) ENCL(true, uint8_t, 8); else ENCL(false, uint8_t, 8); }
+#undef ENCL
     return launch_status("encode_recon_staged");
 }
 template <int W, int H>
@@ -538,19 +541,19 @@ static int encode_recon_impl(const void* d_src_v, uint32_t src_stride, const voi
     {   // every other size: the staged fused kernel (dense 8-bit batches, power-of-two quant_shift tables)
         const int pels = kTxW[tx_size] * kTxH[tx_size];
         const QParams qp = make_qparams(zbin, round, quant, quant_shift, dequant, pels > 1024 ? 2 : (pels > 256 ? 1 : 0));
-        bool ok = qp.fast_ok && pels > 16 && !is_16bit && !g_tune_no_enc_staged && ((d_coeff != nullptr) == (d_dqcoeff != nullptr));
+        bool ok = qp.fast_ok && pels > 16 && !g_tune_no_enc_staged && ((d_coeff != nullptr) == (d_dqcoeff != nullptr));
         for (int i = 0; i < 2; i++) ok = ok && qp.quant_shift[i] >= 0 && qp.dequant[i] >= 0 && qp.round[i] >= 0;
         ok = ok && (((uintptr_t)d_qcoeff | (uintptr_t)d_coeff | (uintptr_t)d_dqcoeff) & 15) == 0;
         ok = ok && (d_xy || (((uintptr_t)d_src | (uintptr_t)d_pred | (uintptr_t)d_recon) & 15) == 0);
         if (ok) {
-#define ENCS(W, H) launch_enc_staged<W, H>(d_src, d_pred, d_recon, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, tx_type, nblocks, d_xy, src_stride, pred_stride, recon_stride, s)
+#define ENCS(W, H) launch_enc_staged<W, H>(d_src_v, d_pred_v, d_recon_v, is_16bit, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, tx_type, nblocks, d_xy, src_stride, pred_stride, recon_stride, s)
             TX_SWITCH(tx_size, ENCS)
 #undef ENCS
         }
     }
     // composed path: the two batched stages around a device copy of the prediction
     if (!d_coeff || !d_dqcoeff) return set_err(SVT_HIP_ERR_INVALID, "this size/type/quantizer needs d_coeff and d_dqcoeff");
-    if (d_xy || is_16bit) return set_err(SVT_HIP_ERR_INVALID, "no fused kernel for this case (4x4, 16-bit samples other than 32x32, non-power-of-two quant_shift or misaligned coefficient buffers); use svt_hip_fwd_quant_planes_batch + svt_hip_inv_txfm2d_add_batch");
+    if (d_xy || is_16bit) return set_err(SVT_HIP_ERR_INVALID, "no fused kernel for this case (4x4, non-power-of-two quant_shift or misaligned coefficient buffers); use svt_hip_fwd_quant_planes_batch + svt_hip_inv_txfm2d_add_batch");
     if (int rc = svt_hip_fwd_quant_sad_batch(d_src, d_pred, nblocks, tx_size, tx_type, zbin, round, quant, quant_shift, dequant,
                                              d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, stream)) return rc;
     const size_t pels = (size_t)kTxW[tx_size] * kTxH[tx_size];

@@ -173,9 +173,9 @@ int svt_hip_encode_recon_batch(const uint8_t *d_src, const uint8_t *d_pred, size
  * d_xy[b] >> 16) of the source, prediction and reconstruction planes (row strides in samples); the
  * reconstruction may be written in place into the prediction plane (d_recon == d_pred with equal
  * strides), as the reference does after pic_copy_kernel (EbCodingLoop.c:741-753).  is_16bit / bd: uint8
- * samples (bd 8) or uint16 samples (bd 10; d_sad must be NULL).  Fused kernels only: 4x4 blocks,
- * 16-bit samples at sizes other than 32x32 and non-standard quantiser tables return
- * SVT_HIP_ERR_INVALID (use svt_hip_fwd_quant_planes_batch + svt_hip_inv_txfm2d_add_batch there). */
+ * samples (bd 8) or uint16 samples (bd 10; d_sad must be NULL).  Fused kernels only: 4x4 blocks and
+ * non-standard quantiser tables return SVT_HIP_ERR_INVALID (use svt_hip_fwd_quant_planes_batch +
+ * svt_hip_inv_txfm2d_add_batch there). */
 int svt_hip_encode_recon_planes_batch(const void *d_src, uint32_t src_stride, const void *d_pred,
                                       uint32_t pred_stride, void *d_recon, uint32_t recon_stride,
                                       const uint32_t *d_xy, size_t nblocks, int is_16bit, int bd,

@@ -141,14 +141,16 @@ def test_encode_recon_on_planes(dsp, tx_size, tx_type, inplace):
     assert np.array_equal(rec, expect)
 
 
-@pytest.mark.parametrize("tx_type", [0, 9])
+@pytest.mark.parametrize("tx_size,tx_type", [(3, 0), (3, 9), (2, 0), (2, 7), (1, 0), (4, 0), (9, 0), (8, 2), (5, 0), (13, 0), (18, 0)])
 @pytest.mark.parametrize("inplace", [False, True])
-def test_encode_recon_on_planes_10bit_32x32(dsp, tx_type, inplace):
-    """BASELINE configs[4] shape: the fused chain on 10-bit planes (uint16 samples), 32x32 blocks."""
+def test_encode_recon_on_planes_10bit(dsp, tx_size, tx_type, inplace):
+    """BASELINE configs[4] shape: the fused chain on 10-bit planes (uint16 samples), every fused size."""
     import ctypes
+    if not svtlibs.txfm_allowed(tx_size, tx_type):
+        pytest.skip("type not defined for this size")
     O = svtlibs.oracle()
-    tx_size, w, h = 3, 32, 32
-    rng = np.random.default_rng(1010 + tx_type)
+    w, h = TX_W[tx_size], TX_H[tx_size]
+    rng = np.random.default_rng(1010 + tx_type + 17 * tx_size)
     PH, PW = 136, 200
     src = rng.integers(0, 1024, size=(PH, PW)).astype(np.uint16)
     pred = np.clip(src.astype(int) + rng.integers(-30, 31, size=src.shape), 0, 1023).astype(np.uint16)
@@ -166,13 +168,14 @@ def test_encode_recon_on_planes_10bit_32x32(dsp, tx_type, inplace):
     rec = d_recon.cpu().numpy().view(np.uint16)
     expect = pred.copy() if inplace else np.full_like(pred, 9)
     for i, (y, x) in enumerate([(y, x) for y in ys for x in xs]):
-        rc = np.zeros(1024, np.int32); rq = np.zeros(1024, np.int32); rdq = np.zeros(1024, np.int32); reob = np.zeros(1, np.uint16)
+        nc = min(w, 32) * min(h, 32)
+        rc = np.zeros(w * h, np.int32); rq = np.zeros(w * h, np.int32); rdq = np.zeros(w * h, np.int32); reob = np.zeros(1, np.uint16)
         sp = ctypes.c_void_p(int(src.ctypes.data) + int(y * PW + x) * 2); pp = ctypes.c_void_p(int(pred.ctypes.data) + int(y * PW + x) * 2)
         O.svt_oracle_fwd_quant_planes(sp, PW, pp, PW, 1, 10, tx_size, tx_type, ptr(qrow["zbin"]), ptr(qrow["round"]), ptr(qrow["quant"]),
                                       ptr(qrow["quant_shift"]), ptr(qrow["dequant"]), ptr(rc), ptr(rq), ptr(rdq), ptr(reob), None, None)
         blk = np.ascontiguousarray(pred[y:y + h, x:x + w])
         O.svt_oracle_inv_txfm2d_add(ptr(rdq), ptr(blk), w, tx_type, tx_size, 10)
         expect[y:y + h, x:x + w] = blk
-        assert np.array_equal(out["qcoeff"][i].cpu().numpy(), rq) and np.array_equal(out["coeff"][i].cpu().numpy(), rc), i
-        assert np.array_equal(out["dqcoeff"][i].cpu().numpy(), rdq) and int(out["eob"][i].cpu().numpy().view(np.uint16)) == int(reob[0]), i
+        assert np.array_equal(out["qcoeff"][i].cpu().numpy(), rq[:nc]) and np.array_equal(out["coeff"][i].cpu().numpy(), rc[:nc]), i
+        assert np.array_equal(out["dqcoeff"][i].cpu().numpy(), rdq[:nc]) and int(out["eob"][i].cpu().numpy().view(np.uint16)) == int(reob[0]), i
     assert np.array_equal(rec, expect)

@@ -120,6 +120,10 @@ if want("gop"):
         ms = timeit(gop, iters=4)
         n = xy.numel()
         rec(f"gop16_1080p_bd10_planes_fwd+quant+inv_{S}x{S}", n, 18 * S * S, ms, {"ms_per_frame": round(ms / FR, 4), "Mpx_per_s": round(n * S * S / ms / 1e3, 1)})
+        recon2 = predp.clone()
+        ms = timeit(lambda: dsp.encode_recon_planes(srcp, PW, predp, PW, recon2, PW, xy, s, 0, qrow10, iscan, bd=10), iters=4)
+        rec(f"gop16_1080p_bd10_planes_encode_recon_fused_{S}x{S}", n, 10 * S * S, ms, {"ms_per_frame": round(ms / FR, 4), "Mpx_per_s": round(n * S * S / ms / 1e3, 1)})
+        del recon2
         del recon, xy, offs
     del srcp, predp
 # fused encode-pass chain (residual -> fwd -> quant/dequant -> inverse -> recon), 32x32
