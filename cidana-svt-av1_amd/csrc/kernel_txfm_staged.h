@@ -239,7 +239,9 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void fwd_staged_kernel(
 // ---------------------------------------------------------------------------
 // dst_offsets != NULL: destination block b starts at dst + dst_offsets[b] (samples) with row stride dst_stride
 // (reconstruction written in place into a picture plane); NULL: dense W*H blocks back to back.
-template <int W, int H, typename PixT>
+// TILE16 (bd <= 10: the column pass clamps its input to 16 bits anyway): the transpose tile holds the row-pass output
+// already clamped, as int16 - half the LDS, which is what limits the 64-point sizes to 2 waves per SIMD.
+template <int W, int H, typename PixT, bool TILE16 = false>
 __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
     const int32_t* __restrict__ in, PixT* __restrict__ dst, int tx_type, int bd, uint32_t nblocks,
     const uint32_t* __restrict__ dst_offsets = nullptr, int32_t dst_stride = 0) {
@@ -248,7 +250,8 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
     constexpr int KW = S::KW, KH = S::KH, NC = S::NC;
     constexpr int PQ = (KW == 4) ? 3 : KW / 4 + 1;       // row pitch of the coefficient tile in 16-B units (odd-ish: conflict-free b128 row reads)
     constexpr int IN_BYTES = G::BPW * KH * PQ * 16;
-    constexpr int TILE_BYTES = G::BPW * G::TILE * 4;
+    constexpr int P16 = W + 2;                           // int16 tile row pitch: (W+2)/2 is odd -> conflict-free row writes
+    constexpr int TILE_BYTES = TILE16 ? G::BPW * H * P16 * 2 : G::BPW * G::TILE * 4;
     constexpr int RES_BYTES = G::BPW * W * H * 2;
     constexpr int WAVE_LDS = (cmax(cmax(IN_BYTES, TILE_BYTES), RES_BYTES) + 15) & ~15;
     __shared__ __attribute__((aligned(16))) char lds[S::WAVES * WAVE_LDS];
@@ -302,18 +305,30 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
     }
     wave_lds_fence();
     int32_t* tile = reinterpret_cast<int32_t*>(wl) + sub * G::TILE;
+    short* tile16 = reinterpret_cast<short*>(wl) + sub * (H * P16);
     if (l < H) {
+        if (TILE16) {
+            const int lo16 = svtgen::svt_vgpr(-32768), hi16 = svtgen::svt_vgpr(32767);
 #pragma unroll
-        for (int c = 0; c < W; c++) tile[l * G::PITCH + c] = round_shift_c<-S0>(x[c]);
+            for (int c = 0; c < W; c++) tile16[l * P16 + c] = (short)svtgen::svt_clamp(round_shift_c<-S0>(x[c]), lo16, hi16);
+        } else {
+#pragma unroll
+            for (int c = 0; c < W; c++) tile[l * G::PITCH + c] = round_shift_c<-S0>(x[c]);
+        }
     }
     wave_lds_fence();
     // ---- column pass -------------------------------------------------------------------------
     int y[H];
     if (l < W) {
         const int csrc = lr ? W - 1 - l : l;
+        if (TILE16) {
 #pragma unroll
-        for (int r = 0; r < H; r++)
-            y[r] = svtgen::svt_clamp(tile[r * G::PITCH + csrc], -(1 << (colin_bits - 1)), (1 << (colin_bits - 1)) - 1);
+            for (int r = 0; r < H; r++) y[r] = tile16[r * P16 + csrc];          // already clamped to 16 bits (== colin range)
+        } else {
+#pragma unroll
+            for (int r = 0; r < H; r++)
+                y[r] = svtgen::svt_clamp(tile[r * G::PITCH + csrc], -(1 << (colin_bits - 1)), (1 << (colin_bits - 1)) - 1);
+        }
         inv1d<H>(vk, y, -(1 << (col_bits - 1)), (1 << (col_bits - 1)) - 1);
     }
     wave_lds_fence();
