@@ -188,10 +188,12 @@ int launch_inv_staged(const int32_t* in, void* dst, int is16, size_t n, int tx_t
     using SG = StagedGeom<W, H>;
     const uint32_t per_wg = SG::WAVES * TxGeom<W, H>::BPW;
     const uint32_t grid = (uint32_t)((n + per_wg - 1) / per_wg);
-    // bd <= 10: 16-bit transpose tile (the column input is clamped to 16 bits there anyway)
+    // 64-point sizes at bd <= 10: 16-bit transpose tile (the column input is clamped to 16 bits there anyway), which lifts
+    // their LDS-limited 2 waves per SIMD to 4; smaller sizes are not LDS-limited and sub-dword LDS writes are slower
+    constexpr bool T16 = W >= 64 || H >= 64;
     if (is16 && bd > 10) hipLaunchKernelGGL((inv_staged_kernel<W, H, uint16_t, false>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint16_t*)dst, tx_type, bd, (uint32_t)n, offs, stride);
-    else if (is16) hipLaunchKernelGGL((inv_staged_kernel<W, H, uint16_t, true>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint16_t*)dst, tx_type, bd, (uint32_t)n, offs, stride);
-    else hipLaunchKernelGGL((inv_staged_kernel<W, H, uint8_t, true>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint8_t*)dst, tx_type, bd, (uint32_t)n, offs, stride);
+    else if (is16) hipLaunchKernelGGL((inv_staged_kernel<W, H, uint16_t, T16>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint16_t*)dst, tx_type, bd, (uint32_t)n, offs, stride);
+    else hipLaunchKernelGGL((inv_staged_kernel<W, H, uint8_t, T16>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint8_t*)dst, tx_type, bd, (uint32_t)n, offs, stride);
     return launch_status("inv_staged");
 }
 template <int W, int H>
