@@ -76,6 +76,12 @@ if want("sad_search"):
     ms = timeit(lambda: dsp.sad_search(src, ref, 8, 8))
     rec("sad_search_16x16_64cand(C3)", n, 797, ms, {"abs_diff_per_s_T": round(n * 64 * 256 / ms / 1e9, 2)})
     del src, ref
+    # HME level 1 / 2 shapes: 32x32 and 64x64 blocks, 16x16 refinement area
+    for bs, n in ((32, 1 << 17), (64, 1 << 15)):
+        src = torch.randint(0, 256, (n, bs, bs), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, bs + 15, bs + 15), dtype=torch.uint8, device=dev)
+        ms = timeit(lambda: dsp.sad_search(src, ref, 16, 16))
+        rec(f"sad_search_{bs}x{bs}_256cand", n, bs * bs + (bs + 15) ** 2 + 12, ms, {"abs_diff_per_s_T": round(n * 256 * bs * bs / ms / 1e9, 2)})
+        del src, ref
 # plain sad / sse / residual 32x32
 if want("pixel"):
     n = 1 << 21
