@@ -1,0 +1,124 @@
+"""Every svt_hip_tune knob selects another kernel for the same job: results must not change.  This keeps the
+first-generation / general kernels (which the default routing now rarely reaches) under test."""
+import numpy as np
+import pytest
+import torch
+
+import svtlibs
+from test_gpu_parity import dev, make_pixels
+
+pytestmark = pytest.mark.gpu
+
+
+def _qrow(bd, q):
+    qt = svtlibs.quant_tables(bd)
+    return {k: v[q].copy() for k, v in qt.items()}
+
+
+def _tune(dsp, key, value):
+    assert dsp.lib.svt_hip_tune(key.encode(), int(value)) == 0
+
+
+def _eq(a, b):
+    if isinstance(a, dict):
+        return all(_eq(a[k], b[k]) for k in a)
+    if isinstance(a, (tuple, list)):
+        return all(_eq(x, y) for x, y in zip(a, b))
+    if a is None or b is None:
+        return a is b
+    return torch.equal(a, b)
+
+
+@pytest.mark.parametrize("knob", ["no_staged", "no_f32p"])
+@pytest.mark.parametrize("tx_size", [3, 2, 1, 4, 9])
+@pytest.mark.parametrize("bd", [8, 10])
+def test_fwd_quant_planes_variants(dsp, knob, tx_size, bd):
+    w, h = svtlibs.TX_W[tx_size], svtlibs.TX_H[tx_size]
+    rng = np.random.default_rng(tx_size * 10 + bd)
+    PH, PW = 3 * h + 5, 4 * w + 9
+    hi = 1 << bd
+    src = rng.integers(0, hi, size=(PH, PW)); pred = np.clip(src + rng.integers(-20, 21, size=src.shape), 0, hi - 1)
+    conv = (lambda a: dev(a.astype(np.uint8))) if bd == 8 else (lambda a: dev(a.astype(np.uint16).view(np.int16)))
+    xy = dev(np.array([(y << 16) | x for y in range(2, PH - h + 1, h) for x in range(5, PW - w + 1, w)], np.uint32).view(np.int32))
+    _, iscan = svtlibs.scan_tables(tx_size, 0)
+    call = lambda: dsp.fwd_quant_planes(conv(src), PW, conv(pred), PW, xy, tx_size, 0, _qrow(bd, 90), dev(iscan), bd=bd)
+    try:
+        _tune(dsp, knob, 0); a = call()
+        _tune(dsp, knob, 1); b = call()
+    finally:
+        _tune(dsp, knob, 0)
+    torch.cuda.synchronize()
+    assert _eq(a[:4], b[:4])
+
+
+@pytest.mark.parametrize("knob", ["no_enc_staged"])
+@pytest.mark.parametrize("tx_size", [1, 2, 4, 7])
+def test_encode_recon_variants(dsp, knob, tx_size):
+    rng = np.random.default_rng(5 + tx_size)
+    src, pred = make_pixels(rng, 19, svtlibs.TX_H[tx_size], svtlibs.TX_W[tx_size], "smooth")
+    _, iscan = svtlibs.scan_tables(tx_size, 0)
+    call = lambda: dsp.encode_recon(dev(src), dev(pred), tx_size, 0, _qrow(8, 70), dev(iscan), keep_coeff=True)
+    try:
+        _tune(dsp, knob, 0); a = call()
+        _tune(dsp, knob, 1); b = call()          # composed two-kernel path
+    finally:
+        _tune(dsp, knob, 0)
+    torch.cuda.synchronize()
+    assert _eq(a, b)
+
+
+@pytest.mark.parametrize("knob", ["no_inv_planes", "no_staged"])
+@pytest.mark.parametrize("tx_size,bd", [(2, 8), (1, 8), (4, 8), (11, 8), (2, 10), (4, 10)])
+def test_inverse_on_planes_variants(dsp, knob, tx_size, bd):
+    w, h = svtlibs.TX_W[tx_size], svtlibs.TX_H[tx_size]
+    kw, kh = min(w, 32), min(h, 32)
+    rng = np.random.default_rng(tx_size + bd)
+    PH, PW = 2 * h + 3, 3 * w + 4
+    offs = np.array([y * PW + x for y in range(1, PH - h + 1, h) for x in range(2, PW - w + 1, w)], np.uint32)
+    co = dev(rng.integers(-900, 901, size=(len(offs), kw * kh)).astype(np.int32))
+    plane = rng.integers(0, 1 << bd, size=(PH, PW))
+    mk = (lambda: dev(plane.astype(np.uint8))) if bd == 8 else (lambda: dev(plane.astype(np.uint16).view(np.int16)))
+    outs = []
+    try:
+        for v in (0, 1):
+            _tune(dsp, knob, v)
+            d = mk()
+            dsp.inv_txfm2d_add(co, d, tx_size, 0, bd, dst_stride=PW, dst_block_pitch=0, offsets=dev(offs.view(np.int32)))
+            outs.append(d)
+    finally:
+        _tune(dsp, knob, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("knob,bw,sw,sh", [("no_q2", 16, 8, 8), ("no_q2", 8, 13, 5), ("no_qsad", 16, 8, 8), ("no_qsad", 32, 9, 6)])
+def test_sad_search_variants(dsp, knob, bw, sw, sh):
+    rng = np.random.default_rng(bw + sw)
+    n = 37
+    src = rng.integers(0, 256, size=(n, bw, bw), dtype=np.uint8)
+    ref = rng.integers(0, 256, size=(n, bw + sh - 1, bw + sw - 1), dtype=np.uint8)
+    ref[0] = 3; src[0] = 4                                   # ties everywhere
+    try:
+        _tune(dsp, knob, 0); a = dsp.sad_search(dev(src), dev(ref), sw, sh)
+        _tune(dsp, knob, 1); b = dsp.sad_search(dev(src), dev(ref), sw, sh)
+    finally:
+        _tune(dsp, knob, 0)
+    torch.cuda.synchronize()
+    assert _eq(a, b)
+
+
+@pytest.mark.parametrize("sw,sh", [(64, 64), (16, 5), (48, 16)])
+def test_me_sb_search_variants(dsp, sw, sh):
+    rng = np.random.default_rng(sw + sh)
+    n = 6
+    src = rng.integers(0, 256, size=(n, 64, 64), dtype=np.uint8)
+    ref = rng.integers(0, 256, size=(n, 64 + sh - 1, 64 + sw - 1 + 2), dtype=np.uint8)
+    ref[0] = 9; src[0] = 7
+    ref[1] = 255; src[1] = 0
+    try:
+        _tune(dsp, "no_me16", 0); a = dsp.me_sb_search(dev(src), dev(ref), sw, sh)
+        _tune(dsp, "no_me16", 1); b = dsp.me_sb_search(dev(src), dev(ref), sw, sh)
+    finally:
+        _tune(dsp, "no_me16", 0)
+    torch.cuda.synchronize()
+    assert _eq(a, b)
