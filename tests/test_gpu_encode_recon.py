@@ -179,3 +179,24 @@ def test_encode_recon_on_planes_10bit(dsp, tx_size, tx_type, inplace):
         assert np.array_equal(out["qcoeff"][i].cpu().numpy(), rq[:nc]) and np.array_equal(out["coeff"][i].cpu().numpy(), rc[:nc]), i
         assert np.array_equal(out["dqcoeff"][i].cpu().numpy(), rdq[:nc]) and int(out["eob"][i].cpu().numpy().view(np.uint16)) == int(reob[0]), i
     assert np.array_equal(rec, expect)
+
+
+@pytest.mark.parametrize("tx_size,n", [(1, 100003), (2, 50021), (4, 4099), (9, 20011), (16, 30011)])
+def test_fused_chain_equals_two_kernel_path_at_scale(dsp, tx_size, n):
+    """Size-independent property at batch sizes that are not multiples of any tile: the fused chain and the two
+    separate kernels (each bit-exact against the oracle on small cases) must agree on every block."""
+    w, h = TX_W[tx_size], TX_H[tx_size]
+    g = torch.Generator(device="cuda:0"); g.manual_seed(n)
+    src = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device="cuda:0", generator=g)
+    pred = (src.to(torch.int16) + torch.randint(-25, 26, (n, h, w), dtype=torch.int16, device="cuda:0", generator=g)).clamp(0, 255).to(torch.uint8)
+    qt = svtlibs.quant_tables(8)
+    qrow = {k: v[55].copy() for k, v in qt.items()}
+    _, iscan = svtlibs.scan_tables(tx_size, 0)
+    isc = dev(iscan)
+    a = dsp.encode_recon(src, pred, tx_size, 0, qrow, isc, keep_coeff=True)
+    co, q, dq, eob, sad = dsp.fwd_quant_sad(src, pred, tx_size, 0, qrow, isc)
+    rec2 = pred.clone()
+    dsp.inv_txfm2d_add(dq, rec2, tx_size, 0, 8)
+    torch.cuda.synchronize()
+    assert torch.equal(a["recon"], rec2) and torch.equal(a["qcoeff"], q) and torch.equal(a["coeff"], co)
+    assert torch.equal(a["dqcoeff"], dq) and torch.equal(a["eob"], eob) and torch.equal(a["sad"], sad)
