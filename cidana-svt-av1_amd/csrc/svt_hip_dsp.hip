@@ -495,7 +495,9 @@ extern "C" int svt_hip_fwd_quant_sad_batch(const uint8_t* d_src, const uint8_t* 
                        (const void*)d_src, d_pred, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp,           \
                        tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks)
     const bool fastq = qp.fast_ok && !g_tune_f32_qmode1;
-    if (g_tune_f32_nt) {
+    if (g_tune_f32_nt && fastq) {
+        if (d_sad) F32_LAUNCH_Q(true, 1, true, 2); else F32_LAUNCH_Q(false, 1, true, 2);
+    } else if (g_tune_f32_nt) {
         if (d_sad) F32_LAUNCH_Q(true, 1, true, 1); else F32_LAUNCH_Q(false, 1, true, 1);
     } else if (!fastq) {
         if (d_sad) F32_LAUNCH_Q(true, 1, false, 1); else F32_LAUNCH_Q(false, 1, false, 1);
