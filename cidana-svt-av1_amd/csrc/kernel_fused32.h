@@ -173,7 +173,8 @@ __global__ __launch_bounds__(F32_WAVES * 64, MIN_WAVES_PER_SIMD) void fwd32_kern
                 const uint4* r4 = reinterpret_cast<const uint4*>(res + pix_off);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint4 v = valid ? r4[k * 32 + li] : make_uint4(0, 0, 0, 0);
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (valid) v = r4[k * 32 + li];
                     *reinterpret_cast<uint4*>(tile + k * 512 + li * 16) = v;
                 }
             }

@@ -46,21 +46,23 @@ constexpr int NB_ORIGIN = 16;
 // paths structurally different stops the compiler from "hoisting common stores" out of them, which
 // had turned the aligned 16-B store into byte + short + dwordx3 + byte stores (half the bandwidth).
 template <typename PixT>
-__device__ __forceinline__ void intra_store(PixT* d, const PixT (&out)[16 / sizeof(PixT)], int ppl) {
-    uint4 v;
-    __builtin_memcpy(&v, out, 16);
+__device__ __forceinline__ void intra_store(PixT* d, const uint4 v, int ppl) {
     const int nbytes = ppl * (int)sizeof(PixT);
     const uintptr_t a = reinterpret_cast<uintptr_t>(d);
     if (nbytes == 16 && (a & 15) == 0) {
         *reinterpret_cast<uint4*>(d) = v;
     } else if ((a & 3) == 0) {                       // nbytes is 4, 8 or 16
+        // (static register indexing + predicates: a runtime-indexed copy of `v` would live in scratch memory,
+        // i.e. one extra 16-B scratch store per lane even when this path is not taken - measured as 1.6x WRITE_SIZE)
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t* d4 = reinterpret_cast<uint32_t*>(d);
-        for (int q = 0; q < (nbytes >> 2); q++) d4[q] = w[q];
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (q < (nbytes >> 2)) d4[q] = w[q];
     } else {
-        const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint8_t* d1 = reinterpret_cast<uint8_t*>(d);
-        for (int q = 0; q < nbytes; q++) d1[q] = b[q];
+#pragma unroll
+        for (int q = 0; q < 16; q++) if (q < nbytes) d1[q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
     }
 }
 
@@ -68,8 +70,9 @@ __device__ const uint32_t kZeroWord[1] = {0};     // stand-in offset table (keep
 
 template <typename PixT>
 struct IntraNb {                       // what one lane needs from a block's neighbours
-    PixT ab[16 / sizeof(PixT)];        // above[c0 .. c0+ppl-1]
-    uint8_t ww[16 / sizeof(PixT)];     // smooth weights of those columns
+    uint4 abv;                         // above[c0 .. c0+ppl-1], packed as loaded (kept as registers: a byte array here
+                                       // makes the compiler split the 16-B load into eight 2-B loads)
+    uint4 wwv;                         // smooth weights (bytes) of those columns
     int lft, bl, tr, tl, sum;
 };
 
@@ -81,19 +84,27 @@ template <typename PixT, int MODE, bool WIDE>
 __device__ __forceinline__ void intra_load(IntraNb<PixT>& nb, const PixT* __restrict__ above, const PixT* __restrict__ left,
                                            int r, int c0, int ppl, int bw, int bh, int lj, int grp) {
     constexpr int PXL = 16 / (int)sizeof(PixT);
+    typedef unsigned svt_v4u_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+    nb.abv = make_uint4(0, 0, 0, 0); nb.wwv = nb.abv;
     if (MODE == IM_V || MODE == IM_SMOOTH || MODE == IM_SMOOTH_V || MODE == IM_PAETH) {
-        if (WIDE) __builtin_memcpy(nb.ab, above + c0, 16);
-        else {
+        if (WIDE) {
+            const svt_v4u_unaligned t = *reinterpret_cast<const svt_v4u_unaligned*>(above + c0);     // one unaligned 16-B load
+            nb.abv = make_uint4(t.x, t.y, t.z, t.w);
+        } else {
+            PixT tmp[PXL];
 #pragma unroll
-            for (int k = 0; k < PXL; k++) nb.ab[k] = k < ppl ? above[c0 + k] : (PixT)0;
+            for (int k = 0; k < PXL; k++) tmp[k] = k < ppl ? above[c0 + k] : (PixT)0;
+            __builtin_memcpy(&nb.abv, tmp, 16);
         }
     }
     if (MODE == IM_SMOOTH || MODE == IM_SMOOTH_H) {
-        if (WIDE) __builtin_memcpy(nb.ww, kSmWeights + bw + c0, PXL);
+        uint8_t tmp[16] = {0};
+        if (WIDE) __builtin_memcpy(tmp, kSmWeights + bw + c0, PXL);
         else {
 #pragma unroll
-            for (int k = 0; k < PXL; k++) nb.ww[k] = kSmWeights[bw + c0 + (k < ppl ? k : 0)];
+            for (int k = 0; k < PXL; k++) tmp[k] = kSmWeights[bw + c0 + (k < ppl ? k : 0)];
         }
+        __builtin_memcpy(&nb.wwv, tmp, 16);
     }
     nb.lft = (MODE == IM_H || MODE == IM_SMOOTH || MODE == IM_SMOOTH_H || MODE == IM_PAETH) ? (int)left[r] : 0;
     nb.bl = (MODE == IM_SMOOTH || MODE == IM_SMOOTH_V) ? (int)left[bh - 1] : 0;
@@ -125,8 +136,15 @@ __device__ __forceinline__ void intra_load(IntraNb<PixT>& nb, const PixT* __rest
 }
 
 template <typename PixT, int MODE, bool WIDE>
-__device__ __forceinline__ void intra_row(PixT (&out)[16 / sizeof(PixT)], const IntraNb<PixT>& nb, int wh, int dc) {
-    constexpr int PXL = 16 / (int)sizeof(PixT);
+__device__ __forceinline__ uint4 intra_row(const IntraNb<PixT>& nb, int wh, int dc) {
+    constexpr int PXL = 16 / (int)sizeof(PixT), ES = (int)sizeof(PixT), BITS = 8 * ES;
+    constexpr uint32_t MASK = ES == 1 ? 0xffu : 0xffffu;
+    if (MODE == IM_V) return nb.abv;                                   // the above segment as loaded
+    if (MODE == IM_H || MODE == IM_DC || MODE == IM_DC_TOP || MODE == IM_DC_LEFT || MODE == IM_DC_128) {
+        const uint32_t v = (uint32_t)(MODE == IM_H ? nb.lft : dc);
+        const uint32_t w = ES == 1 ? v * 0x01010101u : v * 0x00010001u;
+        return make_uint4(w, w, w, w);
+    }
     // terms that do not depend on the column
     const int sm_c = (256 - wh) * nb.bl + 256 * nb.tr + 256;          // SMOOTH: + wh*ab + ww*(lft - tr)
     const int smv_c = (256 - wh) * nb.bl + 128;                       // SMOOTH_V
@@ -134,21 +152,23 @@ __device__ __forceinline__ void intra_row(PixT (&out)[16 / sizeof(PixT)], const 
     const int dlt = nb.lft - nb.tr;
     const int p_t = abs(nb.lft - nb.tl);                              // PAETH: |base - top|  = |left - topleft|
     const int p_k = nb.lft - 2 * nb.tl;                               //        |base - tl|   = |top + left - 2 topleft|
+    const uint32_t aw[4] = {nb.abv.x, nb.abv.y, nb.abv.z, nb.abv.w}, ww4[4] = {nb.wwv.x, nb.wwv.y, nb.wwv.z, nb.wwv.w};
+    uint32_t ow[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < PXL; k++) {
+        const int t = (int)((aw[(k * ES) >> 2] >> (BITS * (k & (4 / ES - 1)))) & MASK);      // above[c0 + k]
+        const int ww = (int)((ww4[k >> 2] >> (8 * (k & 3))) & 0xffu);                          // smooth weight of that column
         int v;
-        if (MODE == IM_V) v = nb.ab[k];
-        else if (MODE == IM_H) v = nb.lft;
-        else if (MODE == IM_SMOOTH) v = (wh * nb.ab[k] + nb.ww[k] * dlt + sm_c) >> 9;
-        else if (MODE == IM_SMOOTH_V) v = (wh * nb.ab[k] + smv_c) >> 8;
-        else if (MODE == IM_SMOOTH_H) v = (nb.ww[k] * dlt + smh_c) >> 8;
-        else if (MODE == IM_PAETH) {
-            const int t = nb.ab[k];
+        if (MODE == IM_SMOOTH) v = (wh * t + ww * dlt + sm_c) >> 9;
+        else if (MODE == IM_SMOOTH_V) v = (wh * t + smv_c) >> 8;
+        else if (MODE == IM_SMOOTH_H) v = (ww * dlt + smh_c) >> 8;
+        else {   // IM_PAETH
             const int pl = abs(t - nb.tl), ptl = abs(t + p_k);        // |base - left| = |top - topleft|
             v = (pl <= p_t && pl <= ptl) ? nb.lft : (p_t <= ptl ? t : nb.tl);
-        } else v = dc;
-        out[k] = (PixT)v;
+        }
+        ow[(k * ES) >> 2] |= ((uint32_t)v & MASK) << (BITS * (k & (4 / ES - 1)));
     }
+    return make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
 template <typename PixT, int MODE, bool WIDE, int IU>
@@ -203,23 +223,25 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(
         } else if (MODE == IM_DC_128) {
             dc = 128 << (bd - 8);
         }
-        PixT out[PXL];
-        intra_row<PixT, MODE, WIDE>(out, nb[u], wh, dc);
+        const uint4 out = intra_row<PixT, MODE, WIDE>(nb[u], wh, dc);
         if (live[u]) intra_store<PixT>(dst + boff[u] + (size_t)r * dst_stride + c0, out, ppl);
     }
 }
 
 // ---- directional modes (av1_dr_prediction_z1/z2/z3, :370-477 / :3394-3506) ------------------
 // Same lane -> (row, 16-B column segment) mapping, one step per workgroup.  The two edge arrays of
-// the blocks a workgroup works on are first copied into LDS (every edge sample is used by many
-// pixels of the block) and PADDED with copies of their last valid sample edge[max_base]: the
-// reference's "base >= max_base -> edge[max_base]" case then falls out of the same interpolation
-// ((32*e + 16) >> 5 == e), so the pixel loop has no bounds test.  Each pixel is
-//   (a*(32-sh) + b*sh + 16) >> 5  =  two multiply-adds and a shift,
-// z1 walks one edge with a fixed phase per row (ppl+1 LDS reads for ppl pixels); results are packed
-// into dwords with v_lshl_or.
-__device__ __forceinline__ uint32_t dir_lerp(uint32_t a, uint32_t b, uint32_t w0, uint32_t sh) {
-    return (__umul24(b, sh) + (__umul24(a, w0) + 16u)) >> 5;
+// the blocks a workgroup works on are staged in LDS in PAIR form: dword i = edge[i] | edge[i+1] << 16,
+// padded with copies of the last valid sample edge[max_base] (the reference's "base >= max_base ->
+// edge[max_base]" case then falls out of the same interpolation: (32*e + 16) >> 5 == e, so the pixel
+// loop has no bounds test).  A pixel is then ONE aligned ds_read_b32 and ONE v_dot2_u32_u16:
+//   (a*(32-sh) + b*sh + 16) >> 5  =  dot2((a, b), (32-sh, sh), 16) >> 5.
+// (The first LDS version kept samples as bytes: the compiler merged the per-sample reads into unaligned
+// ds_read_b128/b64 at ~23 LDS cycles each and the LDS was 86 % busy; one ds_read_u8 per sample was slower
+// still.)  8- and 16-bit samples share the pair format.
+__device__ __forceinline__ uint32_t dir_lerp2(uint32_t pair, uint32_t w) {          // w = (32 - sh) | sh << 16
+    uint32_t r;
+    asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(pair), "v"(w), "v"(16u));
+    return r >> 5;
 }
 
 template <typename PixT, int MODE>
@@ -231,7 +253,7 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
     // samples, which clip_pixel_highbd (EbIntraPrediction.c:3394-3506) would clip: keep that
     const uint32_t maxv = (1u << bd) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t dir_smem[];
-    PixT* sm = reinterpret_cast<PixT*>(dir_smem);
+    uint32_t* sm = reinterpret_cast<uint32_t*>(dir_smem);
     constexpr int PXL = 16 / (int)sizeof(PixT);
     constexpr int PPW = 4 / (int)sizeof(PixT);                             // pixels per output dword
     const int ppl = bw < PXL ? bw : PXL;
@@ -246,27 +268,28 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
     const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = (uint32_t)(item & (per_block - 1));
     const int r = (int)(j >> lr_shift), c0 = (int)(j & (uint32_t)(lanes_per_row - 1)) * ppl;
-    const int estride = (n_pad + 7) & ~7;                                  // samples per staged edge
-    PixT* sa = sm + (size_t)slot * 2 * estride;                            // above edge of this lane's block
-    PixT* sl = sa + estride;
+    const int estride = (n_pad + 7) & ~7;                                  // pair dwords per staged edge
+    uint32_t* sa = sm + (size_t)slot * 2 * estride;                        // above edge of this lane's block
+    uint32_t* sl = sa + estride;
     const bool live = item < total;
     const uint32_t blk = live ? (uint32_t)(item >> pb_shift) : 0u;
     const bool has_offs = dst_offsets != nullptr;
     const uint32_t off_word = (has_offs ? dst_offsets : kZeroWord)[has_offs ? blk : 0u];
-    // ---- stage the block's two edges: array positions [NB_ORIGIN-2, lim] from memory (lim = NB_ORIGIN +
-    // max_base), everything after it = edge[max_base].  All loads of a lane are issued before the
-    // first LDS write (fixed trip count, clamped index: no branch, no wait between the loads).
+    // ---- stage the block's two edges as pairs: array positions [NB_ORIGIN-2, lim] from memory (lim = NB_ORIGIN +
+    // max_base), everything after it = edge[max_base].  All loads of a lane are issued before the first LDS
+    // write (fixed trip count, clamped index: no branch, no wait between the loads).
     {
         const PixT* ga = above_all + (size_t)blk * nb_pitch;
         const PixT* gl = left_all + (size_t)blk * nb_pitch;
         const int i0 = NB_ORIGIN - 2 + (int)jl, last = n_pad - 1;
         auto stage = [&](auto itc) {
             constexpr int IT = decltype(itc)::value;
-            PixT va[IT], vl[IT];
+            uint32_t va[IT], vl[IT];
 #pragma unroll
             for (int t = 0; t < IT; t++) {
                 const int i = min(i0 + t * (int)lpb, last);
-                va[t] = ga[min(i, lim_a)]; vl[t] = gl[min(i, lim_l)];
+                va[t] = (uint32_t)ga[min(i, lim_a)] | ((uint32_t)ga[min(i + 1, lim_a)] << 16);
+                vl[t] = (uint32_t)gl[min(i, lim_l)] | ((uint32_t)gl[min(i + 1, lim_l)] << 16);
             }
 #pragma unroll
             for (int t = 0; t < IT; t++) {
@@ -279,36 +302,33 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
         else if (niter <= 2) stage(std::integral_constant<int, 2>{});
         else if (niter <= 4) stage(std::integral_constant<int, 4>{});
         else if (niter <= 8) stage(std::integral_constant<int, 8>{});
-        else for (int i = i0; i < n_pad; i += (int)lpb) { sa[i] = ga[min(i, lim_a)]; sl[i] = gl[min(i, lim_l)]; }
+        else for (int i = i0; i < n_pad; i += (int)lpb) {
+            sa[i] = (uint32_t)ga[min(i, lim_a)] | ((uint32_t)ga[min(i + 1, lim_a)] << 16);
+            sl[i] = (uint32_t)gl[min(i, lim_l)] | ((uint32_t)gl[min(i + 1, lim_l)] << 16);
+        }
     }
     __syncthreads();
-    const PixT* A = sa + NB_ORIGIN;
-    const PixT* L = sl + NB_ORIGIN;
+    const uint32_t* A = sa + NB_ORIGIN;
+    const uint32_t* L = sl + NB_ORIGIN;
     uint32_t px[PXL];
     if (MODE == IM_Z1) {
         const int x = dx * (r + 1);
-        const uint32_t sh = (uint32_t)(((x << up_above) & 0x3f) >> 1), w0 = 32u - sh;
+        const uint32_t sh = (uint32_t)(((x << up_above) & 0x3f) >> 1), w = (32u - sh) | (sh << 16);
         // a start at or past max_base reads only padding (= above[max_base]), as the reference's tail fill does
-        const PixT* q = A + min((x >> (6 - up_above)) + (c0 << up_above), lim_a - NB_ORIGIN);
+        const uint32_t* q = A + min((x >> (6 - up_above)) + (c0 << up_above), lim_a - NB_ORIGIN);
         if (up_above == 0) {
-            uint32_t a = q[0];
 #pragma unroll
-            for (int k = 0; k < PXL; k++) {
-                const uint32_t b = q[k + 1];
-                px[k] = dir_lerp(a, b, w0, sh);
-                a = b;
-            }
+            for (int k = 0; k < PXL; k++) px[k] = dir_lerp2(q[k], w);
         } else {
 #pragma unroll
-            for (int k = 0; k < PXL; k++) px[k] = dir_lerp(q[2 * k], q[2 * k + 1], w0, sh);
+            for (int k = 0; k < PXL; k++) px[k] = dir_lerp2(q[2 * k], w);
         }
     } else if (MODE == IM_Z3) {
         int y = dy * (c0 + 1);
 #pragma unroll
         for (int k = 0; k < PXL; k++) {
             const uint32_t sh = (uint32_t)(((y << up_left) & 0x3f) >> 1);
-            const PixT* e = L + min((y >> (6 - up_left)) + (r << up_left), lim_l - NB_ORIGIN);
-            px[k] = dir_lerp(e[0], e[1], 32u - sh, sh);
+            px[k] = dir_lerp2(L[min((y >> (6 - up_left)) + (r << up_left), lim_l - NB_ORIGIN)], (32u - sh) | (sh << 16));
             y += dy;
         }
     } else {   // IM_Z2
@@ -324,7 +344,7 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
             const uint32_t s2 = (uint32_t)(((y * (1 << up_left)) & 0x3f) >> 1);
             const int idx = ab ? aoff + (k << up_above) : loff + (y >> (6 - up_left));
             const uint32_t sh = ab ? s1 : s2;
-            px[k] = dir_lerp(sm[idx], sm[idx + 1], 32u - sh, sh);
+            px[k] = dir_lerp2(sm[idx], (32u - sh) | (sh << 16));
             y -= dy;
         }
     }
@@ -341,10 +361,8 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
             for (int t = 1; t < PPW; t++) v |= px[q * PPW + t] << (8 * (int)sizeof(PixT) * t);
             w[q] = v;
         }
-        PixT out[PXL];
-        __builtin_memcpy(out, w, 16);
         const size_t base_off = has_offs ? (size_t)off_word : (size_t)blk * dst_block_pitch;
-        intra_store<PixT>(dst + base_off + (size_t)r * dst_stride + c0, out, ppl);
+        intra_store<PixT>(dst + base_off + (size_t)r * dst_stride + c0, make_uint4(w[0], w[1], w[2], w[3]), ppl);
     }
 }
 

@@ -105,10 +105,12 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void fwd_staged_kernel(
             if (NCH % 64 == 0 || q < NCH) {
                 const int b = (q * 16) / BB;
                 const bool ok = first + b < nblocks;
-                const uint4 z = make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(wl + q * 16 + b * PADI) = ok ? *reinterpret_cast<const uint4*>(g0 + (size_t)q * 16) : z;
-                if (FUSED)
-                    *reinterpret_cast<uint4*>(wl + IN_ONE + q * 16 + b * PADI) = ok ? *reinterpret_cast<const uint4*>(g1 + (size_t)q * 16) : z;
+                // (predicated loads into zeroed registers: `ok ? *p : zero` makes the compiler park the zero in scratch
+                // and select the POINTER - a flat load through private memory)
+                uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+                if (ok) { va = *reinterpret_cast<const uint4*>(g0 + (size_t)q * 16); if (FUSED) vb = *reinterpret_cast<const uint4*>(g1 + (size_t)q * 16); }
+                *reinterpret_cast<uint4*>(wl + q * 16 + b * PADI) = va;
+                if (FUSED) *reinterpret_cast<uint4*>(wl + IN_ONE + q * 16 + b * PADI) = vb;
             }
         }
     }
@@ -276,7 +278,8 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
             const int q = q0 + lane;
             if (NCH % 64 == 0 || q < NCH) {
                 const int b = q / CPB, w4 = q % CPB;
-                const int4 v = (first + b < nblocks) ? g[q] : make_int4(0, 0, 0, 0);
+                int4 v = make_int4(0, 0, 0, 0);
+                if (first + b < nblocks) v = g[q];
                 *reinterpret_cast<int4*>(wl + ((b * KH + w4 / (KW / 4)) * PQ + w4 % (KW / 4)) * 16) = v;
             }
         }
@@ -504,9 +507,9 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
             if (NCH % 64 == 0 || q < NCH) {
                 const int b = (q * 16) / BB;
                 const bool ok = first + b < nblocks;
-                const uint4 z = make_uint4(0, 0, 0, 0);
-                if (ok) pk[it] = *reinterpret_cast<const uint4*>(g1 + (size_t)q * 16);
-                *reinterpret_cast<uint4*>(wl + q * 16 + b * PADI) = ok ? *reinterpret_cast<const uint4*>(g0 + (size_t)q * 16) : z;
+                uint4 va = make_uint4(0, 0, 0, 0);
+                if (ok) { pk[it] = *reinterpret_cast<const uint4*>(g1 + (size_t)q * 16); va = *reinterpret_cast<const uint4*>(g0 + (size_t)q * 16); }
+                *reinterpret_cast<uint4*>(wl + q * 16 + b * PADI) = va;
                 *reinterpret_cast<uint4*>(wl + IN_ONE + q * 16 + b * PADI) = pk[it];
             }
         }

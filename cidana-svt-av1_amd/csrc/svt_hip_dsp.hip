@@ -938,7 +938,7 @@ extern "C" int svt_hip_intra_pred_batch(void* d_dst, int32_t dst_stride, size_t 
         const int up = upsample_above > upsample_left ? upsample_above : upsample_left;
         const int n_pad = (lim_a > lim_l ? lim_a : lim_l) + ((16 / es) << up) + 3;
         const size_t slots = per_block >= 256 ? 1 : 256 / per_block;
-        const size_t shmem = slots * 2 * (size_t)((n_pad + 7) & ~7) * es;
+        const size_t shmem = slots * 2 * (size_t)((n_pad + 7) & ~7) * 4;            // pair dwords (see the kernel)
 #define IDL(T, M)                                                                                                     \
     hipLaunchKernelGGL((intra_dir_kernel<T, M>), dim3((uint32_t)grid), dim3(256), shmem, s, (T*)d_dst, dst_stride,        \
                        dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh,            \
