@@ -228,14 +228,20 @@ __device__ __forceinline__ unsigned wave_min_u32_to_lane63(unsigned v) {
     return v;
 }
 
-__device__ __forceinline__ unsigned me_key16_min(const unsigned long long (&a)[4], unsigned idb) {
-    // a[g] = packed SADs of points 4g .. 4g+3; returns min over the 16 points of (sad << 16 | idb + point)
+template <bool MASKED>
+__device__ __forceinline__ unsigned me_key16_min(const unsigned long long (&a)[4], unsigned idb, unsigned nvalid) {
+    // a[g] = packed SADs of points 4g .. 4g+3; returns min over the lane's first `nvalid` points (all 16 unless
+    // MASKED: search widths that are not a multiple of 16) of (sad << 16 | idb + point)
     unsigned best = 0xffffffffu;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const unsigned lo = (unsigned)a[g], hi = (unsigned)(a[g] >> 32);
-        const unsigned k0 = ((lo << 16) | idb) + (4 * g + 0), k1 = ((lo & 0xffff0000u) | idb) + (4 * g + 1);
-        const unsigned k2 = ((hi << 16) | idb) + (4 * g + 2), k3 = ((hi & 0xffff0000u) | idb) + (4 * g + 3);
+        unsigned k0 = ((lo << 16) | idb) + (4 * g + 0), k1 = ((lo & 0xffff0000u) | idb) + (4 * g + 1);
+        unsigned k2 = ((hi << 16) | idb) + (4 * g + 2), k3 = ((hi & 0xffff0000u) | idb) + (4 * g + 3);
+        if (MASKED) {
+            k0 = 4 * g + 0 < nvalid ? k0 : 0xffffffffu; k1 = 4 * g + 1 < nvalid ? k1 : 0xffffffffu;
+            k2 = 4 * g + 2 < nvalid ? k2 : 0xffffffffu; k3 = 4 * g + 3 < nvalid ? k3 : 0xffffffffu;
+        }
         best = min(best, min(k0, k1));
         best = min(best, min(k2, k3));
     }
@@ -247,6 +253,8 @@ __device__ __forceinline__ unsigned long long me_pk_add(unsigned long long a, un
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// MASKED: the search width is not a multiple of 16; the last 16-point group of a row is partly outside the area.
+template <bool MASKED>
 __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void me_sb_search16_kernel(
     const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
     const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     __syncthreads();
 
-    const int xqn = search_w >> 4;
+    const int xqn = (search_w + 15) >> 4;
     const int ntasks = xqn * search_h;
     for (int t0 = 0; t0 < ntasks; t0 += ME_THREADS) {
         const int t = t0 + tid;
@@ -317,6 +325,7 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const int tc = act ? t : 0;
         const int ys = tc / xqn, xs0 = (tc - ys * xqn) * 16;
         const unsigned idb = (unsigned)(ys * search_w + xs0);         // point index of the lane's first point (< 4096)
+        const unsigned nvalid = MASKED ? (unsigned)min(16, search_w - xs0) : 16u;
         const unsigned dead = act ? 0u : 0xffffffffu;
         const uint8_t* rbase = s_ref + (size_t)ys * wpitch + xs0;
         unsigned s64[16];
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                     for (int bx = 0; bx < 8; bx++) {
                         const unsigned long long a4[4] = {acc[0][bx], acc[1][bx], acc[2][bx], acc[3][bx]};
-                        const unsigned k = wave_min_u32_to_lane63(me_key16_min(a4, idb) | dead);
+                        const unsigned k = wave_min_u32_to_lane63(me_key16_min<MASKED>(a4, idb, nvalid) | dead);
                         const int bx16 = bx >> 1;
                         const int zc = (bx16 >> 1) * 4 + h16 * 2 + (bx16 & 1);           // z-order inside the half
                         const int idx = 32 * h32 + 4 * zc + kb * 2 + (bx & 1);
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                 for (int c16 = 0; c16 < 4; c16++) {
                     const unsigned long long a4[4] = {s16[0][c16], s16[1][c16], s16[2][c16], s16[3][c16]};
-                    const unsigned k = wave_min_u32_to_lane63(me_key16_min(a4, idb) | dead);
+                    const unsigned k = wave_min_u32_to_lane63(me_key16_min<MASKED>(a4, idb, nvalid) | dead);
                     const int zc = (c16 >> 1) * 4 + h16 * 2 + (c16 & 1);
                     const int idx = 64 + 8 * h32 + zc;
                     if (lane == 63) s_red[wave][idx] = min(s_red[wave][idx], k);
@@ -401,7 +410,8 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         const unsigned a = (unsigned)((PA[c32][g] >> (16 * jj)) & 0xffffu), b = (unsigned)((PB[c32][g] >> (16 * jj)) & 0xffffu);
                         const unsigned s = (a + b) << 1;
                         s64[4 * g + jj] += s;
-                        best = min(best, (s << 12) | (idb + 4 * g + jj));
+                        const unsigned key = (s << 12) | (idb + 4 * g + jj);
+                        best = min(best, (MASKED && (unsigned)(4 * g + jj) >= nvalid) ? 0xffffffffu : key);
                     }
                 const unsigned k = wave_min_u32_to_lane63(best | dead);
                 const int idx = 80 + 2 * h32 + c32;
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         {
             unsigned best = 0xffffffffu;
 #pragma unroll
-            for (int i = 0; i < 16; i++) best = min(best, (s64[i] << 12) | (idb + i));
+            for (int i = 0; i < 16; i++) best = min(best, (MASKED && (unsigned)i >= nvalid) ? 0xffffffffu : (s64[i] << 12) | (idb + i));
             const unsigned k = wave_min_u32_to_lane63(best | dead);
             if (lane == 63) s_red[wave][84] = min(s_red[wave][84], k);
         }

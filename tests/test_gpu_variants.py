@@ -107,7 +107,7 @@ def test_sad_search_variants(dsp, knob, bw, sw, sh):
     assert _eq(a, b)
 
 
-@pytest.mark.parametrize("sw,sh", [(64, 64), (16, 5), (48, 16)])
+@pytest.mark.parametrize("sw,sh", [(64, 64), (16, 5), (48, 16), (13, 7), (1, 1), (37, 21)])
 def test_me_sb_search_variants(dsp, sw, sh):
     rng = np.random.default_rng(sw + sh)
     n = 6
