@@ -585,4 +585,165 @@ __global__ __launch_bounds__(256) void sad_search_q2_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// SAD search for 32- and 64-wide blocks (any height that is a multiple of 256 / CW), plain reference
+// window.  sad_search_q_kernel issues two ds_read_b32 per v_qsad_pk_u16_u8 (a reference and a source
+// dword), which makes the LDS pipe - shared by the CU's four SIMDs, 128 B/clk - its limiter at about
+// a third of the v_qsad rate.  Here a lane owns SIXTEEN horizontally adjacent candidates of one search
+// row (as me_sb_search16_kernel does): per block row it reads CW/16 + 1 ALIGNED ds_read_b128 of the
+// window and CW/16 broadcast ds_read_b128 of the source row and feeds CW v_qsad from them - 2.25 LDS
+// bytes per qsad instead of 8.  Packed u16 sums are widened every 256 / CW rows (CW * 255 * 256 / CW
+// < 2^16).  The window's row pitch is an odd multiple of 16 bytes so that the lanes of consecutive
+// search rows read different bank groups.
+// ---------------------------------------------------------------------------
+template <int CW>
+__global__ __launch_bounds__(256) void sad_search_q16_kernel(
+    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
+    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, uint32_t height, int search_w, int search_h,
+    unsigned long long* __restrict__ best_sad, int16_t* __restrict__ best_x, int16_t* __restrict__ best_y,
+    uint32_t wpitch, uint32_t ref_lds_bytes, uint32_t lpb, uint32_t tsh, uint32_t cpr_magic,
+    const uint32_t* __restrict__ src_offs, const uint32_t* __restrict__ ref_offs, uint32_t nblocks) {
+    static_assert(CW == 32 || CW == 64, "block width");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int WQ = CW / 4, WC = CW / 16, FL = 256 / CW;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lsh = __builtin_ctz(lpb);
+    const uint32_t slot = tid >> lsh, l = tid & (lpb - 1);
+    const uint32_t slots = blockDim.x >> lsh;
+    const uint32_t blk = blockIdx.x * slots + slot;
+    const bool valid = blk < nblocks;
+    const uint32_t win_w = CW + search_w - 1;
+    const uint32_t nrows = (uint32_t)search_h + height - 1;
+    const uint32_t src_bytes = CW * height;
+    uint8_t* s_src = smem + (size_t)slot * (src_bytes + ref_lds_bytes);
+    uint8_t* s_ref = s_src + src_bytes;
+    if (valid) {
+        const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
+        const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
+        // staging as in sad_search_q2_kernel: one flat list of 16-B chunks, SU unconditional (clamped) loads
+        // per lane issued back to back, then the LDS writes - one memory latency per SU chunks
+        constexpr int SU = 4;
+        const uint32_t nsrc = WC * height;
+        const uint32_t cpr = (win_w + 15) >> 4;
+        const uint32_t nref = nrows * cpr;
+        const size_t span = (size_t)(nrows - 1) * ref_stride + win_w;
+        for (uint32_t i0 = l; i0 < nsrc || i0 < nref; i0 += SU * lpb) {
+            uint4 vs[SU], vr[SU];
+            uint32_t rdst[SU], tdst[SU];
+#pragma unroll
+            for (int k = 0; k < SU; k++) {
+                const uint32_t i = min(i0 + k * lpb, nsrc - 1);
+                __builtin_memcpy(&vs[k], gs + (size_t)(i / WC) * src_stride + (i % WC) * 16, 16);
+            }
+#pragma unroll
+            for (int k = 0; k < SU; k++) {
+                const uint32_t j = min(i0 + k * lpb, nref - 1);
+                const uint32_t rr = __umulhi(j, cpr_magic), c = j - rr * cpr;     // j / cpr, j % cpr (cpr >= 2)
+                const size_t off = (size_t)rr * ref_stride + c * 16;
+                // a chunk that would end past the window's footprint is fetched as the LAST 16 bytes of the
+                // footprint instead and stored `delta` bytes earlier (the bytes it re-writes are the same data)
+                const size_t offc = off + 16 <= span ? off : span - 16;
+                __builtin_memcpy(&vr[k], gr + offc, 16);
+                const bool want = i0 + k * lpb < nref;
+                rdst[k] = (want && off == offc) ? rr * wpitch + c * 16 : ~0u;
+                tdst[k] = (want && off != offc) ? rr * wpitch + c * 16 - (uint32_t)(off - offc) : ~0u;
+            }
+            static_assert(SU == 4, "operand list below");
+            asm volatile("" ::"v"(vs[0].x), "v"(vs[1].x), "v"(vs[2].x), "v"(vs[3].x), "v"(vr[0].x), "v"(vr[1].x), "v"(vr[2].x), "v"(vr[3].x));
+#pragma unroll
+            for (int k = 0; k < SU; k++) {
+                const uint32_t i = i0 + k * lpb;
+                if (i < nsrc) *reinterpret_cast<uint4*>(s_src + i * 16) = vs[k];
+                if (rdst[k] != ~0u) *reinterpret_cast<uint4*>(s_ref + rdst[k]) = vr[k];
+            }
+#pragma unroll
+            for (int k = 0; k < SU; k++)
+                if (tdst[k] != ~0u) {                      // footprint tail: byte-granular LDS store, no global access
+                    const uint8_t* vb = reinterpret_cast<const uint8_t*>(&vr[k]);
+                    for (int bb = 0; bb < 16; bb++) s_ref[tdst[k] + bb] = vb[bb];
+                }
+        }
+    }
+    __syncthreads();
+    unsigned long long best = ~0ull;
+    if (valid) {
+        // lane = row split * TP + task: the lanes of one 8-lane LDS group are consecutive search rows (window
+        // pitch = odd multiple of 16 B: conflict-free), and a block with few tasks still fills 64 lanes by
+        // splitting the block's row groups over RS lanes per task (sums are added across them below)
+        const uint32_t TP = 1u << tsh, RS = lpb >> tsh;
+        const uint32_t t0 = l & (TP - 1), rs = l >> tsh;
+        const int xqn = (search_w + 15) >> 4;
+        const int ntasks = xqn * search_h;
+        for (int tb = 0; tb < ntasks; tb += (int)TP) {
+            const int t = tb + (int)t0;
+            const bool act = t < ntasks;
+            const int tc = act ? t : 0;
+            const int ys = tc / xqn, xs0 = (tc - ys * xqn) * 16;
+            const uint8_t* rbase = s_ref + (size_t)ys * wpitch + xs0;
+            uint32_t sum[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) sum[i] = 0;
+            for (uint32_t y0 = rs * FL; y0 < height; y0 += RS * FL) {
+                unsigned long long acc[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < FL; r++) {
+                    const uint4* sp = reinterpret_cast<const uint4*>(s_src + (size_t)(y0 + r) * CW);
+                    const uint4* rp = reinterpret_cast<const uint4*>(rbase + (size_t)(y0 + r) * wpitch);
+                    uint32_t sw[WQ], rw[WQ + 4];
+#pragma unroll
+                    for (int i = 0; i < WC; i++) { const uint4 a = sp[i]; sw[4 * i] = a.x; sw[4 * i + 1] = a.y; sw[4 * i + 2] = a.z; sw[4 * i + 3] = a.w; }
+#pragma unroll
+                    for (int i = 0; i < WC + 1; i++) { const uint4 a = rp[i]; rw[4 * i] = a.x; rw[4 * i + 1] = a.y; rw[4 * i + 2] = a.z; rw[4 * i + 3] = a.w; }
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+#pragma unroll
+                        for (int q = 0; q < WQ; q++)
+                            acc[g] = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)rw[g + q + 1] << 32) | rw[g + q], sw[q], acc[g]);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    sum[4 * g] += (uint32_t)(acc[g] & 0xffffu); sum[4 * g + 1] += (uint32_t)((acc[g] >> 16) & 0xffffu);
+                    sum[4 * g + 2] += (uint32_t)((acc[g] >> 32) & 0xffffu); sum[4 * g + 3] += (uint32_t)(acc[g] >> 48);
+                }
+            }
+            for (uint32_t m = TP; m < lpb; m <<= 1) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) sum[i] += (uint32_t)__shfl_xor((int)sum[i], (int)m, 64);
+            }
+            const int cbase = ys * search_w + xs0;
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    if (xs0 + j < search_w) {
+                        const unsigned long long key = ((unsigned long long)sum[j] << 32) | (unsigned)(cbase + j);
+                        best = key < best ? key : best;
+                    }
+            }
+        }
+    }
+    for (uint32_t m = lpb >> 1; m >= 1; m >>= 1) {
+        const unsigned long long o = __shfl_xor(best, (int)m, 64);
+        best = o < best ? o : best;
+    }
+    __syncthreads();
+    unsigned long long* s_out = reinterpret_cast<unsigned long long*>(smem);     // staging is dead
+    if (l == 0) s_out[slot] = valid ? best : ~0ull;
+    __syncthreads();
+    if (tid < slots) {
+        const uint32_t ob = blockIdx.x * slots + tid;
+        if (ob < nblocks) {
+            const unsigned long long key = s_out[tid];
+            const unsigned sadv = (unsigned)(key >> 32);
+            const int cand = (int)(key & 0xffffffffu);
+            if (sadv < 0xffffffu) {          // reference initialises best_sad = 0xffffff, strict '<'
+                best_sad[ob] = sadv;
+                best_x[ob] = (int16_t)(cand % search_w);
+                best_y[ob] = (int16_t)(cand / search_w);
+            } else {
+                best_sad[ob] = 0xffffffu;
+            }
+        }
+    }
+}
+
 }  // namespace svtdev

@@ -37,6 +37,7 @@ int g_tune_f32_qmode1 = 0;
 int g_tune_no_staged = 0;
 int g_tune_no_qsad = 0;
 int g_tune_no_q2 = 0;
+int g_tune_no_q16 = 0;
 int g_tune_no_me16 = 0;
 int g_tune_no_f32p = 0;
 int g_tune_no_inv_planes = 0;
@@ -308,6 +309,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "no_staged")) { g_tune_no_staged = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_qsad")) { g_tune_no_qsad = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_q2")) { g_tune_no_q2 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_q16")) { g_tune_no_q16 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_me16")) { g_tune_no_me16 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_f32p")) { g_tune_no_f32p = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_inv_planes")) { g_tune_no_inv_planes = value; return SVT_HIP_OK; }
@@ -773,6 +775,34 @@ static int sad_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src
             if (width == 16) SSQ2(16, 16); else SSQ2(8, 8);
 #undef SSQ2
             return launch_status("sad_search_q2");
+        }
+    }
+    if (plain && !g_tune_no_qsad && !g_tune_no_q16 && (width == 32 || width == 64) && height % (256 / width) == 0) {
+        // wide blocks: 16 candidates per lane on b128 LDS reads (sad_search_q16_kernel)
+        uint32_t wpitch = (((uint32_t)search_area_width + 15) & ~15u) + width;
+        if (((wpitch >> 4) & 1) == 0) wpitch += 16;            // odd multiple of 16 B: bank spread over search rows
+        const uint32_t ref_bytes = wpitch * nrows;
+        const uint32_t per_blk = width * height + ref_bytes;
+        if (per_blk <= 64 * 1024) {
+            const uint32_t tasks = (uint32_t)((search_area_width + 15) / 16) * (uint32_t)search_area_height;
+            uint32_t tsh = 0;
+            while ((1u << tsh) < tasks && tsh < 6) tsh++;
+            const uint32_t row_groups = height / (256 / width);
+            uint32_t lpb = 1u << tsh;
+            while (lpb < 64 && (lpb >> tsh) * 2 <= row_groups) lpb <<= 1;
+            uint32_t threads = 256;
+            while (threads > lpb && (size_t)(threads / lpb) * per_blk > 64 * 1024) threads >>= 1;
+            const uint32_t slots = threads / lpb;
+            const uint32_t grid = (uint32_t)((nblocks + slots - 1) / slots);
+            const uint32_t cpr_magic = (uint32_t)(0x100000000ull / ((win_w + 15) >> 4)) + 1u;
+#define SSQ16(CW)                                                                                                       \
+    hipLaunchKernelGGL((sad_search_q16_kernel<CW>), dim3(grid), dim3(threads), (size_t)slots * per_blk, (hipStream_t)stream, \
+                       d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, height, (int)search_area_width,  \
+                       (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, wpitch, ref_bytes, lpb, tsh,         \
+                       cpr_magic, d_src_offs, d_ref_offs, (uint32_t)nblocks)
+            if (width == 32) SSQ16(32); else SSQ16(64);
+#undef SSQ16
+            return launch_status("sad_search_q16");
         }
     }
     if ((width & 3) == 0 && !g_tune_no_qsad) {

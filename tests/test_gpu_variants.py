@@ -91,7 +91,8 @@ def test_inverse_on_planes_variants(dsp, knob, tx_size, bd):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("knob,bw,sw,sh", [("no_q2", 16, 8, 8), ("no_q2", 8, 13, 5), ("no_qsad", 16, 8, 8), ("no_qsad", 32, 9, 6)])
+@pytest.mark.parametrize("knob,bw,sw,sh", [("no_q2", 16, 8, 8), ("no_q2", 8, 13, 5), ("no_qsad", 16, 8, 8), ("no_qsad", 32, 9, 6),
+                                             ("no_q16", 32, 9, 6), ("no_q16", 64, 16, 16), ("no_q16", 32, 37, 3)])
 def test_sad_search_variants(dsp, knob, bw, sw, sh):
     rng = np.random.default_rng(bw + sw)
     n = 37
@@ -105,6 +106,28 @@ def test_sad_search_variants(dsp, knob, bw, sw, sh):
         _tune(dsp, knob, 0)
     torch.cuda.synchronize()
     assert _eq(a, b)
+
+
+@pytest.mark.parametrize("bw,bh,sw,sh", [(32, 8, 16, 16), (32, 16, 5, 9), (32, 64, 33, 2), (64, 16, 16, 7), (64, 32, 70, 3),
+                                         (64, 64, 1, 1), (32, 32, 1, 40), (64, 64, 64, 17)])
+def test_sad_search_wide_variants(dsp, bw, bh, sw, sh):
+    """sad_search_q16_kernel (16 candidates per lane) vs the 4-candidate kernel: rectangular blocks, search
+    widths that are not a multiple of 16, more tasks than lanes, row splits, ties and the maximum SAD."""
+    rng = np.random.default_rng(bw * bh + sw)
+    n = 19
+    src = rng.integers(0, 256, size=(n, bh, bw), dtype=np.uint8)
+    ref = rng.integers(0, 256, size=(n, bh + sh - 1, bw + sw - 1), dtype=np.uint8)
+    ref[0] = 3; src[0] = 4
+    ref[1] = 255; src[1] = 0
+    ref[2] = src[2, :1, :1]; ref[2, sh - 1:, sw - 1:] = src[2]             # exact match at the LAST candidate
+    try:
+        _tune(dsp, "no_q16", 0); a = dsp.sad_search(dev(src), dev(ref), sw, sh)
+        _tune(dsp, "no_q16", 1); b = dsp.sad_search(dev(src), dev(ref), sw, sh)
+    finally:
+        _tune(dsp, "no_q16", 0)
+    torch.cuda.synchronize()
+    assert _eq(a, b)
+    assert int(a[0][2]) == 0 and int(a[1][2]) == sw - 1 and int(a[2][2]) == sh - 1
 
 
 @pytest.mark.parametrize("sw,sh", [(64, 64), (16, 5), (48, 16), (13, 7), (1, 1), (37, 21)])
