@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void sad_search_q2_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// SAD search for 32- and 64-wide blocks (any height that is a multiple of 256 / CW), plain reference
+// SAD search for 16-, 32- and 64-wide blocks (any height that is a multiple of 256 / CW), plain reference
 // window.  sad_search_q_kernel issues two ds_read_b32 per v_qsad_pk_u16_u8 (a reference and a source
 // dword), which makes the LDS pipe - shared by the CU's four SIMDs, 128 B/clk - its limiter at about
 // a third of the v_qsad rate.  Here a lane owns SIXTEEN horizontally adjacent candidates of one search
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void sad_search_q16_kernel(
     unsigned long long* __restrict__ best_sad, int16_t* __restrict__ best_x, int16_t* __restrict__ best_y,
     uint32_t wpitch, uint32_t ref_lds_bytes, uint32_t lpb, uint32_t tsh, uint32_t cpr_magic,
     const uint32_t* __restrict__ src_offs, const uint32_t* __restrict__ ref_offs, uint32_t nblocks) {
-    static_assert(CW == 32 || CW == 64, "block width");
+    static_assert(CW == 16 || CW == 32 || CW == 64, "block width");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int WQ = CW / 4, WC = CW / 16, FL = 256 / CW;
     const uint32_t tid = threadIdx.x;

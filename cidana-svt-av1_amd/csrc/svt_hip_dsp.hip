@@ -748,8 +748,8 @@ static int sad_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src
     const uint32_t win_w = width + search_area_width - 1;
     const bool plain = ref_stride == ref_stride_raw;
     const uint32_t nrows = plain ? (uint32_t)(search_area_height + height - 1) : (uint32_t)search_area_height * height;
-    if (plain && !g_tune_no_qsad && !g_tune_no_q2 && ((width == 16 && height == 16) || (width == 8 && height == 8)) &&
-        (uint32_t)search_area_width * (uint32_t)search_area_height > 0) {
+    const bool q16_for_16x16 = !g_tune_no_q16 && width == 16 && search_area_width % 16 == 0;      // see the q16 routing below
+    if (plain && !g_tune_no_qsad && !g_tune_no_q2 && ((width == 16 && height == 16 && !q16_for_16x16) || (width == 8 && height == 8))) {
         // small blocks: source block in registers, 4 x 2 candidates per lane
         const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
         const uint32_t src_bytes = (width * height + 15) & ~15u;
@@ -777,7 +777,10 @@ static int sad_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src
             return launch_status("sad_search_q2");
         }
     }
-    if (plain && !g_tune_no_qsad && !g_tune_no_q16 && (width == 32 || width == 64) && height % (256 / width) == 0) {
+    // 16-wide blocks: 16x32 / 16x64 always (measured 2.1-2.3x over sad_search_q_kernel); 16x16 when no candidate
+    // of a lane is masked (search width % 16 == 0: 10 % over q2, equal otherwise)
+    if (plain && !g_tune_no_qsad && !g_tune_no_q16 && height % (256 / (width ? width : 1)) == 0 &&
+        (width == 32 || width == 64 || (width == 16 && (height != 16 || search_area_width % 16 == 0)))) {
         // wide blocks: 16 candidates per lane on b128 LDS reads (sad_search_q16_kernel)
         uint32_t wpitch = (((uint32_t)search_area_width + 15) & ~15u) + width;
         if (((wpitch >> 4) & 1) == 0) wpitch += 16;            // odd multiple of 16 B: bank spread over search rows
@@ -800,7 +803,7 @@ static int sad_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src
                        d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, height, (int)search_area_width,  \
                        (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, wpitch, ref_bytes, lpb, tsh,         \
                        cpr_magic, d_src_offs, d_ref_offs, (uint32_t)nblocks)
-            if (width == 32) SSQ16(32); else SSQ16(64);
+            if (width == 16) SSQ16(16); else if (width == 32) SSQ16(32); else SSQ16(64);
 #undef SSQ16
             return launch_status("sad_search_q16");
         }

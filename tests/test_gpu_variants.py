@@ -109,7 +109,8 @@ def test_sad_search_variants(dsp, knob, bw, sw, sh):
 
 
 @pytest.mark.parametrize("bw,bh,sw,sh", [(32, 8, 16, 16), (32, 16, 5, 9), (32, 64, 33, 2), (64, 16, 16, 7), (64, 32, 70, 3),
-                                         (64, 64, 1, 1), (32, 32, 1, 40), (64, 64, 64, 17)])
+                                         (64, 64, 1, 1), (32, 32, 1, 40), (64, 64, 64, 17), (16, 16, 16, 16), (16, 16, 32, 3),
+                                         (16, 32, 7, 5), (16, 64, 24, 9), (16, 32, 80, 2)])
 def test_sad_search_wide_variants(dsp, bw, bh, sw, sh):
     """sad_search_q16_kernel (16 candidates per lane) vs the 4-candidate kernel: rectangular blocks, search
     widths that are not a multiple of 16, more tasks than lanes, row splits, ties and the maximum SAD."""
