@@ -89,6 +89,13 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_sad_search_planes_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_void_p, c_uint32, c_uint32, c_void_p,
                                                   c_uint32, c_uint32, c_int16, c_int16, c_void_p, c_void_p, c_void_p,
                                                   c_size_t, c_void_p]
+    L.svt_hip_cfl_luma_subsampling_420_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_int, c_void_p, c_uint32,
+                                                         c_size_t, c_uint32, c_uint32, c_int, c_size_t, c_void_p]
+    L.svt_hip_subtract_average_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_uint32, c_uint32, c_int32, c_int32, c_size_t,
+                                                 c_void_p]
+    L.svt_hip_cfl_predict_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p,
+                                            c_void_p, c_int, c_uint32, c_uint32, c_int, c_size_t, c_void_p]
+    L.svt_hip_txb_init_levels_batch.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_uint32, c_uint32, c_size_t, c_void_p]
     return L
 
 
@@ -334,6 +341,54 @@ class SvtHipDsp:
                                                               self._p(out), n, self._stream()),
                     "svt_hip_full_distortion32_batch")
         return out
+
+    # -- K11 chroma from luma + level map ---------------------------------------------------
+    CFL_BUF_LINE = 32
+
+    def cfl_luma_subsampling_420(self, luma, luma_stride, width, height, xy=None, luma_block_pitch=0, n=None,
+                                 subtract_average=False, q3=None):
+        """luma: uint8 / int16(uint16 values) plane or dense blocks; width x height = LUMA block.
+        -> int16 [n, 32, 32] Q3 buffers in the reference's layout (rows CFL_BUF_LINE apart)"""
+        t = self.torch
+        if n is None:
+            n = xy.shape[0]
+        if q3 is None:
+            q3 = t.zeros((n, 32, 32), dtype=t.int16, device=luma.device)
+        self._check(self.lib.svt_hip_cfl_luma_subsampling_420_batch(self._p(luma), luma_stride, luma_block_pitch,
+                                                                     self._p(xy) if xy is not None else None,
+                                                                     0 if luma.dtype == t.uint8 else 1, self._p(q3), 32, 1024,
+                                                                     width, height, 1 if subtract_average else 0, n,
+                                                                     self._stream()), "svt_hip_cfl_luma_subsampling_420_batch")
+        return q3
+
+    def subtract_average(self, q3, width, height, round_offset, num_pel_log2):
+        n = q3.shape[0]
+        self._check(self.lib.svt_hip_subtract_average_batch(self._p(q3), q3.shape[2], q3.shape[1] * q3.shape[2], width, height,
+                                                             round_offset, num_pel_log2, n, self._stream()),
+                    "svt_hip_subtract_average_batch")
+        return q3
+
+    def cfl_predict(self, ac_q3, pred, pred_stride, dst, dst_stride, alpha_q3, bd, width, height, xy=None):
+        t = self.torch
+        n = ac_q3.shape[0]
+        self._check(self.lib.svt_hip_cfl_predict_batch(self._p(ac_q3), ac_q3.shape[2], ac_q3.shape[1] * ac_q3.shape[2],
+                                                        self._p(pred), pred_stride, self._p(dst), dst_stride,
+                                                        self._p(xy) if xy is not None else None, self._p(alpha_q3), bd, width,
+                                                        height, 0 if pred.dtype == t.uint8 else 1, n, self._stream()),
+                    "svt_hip_cfl_predict_batch")
+        return dst
+
+    def txb_init_levels(self, coeff, width, height, levels_buf=None):
+        """coeff int32 [n, height*width] -> uint8 [n, pitch] whole padded level buffers"""
+        t = self.torch
+        n = coeff.shape[0]
+        size = (width + 4) * (height + 6) + 16
+        if levels_buf is None:
+            levels_buf = t.empty((n, size), dtype=t.uint8, device=coeff.device)
+        self._check(self.lib.svt_hip_txb_init_levels_batch(self._p(coeff), coeff.shape[1] if coeff.dim() == 2 else width * height,
+                                                            self._p(levels_buf), levels_buf.shape[1], width, height, n,
+                                                            self._stream()), "svt_hip_txb_init_levels_batch")
+        return levels_buf
 
     # -- K9 / K10 ------------------------------------------------------------------------
     NB_ORIGIN = 16

@@ -1,0 +1,176 @@
+// kernel_cfl.h — chroma-from-luma helpers of the encode pass (K11: cfl_luma_subsampling_420_{lbd,hbd},
+// subtract_average, cfl_predict_{lbd,hbd}; reference EbIntraPrediction.c:1303-1402, called from
+// Av1EncodeLoop, EbCodingLoop.c:736-846) and the entropy stage's level map (av1_txb_init_levels,
+// EbRateDistortionCost.c:125-150).  All four are HBM-bound byte / int16 work: one 16-byte item per lane,
+// a grid as large as the job, no LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dev_common.h"
+
+namespace svtdev {
+
+// ---------------------------------------------------------------------------
+// cfl_ac_kernel<IN> — per chroma block: 2x2 luma sums * 2 (Q3), optionally minus the block average.
+//   IN = 0: 8-bit luma, 1: 16-bit luma, 2: the Q3 buffer itself (subtract_average alone, in place).
+// A lane owns one chunk of CS = min(W, 8) chroma samples of one row; a block's chunks sit in lpb <= 64
+// consecutive lanes (two passes when a 32x32 block has 128 chunks), so the block sum is a __shfl_xor
+// reduction.  Blocks are addressed by xy = x | y << 16 in a plane (d_xy) or densely (block pitch).
+// ---------------------------------------------------------------------------
+template <int IN>
+__global__ __launch_bounds__(256) void cfl_ac_kernel(const void* __restrict__ luma, uint32_t luma_stride, size_t luma_block_pitch,
+                                                     const uint32_t* __restrict__ xy, int16_t* __restrict__ q3, uint32_t q3_line,
+                                                     size_t q3_block_pitch, uint32_t w, uint32_t h, uint32_t lpb, int subtract,
+                                                     int round_offset, int num_pel_log2, uint32_t nblocks) {
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lsh = __builtin_ctz(lpb);
+    const uint32_t blk = tid >> lsh, l = tid & (lpb - 1);
+    const bool valid = blk < nblocks;
+    const uint32_t cs = w < 8 ? 4u : 8u;                    // chroma samples per chunk
+    const uint32_t cpr_sh = w == 32 ? 2u : (w == 16 ? 1u : 0u);
+    const uint32_t nchunks = (w / cs) * h;
+    int v[2][8];
+    int sum = 0;
+    int16_t* qb = q3 + (valid ? (size_t)blk * q3_block_pitch : 0);
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const uint32_t c = l + p * lpb;
+        const bool on = valid && c < nchunks;
+        const uint32_t cc = on ? c : 0;
+        const uint32_t row = cc >> cpr_sh, col = (cc & ((1u << cpr_sh) - 1)) * cs;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[p][i] = 0;
+        if (on) {
+            if (IN == 2) {
+                const int16_t* s = qb + (size_t)row * q3_line + col;
+                if (cs == 8) { short vv[8]; __builtin_memcpy(vv, s, 16);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[p][i] = vv[i];
+                } else { short vv[4]; __builtin_memcpy(vv, s, 8);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[p][i] = vv[i];
+                }
+            } else {
+                size_t base;
+                if (xy) { const uint32_t q = xy[blk]; base = (size_t)(q >> 16) * luma_stride + (q & 0xffffu); }
+                else base = (size_t)blk * luma_block_pitch;
+                base += (size_t)(2 * row) * luma_stride + 2 * col;
+                if (IN == 0) {
+                    const uint8_t* s = reinterpret_cast<const uint8_t*>(luma) + base;
+                    uint8_t r0[16], r1[16];
+                    if (cs == 8) { __builtin_memcpy(r0, s, 16); __builtin_memcpy(r1, s + luma_stride, 16); }
+                    else { __builtin_memcpy(r0, s, 8); __builtin_memcpy(r1, s + luma_stride, 8); }
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (i < (int)cs) v[p][i] = ((int)r0[2 * i] + r0[2 * i + 1] + r1[2 * i] + r1[2 * i + 1]) << 1;
+                } else {
+                    const uint16_t* s = reinterpret_cast<const uint16_t*>(luma) + base;
+                    uint16_t r0[16], r1[16];
+                    if (cs == 8) { __builtin_memcpy(r0, s, 32); __builtin_memcpy(r1, s + luma_stride, 32); }
+                    else { __builtin_memcpy(r0, s, 16); __builtin_memcpy(r1, s + luma_stride, 16); }
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (i < (int)cs) v[p][i] = (int)(int16_t)(uint16_t)(((int)r0[2 * i] + r0[2 * i + 1] + r1[2 * i] + r1[2 * i + 1]) << 1);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) sum += v[p][i];
+        }
+    }
+    int avg = 0;
+    if (subtract) {
+        for (uint32_t m = lpb >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, (int)m, 64);
+        avg = (int)(int16_t)((sum + round_offset) >> num_pel_log2);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const uint32_t c = l + p * lpb;
+        if (valid && c < nchunks) {
+            const uint32_t row = c >> cpr_sh, col = (c & ((1u << cpr_sh) - 1)) * cs;
+            short o[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[i] = (short)(v[p][i] - avg);
+            int16_t* d = qb + (size_t)row * q3_line + col;
+            if (cs == 8) __builtin_memcpy(d, o, 16); else __builtin_memcpy(d, o, 8);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// cfl_predict_kernel<PixT> — dst = clip(pred + round_signed(alpha_q3 * ac_q3, 6)); one chunk of min(W, 8)
+// samples per lane.  pred and dst may be the same plane (the encode pass predicts in place).
+// ---------------------------------------------------------------------------
+template <typename PixT>
+__global__ __launch_bounds__(256) void cfl_predict_kernel(const int16_t* __restrict__ ac, uint32_t q3_line, size_t q3_block_pitch,
+                                                          const PixT* pred, uint32_t pred_stride, PixT* dst, uint32_t dst_stride,
+                                                          const uint32_t* __restrict__ xy, const int32_t* __restrict__ alpha_q3,
+                                                          int hi, uint32_t w, uint32_t h, uint32_t per_block_sh, uint32_t nblocks) {
+    const size_t tid = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t blk = (uint32_t)(tid >> per_block_sh);
+    if (blk >= nblocks) return;
+    const uint32_t c = (uint32_t)tid & ((1u << per_block_sh) - 1);
+    const uint32_t cs = w < 8 ? 4u : 8u;
+    const uint32_t cpr_sh = w == 32 ? 2u : (w == 16 ? 1u : 0u);
+    const uint32_t row = c >> cpr_sh, col = (c & ((1u << cpr_sh) - 1)) * cs;
+    size_t pb, db;
+    if (xy) { const uint32_t q = xy[blk]; pb = (size_t)(q >> 16) * pred_stride + (q & 0xffffu); db = (size_t)(q >> 16) * dst_stride + (q & 0xffffu); }
+    else { pb = (size_t)blk * pred_stride * h; db = (size_t)blk * dst_stride * h; }
+    const int a = alpha_q3[blk];
+    short q[8];
+    PixT pv[8], ov[8];
+    const int16_t* s = ac + (size_t)blk * q3_block_pitch + (size_t)row * q3_line + col;
+    const PixT* pp = pred + pb + (size_t)row * pred_stride + col;
+    if (cs == 8) { __builtin_memcpy(q, s, 16); __builtin_memcpy(pv, pp, 8 * sizeof(PixT)); }
+    else { __builtin_memcpy(q, s, 8); __builtin_memcpy(pv, pp, 4 * sizeof(PixT)); }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i < (int)cs) {
+            const int q6 = a * q[i];
+            const int mag = ((q6 < 0 ? -q6 : q6) + 32) >> 6;
+            int v = (int)(int16_t)pv[i] + (q6 < 0 ? -mag : mag);
+            v = v < 0 ? 0 : (v > hi ? hi : v);
+            ov[i] = (PixT)v;
+        }
+    }
+    PixT* dp = dst + db + (size_t)row * dst_stride + col;
+    if (cs == 8) __builtin_memcpy(dp, ov, 8 * sizeof(PixT)); else __builtin_memcpy(dp, ov, 4 * sizeof(PixT));
+}
+
+// ---------------------------------------------------------------------------
+// txb_init_levels_kernel — levels buffer of one block = (W + 4) x (H + 6) bytes + 16: two zero rows, H rows of
+// min(|coeff|, 127) with 4 zero bytes of right padding, four zero rows + 16 zero bytes.  A lane writes one
+// dword of the buffer (W + 4 is a multiple of 4, so a dword never straddles a row) from one 16-byte load.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void txb_init_levels_kernel(const int32_t* __restrict__ coeff, size_t coeff_block_pitch,
+                                                              uint8_t* __restrict__ levels_buf, size_t levels_block_pitch,
+                                                              uint32_t w, uint32_t h, uint32_t lpb, uint32_t ndw, uint32_t row_magic,
+                                                              uint32_t nblocks) {
+    const uint32_t lsh = __builtin_ctz(lpb);
+    const uint32_t slots = 256u >> lsh;
+    const uint32_t blk = blockIdx.x * slots + (threadIdx.x >> lsh);
+    if (blk >= nblocks) return;
+    const uint32_t l = threadIdx.x & (lpb - 1);
+    const uint32_t dpr = (w + 4) >> 2;                       // dwords per row
+    const int32_t* cb = coeff + (size_t)blk * coeff_block_pitch;
+    uint32_t* ob = reinterpret_cast<uint32_t*>(levels_buf + (size_t)blk * levels_block_pitch);
+    for (uint32_t d = l; d < ndw; d += lpb) {
+        const uint32_t r = __umulhi(d, row_magic), cq = d - r * dpr;          // d / dpr, d % dpr
+        uint32_t out = 0;
+        const uint32_t y = r - 2;                            // TX_PAD_TOP rows above (wraps to huge for r < 2)
+        if (y < h && cq < (w >> 2)) {
+            int4 c4;
+            __builtin_memcpy(&c4, cb + (size_t)y * w + 4 * cq, 16);
+            const int cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // |INT32_MIN| is undefined in the reference (abs); every other value is exact
+                const uint32_t a = (uint32_t)(cv[i] < 0 ? -(long long)cv[i] : (long long)cv[i]);
+                out |= (a > 127u ? 127u : a) << (8 * i);
+            }
+        }
+        ob[d] = out;
+    }
+}
+
+}  // namespace svtdev

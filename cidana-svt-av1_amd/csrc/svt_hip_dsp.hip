@@ -12,6 +12,7 @@
 #include <mutex>
 
 #include "../../include/svt_hip_dsp.h"
+#include "kernel_cfl.h"
 #include "kernel_fused32.h"
 #include "kernel_intra.h"
 #include "kernel_me.h"
@@ -932,6 +933,103 @@ extern "C" int svt_hip_full_distortion32_batch(const int32_t* d_coeff, uint32_t 
                        d_coeff, coeff_stride, coeff_block_pitch, d_recon, recon_stride, recon_block_pitch, width, height,
                        cbf_zero, (unsigned long long*)d_out, (uint32_t)nblocks);
     return launch_status("full_distortion32");
+}
+
+// ---- K11 chroma-from-luma helpers + av1_txb_init_levels ----
+static bool cfl_dim_ok(uint32_t v) { return v == 4 || v == 8 || v == 16 || v == 32; }
+
+static int cfl_ac_launch(int in_mode, const void* d_luma, uint32_t luma_stride, size_t luma_block_pitch, const uint32_t* d_xy,
+                         int16_t* d_q3, uint32_t q3_line, size_t q3_block_pitch, uint32_t w, uint32_t h, int subtract,
+                         int round_offset, int num_pel_log2, size_t nblocks, void* stream, const char* what) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_q3 || (in_mode != 2 && !d_luma)) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (!cfl_dim_ok(w) || !cfl_dim_ok(h)) return set_err(SVT_HIP_ERR_INVALID, "chroma block %ux%u", w, h);
+    if (q3_line < w || q3_block_pitch < (size_t)q3_line * (h - 1) + w) return set_err(SVT_HIP_ERR_INVALID, "q3 layout: line %u, block pitch %zu", q3_line, q3_block_pitch);
+    if (num_pel_log2 < 0 || num_pel_log2 > 31) return set_err(SVT_HIP_ERR_INVALID, "num_pel_log2 %d", num_pel_log2);
+    const uint32_t nchunks = (w / (w < 8 ? 4 : 8)) * h;
+    const uint32_t lpb = nchunks < 64 ? nchunks : 64;
+    const size_t lanes = nblocks * lpb;
+    const size_t grid = (lanes + 255) / 256;
+    if (grid > 0x7fffffffu || nblocks > 0x7fffffffu / 64) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+#define CFL_AC(IN)                                                                                                          \
+    hipLaunchKernelGGL((cfl_ac_kernel<IN>), dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_luma, luma_stride,   \
+                       luma_block_pitch, d_xy, d_q3, q3_line, q3_block_pitch, w, h, lpb, subtract, round_offset, num_pel_log2, \
+                       (uint32_t)nblocks)
+    if (in_mode == 0) CFL_AC(0); else if (in_mode == 1) CFL_AC(1); else CFL_AC(2);
+#undef CFL_AC
+    return launch_status(what);
+}
+
+extern "C" int svt_hip_cfl_luma_subsampling_420_batch(const void* d_luma, uint32_t luma_stride, size_t luma_block_pitch,
+                                                      const uint32_t* d_xy, int is_16bit, int16_t* d_q3, uint32_t q3_line,
+                                                      size_t q3_block_pitch, uint32_t width, uint32_t height,
+                                                      int subtract_average, size_t nblocks, void* stream) {
+    if ((width & 1) || (height & 1)) return set_err(SVT_HIP_ERR_INVALID, "luma block %ux%u", width, height);
+    const uint32_t w = width >> 1, h = height >> 1;
+    int lg = 0;
+    while ((1u << lg) < w * h) lg++;
+    return cfl_ac_launch(is_16bit ? 1 : 0, d_luma, luma_stride, luma_block_pitch, d_xy, d_q3, q3_line, q3_block_pitch, w, h,
+                         subtract_average ? 1 : 0, (int)(w * h / 2), lg, nblocks, stream, "cfl_luma_subsampling_420");
+}
+
+extern "C" int svt_hip_subtract_average_batch(int16_t* d_q3, uint32_t q3_line, size_t q3_block_pitch, uint32_t width,
+                                              uint32_t height, int32_t round_offset, int32_t num_pel_log2, size_t nblocks,
+                                              void* stream) {
+    return cfl_ac_launch(2, nullptr, 0, 0, nullptr, d_q3, q3_line, q3_block_pitch, width, height, 1, round_offset,
+                         num_pel_log2, nblocks, stream, "subtract_average");
+}
+
+extern "C" int svt_hip_cfl_predict_batch(const int16_t* d_ac_q3, uint32_t q3_line, size_t q3_block_pitch, const void* d_pred,
+                                         uint32_t pred_stride, void* d_dst, uint32_t dst_stride, const uint32_t* d_xy,
+                                         const int32_t* d_alpha_q3, int bit_depth, uint32_t width, uint32_t height,
+                                         int is_16bit, size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_ac_q3 || !d_pred || !d_dst || !d_alpha_q3) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (!cfl_dim_ok(width) || !cfl_dim_ok(height)) return set_err(SVT_HIP_ERR_INVALID, "chroma block %ux%u", width, height);
+    if ((is_16bit && bit_depth != 8 && bit_depth != 10 && bit_depth != 12) || (!is_16bit && bit_depth != 8))
+        return set_err(SVT_HIP_ERR_INVALID, "bit depth %d", bit_depth);
+    if (q3_line < width || pred_stride < width || dst_stride < width) return set_err(SVT_HIP_ERR_INVALID, "stride smaller than the block");
+    const uint32_t nchunks = (width / (width < 8 ? 4 : 8)) * height;
+    uint32_t sh = 0;
+    while ((1u << sh) < nchunks) sh++;
+    const size_t grid = ((nblocks << sh) + 255) / 256;
+    if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+    const int hi = (1 << bit_depth) - 1;
+    if (is_16bit)
+        hipLaunchKernelGGL((cfl_predict_kernel<uint16_t>), dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_ac_q3, q3_line,
+                           q3_block_pitch, (const uint16_t*)d_pred, pred_stride, (uint16_t*)d_dst, dst_stride, d_xy, d_alpha_q3, hi,
+                           width, height, sh, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL((cfl_predict_kernel<uint8_t>), dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_ac_q3, q3_line,
+                           q3_block_pitch, (const uint8_t*)d_pred, pred_stride, (uint8_t*)d_dst, dst_stride, d_xy, d_alpha_q3, hi,
+                           width, height, sh, (uint32_t)nblocks);
+    return launch_status("cfl_predict");
+}
+
+extern "C" int svt_hip_txb_init_levels_batch(const int32_t* d_coeff, size_t coeff_block_pitch, uint8_t* d_levels_buf,
+                                             size_t levels_block_pitch, uint32_t width, uint32_t height, size_t nblocks,
+                                             void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_coeff || !d_levels_buf) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    auto ok = [](uint32_t v) { return v == 4 || v == 8 || v == 16 || v == 32 || v == 64; };
+    if (!ok(width) || !ok(height)) return set_err(SVT_HIP_ERR_INVALID, "block %ux%u", width, height);
+    const uint32_t bytes = (width + 4) * (height + 6) + 16;      // (W + TX_PAD_HOR) * (H + TX_PAD_VER) + TX_PAD_END
+    if (levels_block_pitch < bytes || (levels_block_pitch & 3) || ((uintptr_t)d_levels_buf & 3))
+        return set_err(SVT_HIP_ERR_INVALID, "levels buffer: %zu B per block (need >= %u, multiple of 4, 4-byte aligned)", levels_block_pitch, bytes);
+    if (coeff_block_pitch < (size_t)width * height) return set_err(SVT_HIP_ERR_INVALID, "coeff_block_pitch %zu", coeff_block_pitch);
+    const uint32_t ndw = bytes >> 2, dpr = (width + 4) >> 2;
+    uint32_t lpb = 1;
+    while (lpb < ndw && lpb < 256) lpb <<= 1;
+    const uint32_t slots = 256 / lpb;
+    const size_t grid = (nblocks + slots - 1) / slots;
+    if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+    const uint32_t row_magic = (uint32_t)(0x100000000ull / dpr) + 1u;
+    hipLaunchKernelGGL(txb_init_levels_kernel, dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_coeff, coeff_block_pitch,
+                       d_levels_buf, levels_block_pitch, width, height, lpb, ndw, row_magic, (uint32_t)nblocks);
+    return launch_status("txb_init_levels");
 }
 
 static bool intra_size_ok(int bw, int bh) {

@@ -293,6 +293,45 @@ int svt_hip_full_distortion32_batch(const int32_t *d_coeff, uint32_t coeff_strid
                                     uint32_t width, uint32_t height, int cbf_zero,
                                     uint64_t *d_out, size_t nblocks, void *stream);
 
+/* K11 chroma-from-luma helpers of the encode pass (Av1EncodeLoop, EbCodingLoop.c:736-846) and the
+ * entropy stage's level map - the remaining pieces of SURVEY.md 8(f) n3.
+ *
+ * svt_hip_cfl_luma_subsampling_420_batch replaces cfl_luma_subsampling_420_{lbd,hbd}_c
+ * (EbIntraPrediction.c:1303-1332; aom_dsp_rtcd.h has no dispatch slot for them): per block, a
+ * width x height LUMA area (8-bit, or 16-bit when is_16bit) becomes width/2 x height/2 Q3 sums
+ * `(a + b + c + d) << 1`.  Blocks are addressed by d_xy[i] = x | y << 16 (sample units) in the
+ * plane d_luma, or, when d_xy is NULL, lie luma_block_pitch samples apart.  Output rows are
+ * q3_line int16 apart (CFL_BUF_LINE = 32 in the reference), blocks q3_block_pitch int16 apart
+ * (CFL_BUF_SQUARE = 1024 there).  subtract_average != 0 also applies subtract_average with the
+ * encode pass's arguments (round_offset = w*h/2, num_pel_log2 = log2(w*h) of the chroma block) in
+ * the same kernel.  Chroma sizes 4..32 in both dimensions. */
+int svt_hip_cfl_luma_subsampling_420_batch(const void *d_luma, uint32_t luma_stride,
+                                           size_t luma_block_pitch, const uint32_t *d_xy, int is_16bit,
+                                           int16_t *d_q3, uint32_t q3_line, size_t q3_block_pitch,
+                                           uint32_t width, uint32_t height, int subtract_average,
+                                           size_t nblocks, void *stream);
+/* subtract_average (aom_dsp_rtcd.h:138, C: EbIntraPrediction.c:1333-1359), in place on Q3 blocks. */
+int svt_hip_subtract_average_batch(int16_t *d_q3, uint32_t q3_line, size_t q3_block_pitch,
+                                   uint32_t width, uint32_t height, int32_t round_offset,
+                                   int32_t num_pel_log2, size_t nblocks, void *stream);
+/* cfl_predict_lbd / cfl_predict_hbd (aom_dsp_rtcd.h:142-146, C: EbIntraPrediction.c:1361-1402):
+ * dst = clip(pred + ROUND_POWER_OF_TWO_SIGNED(alpha_q3 * ac_q3, 6), bit_depth), one alpha per block
+ * (d_alpha_q3[nblocks]).  pred and dst are planes addressed by the same d_xy (the encode pass
+ * predicts in place: d_dst == d_pred is allowed), or dense blocks (stride * height apart) when
+ * d_xy is NULL. */
+int svt_hip_cfl_predict_batch(const int16_t *d_ac_q3, uint32_t q3_line, size_t q3_block_pitch,
+                              const void *d_pred, uint32_t pred_stride, void *d_dst,
+                              uint32_t dst_stride, const uint32_t *d_xy, const int32_t *d_alpha_q3,
+                              int bit_depth, uint32_t width, uint32_t height, int is_16bit,
+                              size_t nblocks, void *stream);
+/* av1_txb_init_levels (aom_dsp_rtcd.h:2374, C: EbRateDistortionCost.c:125-150).  d_levels_buf holds
+ * one WHOLE padded buffer per block (the reference's levels_buf; its `levels` pointer is
+ * buffer + TX_PAD_TOP * (width + TX_PAD_HOR)), levels_block_pitch >= (width + 4) * (height + 6) + 16
+ * bytes, a multiple of 4.  Every byte of the (width + 4) * (height + 6) + 16 is written. */
+int svt_hip_txb_init_levels_batch(const int32_t *d_coeff, size_t coeff_block_pitch,
+                                  uint8_t *d_levels_buf, size_t levels_block_pitch, uint32_t width,
+                                  uint32_t height, size_t nblocks, void *stream);
+
 /* K9/K10 intra prediction.  Replaces the aom_{dc,...,paeth}_predictor_WxH /
  * aom_highbd_* slots (aom_dsp_rtcd.h:442-1262, 1626-2330; C: EbIntraPrediction.c:
  * 1838-2260) and av1_dr_prediction_z{1,2,3} / av1_highbd_dr_prediction_z*

@@ -246,12 +246,59 @@ def gen_intra():
     np.savez_compressed(os.path.join(HERE, "intra.npz"), **d)
 
 
+CFL_SHAPES = [(4, 4), (8, 8), (16, 16), (32, 32), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16), (4, 16), (16, 4), (8, 32), (32, 8)]
+
+
+def gen_cfl_levels():
+    """K11 chroma-from-luma helpers and av1_txb_init_levels: outputs of the reference's scalar C functions
+    (no reference unit test covers them).  Shapes are CHROMA block sizes (the luma block is twice as large)."""
+    rng = np.random.default_rng(13600)
+    d = {}
+    for (w, h) in CFL_SHAPES:
+        for bd in (8, 10):
+            dt = np.uint8 if bd == 8 else np.uint16
+            ls = 2 * w + 5
+            luma = rng.integers(0, 1 << bd, size=(3, 2 * h, ls)).astype(dt)
+            luma[1] = (1 << bd) - 1
+            q3 = np.full((3, 32, 32), 77, np.int16)
+            ac = np.zeros_like(q3)
+            for i in range(3):
+                getattr(R, "cfl_luma_subsampling_420_lbd_c" if bd == 8 else "cfl_luma_subsampling_420_hbd_c")(
+                    ptr(luma[i]), c_int(ls), ptr(q3[i]), c_int(2 * w), c_int(2 * h))
+                ac[i] = q3[i]
+                R.subtract_average_c(ptr(ac[i]), c_int(w), c_int(h), c_int(w * h // 2), c_int(int(np.log2(w * h))))
+            key = f"cfl_{w}x{h}_{bd}"
+            d[key + "_luma"] = luma; d[key + "_q3"] = q3; d[key + "_ac"] = ac
+            ps = w + 3
+            pred = rng.integers(0, 1 << bd, size=(3, h, ps)).astype(dt)
+            pred[1] = (1 << bd) - 1; pred[2] = 0
+            alphas = np.array([-16, 5, 16], np.int32)
+            out = np.zeros((3, h, ps), dt)
+            for i in range(3):
+                getattr(R, "cfl_predict_lbd_c" if bd == 8 else "cfl_predict_hbd_c")(
+                    ptr(ac[i]), ptr(pred[i]), c_int(ps), ptr(out[i]), c_int(ps), c_int(int(alphas[i])), c_int(bd), c_int(w), c_int(h))
+            d[key + "_pred"] = pred; d[key + "_alpha"] = alphas; d[key + "_dst"] = out
+    for (w, h) in ((4, 4), (8, 8), (16, 16), (32, 32), (4, 8), (8, 4), (16, 32), (32, 16), (4, 16), (16, 4), (8, 32), (32, 8), (8, 16), (16, 8)):
+        coeff = rng.integers(-300, 301, size=(3, h, w)).astype(np.int32)
+        coeff[1] = rng.integers(-(1 << 20), 1 << 20, size=(h, w)); coeff[1, 0, 0] = -(1 << 31) + 1; coeff[1, 0, 1] = (1 << 31) - 1; coeff[2] = 0
+        size = (w + 4) * (h + 6) + 16
+        lv = np.full((3, size), 0xAA, np.uint8)
+        for i in range(3):
+            R.av1_txb_init_levels_c(ptr(coeff[i]), c_int(w), c_int(h), ctypes.c_void_p(lv[i].ctypes.data + 2 * (w + 4)))
+        d[f"lv_{w}x{h}_coeff"] = coeff; d[f"lv_{w}x{h}_levels"] = lv
+    np.savez_compressed(os.path.join(HERE, "cfl_levels.npz"), **d)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                    # one family only: python make_golden.py cfl_levels
+        globals()["gen_" + sys.argv[1]]()
+        sys.exit(0)
     gen_txfm()
     tabs = gen_tables()
     gen_quant(tabs)
     gen_pixel()
     gen_intra()
+    gen_cfl_levels()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -146,3 +146,41 @@ def test_intra_golden():
         assert np.array_equal(o, g[key]), key
         checked += 1
     assert checked > 500
+
+
+def test_cfl_levels_golden():
+    """oracle/cfl.c against the reference's scalar C outputs (tests/golden/make_golden.py gen_cfl_levels)."""
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "cfl_levels.npz"))
+    c_int = ctypes.c_int
+    n_cfl = n_lv = 0
+    for key in g.files:
+        if key.startswith("cfl_") and key.endswith("_luma"):
+            base = key[:-5]
+            wh, bd = base.split("_")[1], int(base.split("_")[2])
+            w, h = (int(v) for v in wh.split("x"))
+            luma = g[key]
+            for i in range(luma.shape[0]):
+                li = np.ascontiguousarray(luma[i])
+                q3 = np.full((32, 32), 77, np.int16)
+                O.svt_oracle_cfl_luma_subsampling_420(ptr(li), c_int(bd > 8), c_int(li.shape[1]), ptr(q3), c_int(2 * w), c_int(2 * h))
+                assert np.array_equal(q3, g[base + "_q3"][i]), (base, i)
+                O.svt_oracle_subtract_average(ptr(q3), c_int(w), c_int(h), c_int(w * h // 2), c_int(int(np.log2(w * h))))
+                assert np.array_equal(q3, g[base + "_ac"][i]), (base, i)
+                pred = np.ascontiguousarray(g[base + "_pred"][i])
+                out = np.zeros_like(pred)
+                O.svt_oracle_cfl_predict(ptr(q3), ptr(pred), c_int(pred.shape[1]), ptr(out), c_int(pred.shape[1]),
+                                         c_int(int(g[base + "_alpha"][i])), c_int(bd), c_int(w), c_int(h), c_int(bd > 8))
+                assert np.array_equal(out, g[base + "_dst"][i]), (base, i)
+                n_cfl += 1
+        if key.startswith("lv_") and key.endswith("_coeff"):
+            base = key[:-6]
+            w, h = (int(v) for v in base.split("_")[1].split("x"))
+            coeff = g[key]
+            for i in range(coeff.shape[0]):
+                lv = np.full((w + 4) * (h + 6) + 16, 0xAA, np.uint8)
+                O.svt_oracle_txb_init_levels(ptr(np.ascontiguousarray(coeff[i])), c_int(w), c_int(h),
+                                             ctypes.c_void_p(lv.ctypes.data + 2 * (w + 4)))
+                assert np.array_equal(lv, g[base + "_levels"][i]), (base, i)
+                n_lv += 1
+    assert n_cfl == 14 * 2 * 3 and n_lv == 14 * 3
