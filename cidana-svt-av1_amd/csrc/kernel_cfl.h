@@ -11,6 +11,27 @@
 
 namespace svtdev {
 
+// one (possibly unaligned) 16- / 8-byte global access: a plain memcpy from a 1- or 2-byte-aligned pointer is split
+// into dwordx2 / dword pieces by the compiler
+typedef unsigned cfl_v4u __attribute__((ext_vector_type(4), aligned(1)));
+typedef unsigned cfl_v2u __attribute__((ext_vector_type(2), aligned(1)));
+template <int BYTES, typename T>
+__device__ __forceinline__ void cfl_ld(T* dst, const void* src) {
+    static_assert(BYTES == 32 || BYTES == 16 || BYTES == 8, "chunk");
+    if constexpr (BYTES == 32) {
+        const cfl_v4u a = reinterpret_cast<const cfl_v4u*>(src)[0], b = reinterpret_cast<const cfl_v4u*>(src)[1];
+        __builtin_memcpy(dst, &a, 16); __builtin_memcpy(reinterpret_cast<char*>(dst) + 16, &b, 16);
+    } else if constexpr (BYTES == 16) { const cfl_v4u a = *reinterpret_cast<const cfl_v4u*>(src); __builtin_memcpy(dst, &a, 16); }
+    else { const cfl_v2u a = *reinterpret_cast<const cfl_v2u*>(src); __builtin_memcpy(dst, &a, 8); }
+}
+template <int BYTES, typename T>
+__device__ __forceinline__ void cfl_st(void* dst, const T* src) {
+    static_assert(BYTES == 16 || BYTES == 8 || BYTES == 4, "chunk");
+    if constexpr (BYTES == 16) { cfl_v4u a; __builtin_memcpy(&a, src, 16); *reinterpret_cast<cfl_v4u*>(dst) = a; }
+    else if constexpr (BYTES == 8) { cfl_v2u a; __builtin_memcpy(&a, src, 8); *reinterpret_cast<cfl_v2u*>(dst) = a; }
+    else { unsigned a; __builtin_memcpy(&a, src, 4); __builtin_memcpy(dst, &a, 4); }
+}
+
 // ---------------------------------------------------------------------------
 // cfl_ac_kernel<IN> — per chroma block: 2x2 luma sums * 2 (Q3), optionally minus the block average.
 //   IN = 0: 8-bit luma, 1: 16-bit luma, 2: the Q3 buffer itself (subtract_average alone, in place).
@@ -44,10 +65,10 @@ __global__ __launch_bounds__(256) void cfl_ac_kernel(const void* __restrict__ lu
         if (on) {
             if (IN == 2) {
                 const int16_t* s = qb + (size_t)row * q3_line + col;
-                if (cs == 8) { short vv[8]; __builtin_memcpy(vv, s, 16);
+                if (cs == 8) { short vv[8]; cfl_ld<16>(vv, s);
 #pragma unroll
                     for (int i = 0; i < 8; i++) v[p][i] = vv[i];
-                } else { short vv[4]; __builtin_memcpy(vv, s, 8);
+                } else { short vv[4]; cfl_ld<8>(vv, s);
 #pragma unroll
                     for (int i = 0; i < 4; i++) v[p][i] = vv[i];
                 }
@@ -59,16 +80,16 @@ __global__ __launch_bounds__(256) void cfl_ac_kernel(const void* __restrict__ lu
                 if (IN == 0) {
                     const uint8_t* s = reinterpret_cast<const uint8_t*>(luma) + base;
                     uint8_t r0[16], r1[16];
-                    if (cs == 8) { __builtin_memcpy(r0, s, 16); __builtin_memcpy(r1, s + luma_stride, 16); }
-                    else { __builtin_memcpy(r0, s, 8); __builtin_memcpy(r1, s + luma_stride, 8); }
+                    if (cs == 8) { cfl_ld<16>(r0, s); cfl_ld<16>(r1, s + luma_stride); }
+                    else { cfl_ld<8>(r0, s); cfl_ld<8>(r1, s + luma_stride); }
 #pragma unroll
                     for (int i = 0; i < 8; i++)
                         if (i < (int)cs) v[p][i] = ((int)r0[2 * i] + r0[2 * i + 1] + r1[2 * i] + r1[2 * i + 1]) << 1;
                 } else {
                     const uint16_t* s = reinterpret_cast<const uint16_t*>(luma) + base;
                     uint16_t r0[16], r1[16];
-                    if (cs == 8) { __builtin_memcpy(r0, s, 32); __builtin_memcpy(r1, s + luma_stride, 32); }
-                    else { __builtin_memcpy(r0, s, 16); __builtin_memcpy(r1, s + luma_stride, 16); }
+                    if (cs == 8) { cfl_ld<32>(r0, s); cfl_ld<32>(r1, s + luma_stride); }
+                    else { cfl_ld<16>(r0, s); cfl_ld<16>(r1, s + luma_stride); }
 #pragma unroll
                     for (int i = 0; i < 8; i++)
                         if (i < (int)cs) v[p][i] = (int)(int16_t)(uint16_t)(((int)r0[2 * i] + r0[2 * i + 1] + r1[2 * i] + r1[2 * i + 1]) << 1);
@@ -92,7 +113,7 @@ __global__ __launch_bounds__(256) void cfl_ac_kernel(const void* __restrict__ lu
 #pragma unroll
             for (int i = 0; i < 8; i++) o[i] = (short)(v[p][i] - avg);
             int16_t* d = qb + (size_t)row * q3_line + col;
-            if (cs == 8) __builtin_memcpy(d, o, 16); else __builtin_memcpy(d, o, 8);
+            if (cs == 8) cfl_st<16>(d, o); else cfl_st<8>(d, o);
         }
     }
 }
@@ -121,8 +142,11 @@ __global__ __launch_bounds__(256) void cfl_predict_kernel(const int16_t* __restr
     PixT pv[8], ov[8];
     const int16_t* s = ac + (size_t)blk * q3_block_pitch + (size_t)row * q3_line + col;
     const PixT* pp = pred + pb + (size_t)row * pred_stride + col;
-    if (cs == 8) { __builtin_memcpy(q, s, 16); __builtin_memcpy(pv, pp, 8 * sizeof(PixT)); }
-    else { __builtin_memcpy(q, s, 8); __builtin_memcpy(pv, pp, 4 * sizeof(PixT)); }
+    if (cs == 8) { cfl_ld<16>(q, s); cfl_ld<8 * sizeof(PixT)>(pv, pp); }
+    else {
+        cfl_ld<8>(q, s);
+        if constexpr (sizeof(PixT) == 2) cfl_ld<8>(pv, pp); else __builtin_memcpy(pv, pp, 4);
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         if (i < (int)cs) {
@@ -134,7 +158,7 @@ __global__ __launch_bounds__(256) void cfl_predict_kernel(const int16_t* __restr
         }
     }
     PixT* dp = dst + db + (size_t)row * dst_stride + col;
-    if (cs == 8) __builtin_memcpy(dp, ov, 8 * sizeof(PixT)); else __builtin_memcpy(dp, ov, 4 * sizeof(PixT));
+    if (cs == 8) cfl_st<8 * sizeof(PixT)>(dp, ov); else cfl_st<4 * sizeof(PixT)>(dp, ov);
 }
 
 // ---------------------------------------------------------------------------
@@ -142,6 +166,7 @@ __global__ __launch_bounds__(256) void cfl_predict_kernel(const int16_t* __restr
 // min(|coeff|, 127) with 4 zero bytes of right padding, four zero rows + 16 zero bytes.  A lane writes one
 // dword of the buffer (W + 4 is a multiple of 4, so a dword never straddles a row) from one 16-byte load.
 // ---------------------------------------------------------------------------
+template <bool WIDE>
 __global__ __launch_bounds__(256) void txb_init_levels_kernel(const int32_t* __restrict__ coeff, size_t coeff_block_pitch,
                                                               uint8_t* __restrict__ levels_buf, size_t levels_block_pitch,
                                                               uint32_t w, uint32_t h, uint32_t lpb, uint32_t ndw, uint32_t row_magic,
@@ -154,7 +179,7 @@ __global__ __launch_bounds__(256) void txb_init_levels_kernel(const int32_t* __r
     const uint32_t dpr = (w + 4) >> 2;                       // dwords per row
     const int32_t* cb = coeff + (size_t)blk * coeff_block_pitch;
     uint32_t* ob = reinterpret_cast<uint32_t*>(levels_buf + (size_t)blk * levels_block_pitch);
-    for (uint32_t d = l; d < ndw; d += lpb) {
+    auto dword = [&](uint32_t d) -> uint32_t {
         const uint32_t r = __umulhi(d, row_magic), cq = d - r * dpr;          // d / dpr, d % dpr
         uint32_t out = 0;
         const uint32_t y = r - 2;                            // TX_PAD_TOP rows above (wraps to huge for r < 2)
@@ -169,7 +194,21 @@ __global__ __launch_bounds__(256) void txb_init_levels_kernel(const int32_t* __r
                 out |= (a > 127u ? 127u : a) << (8 * i);
             }
         }
-        ob[d] = out;
+        return out;
+    };
+    if (WIDE) {        // 16 output bytes per lane (block buffers 16-byte aligned): up to four 16-byte loads, one 16-byte store
+        for (uint32_t d = 4 * l; d < ndw; d += 4 * lpb) {
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[k] = dword(min(d + k, ndw - 1));
+            if (d + 4 <= ndw) *reinterpret_cast<uint4*>(ob + d) = make_uint4(o[0], o[1], o[2], o[3]);
+            else {
+#pragma unroll
+                for (int k = 0; k < 3; k++) if (d + k < ndw) ob[d + k] = o[k];
+            }
+        }
+    } else {
+        for (uint32_t d = l; d < ndw; d += lpb) ob[d] = dword(d);
     }
 }
 

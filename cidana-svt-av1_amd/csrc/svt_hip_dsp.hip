@@ -1021,14 +1021,20 @@ extern "C" int svt_hip_txb_init_levels_batch(const int32_t* d_coeff, size_t coef
         return set_err(SVT_HIP_ERR_INVALID, "levels buffer: %zu B per block (need >= %u, multiple of 4, 4-byte aligned)", levels_block_pitch, bytes);
     if (coeff_block_pitch < (size_t)width * height) return set_err(SVT_HIP_ERR_INVALID, "coeff_block_pitch %zu", coeff_block_pitch);
     const uint32_t ndw = bytes >> 2, dpr = (width + 4) >> 2;
+    const bool wide = (levels_block_pitch & 15) == 0 && ((uintptr_t)d_levels_buf & 15) == 0;
+    const uint32_t items = wide ? (ndw + 3) / 4 : ndw;
     uint32_t lpb = 1;
-    while (lpb < ndw && lpb < 256) lpb <<= 1;
+    while (lpb < items && lpb < 256) lpb <<= 1;
     const uint32_t slots = 256 / lpb;
     const size_t grid = (nblocks + slots - 1) / slots;
     if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
     const uint32_t row_magic = (uint32_t)(0x100000000ull / dpr) + 1u;
-    hipLaunchKernelGGL(txb_init_levels_kernel, dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_coeff, coeff_block_pitch,
-                       d_levels_buf, levels_block_pitch, width, height, lpb, ndw, row_magic, (uint32_t)nblocks);
+    if (wide)
+        hipLaunchKernelGGL(txb_init_levels_kernel<true>, dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_coeff, coeff_block_pitch,
+                           d_levels_buf, levels_block_pitch, width, height, lpb, ndw, row_magic, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL(txb_init_levels_kernel<false>, dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_coeff, coeff_block_pitch,
+                           d_levels_buf, levels_block_pitch, width, height, lpb, ndw, row_magic, (uint32_t)nblocks);
     return launch_status("txb_init_levels");
 }
 

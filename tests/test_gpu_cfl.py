@@ -54,9 +54,12 @@ def test_txb_init_levels_golden(dsp, w, h):
     coeff = g[f"lv_{w}x{h}_coeff"]
     n = coeff.shape[0]
     size = (w + 4) * (h + 6) + 16
-    buf = torch.full((n, size), 0x55, dtype=torch.uint8, device="cuda")
-    dsp.txb_init_levels(dev(coeff.reshape(n, -1)), w, h, buf)
-    assert np.array_equal(buf.cpu().numpy(), g[f"lv_{w}x{h}_levels"])
+    for pitch in ((size + 15) // 16 * 16, (size + 15) // 16 * 16 + 4):       # 16-byte stores / dword stores
+        buf = torch.full((n, pitch), 0x55, dtype=torch.uint8, device="cuda")
+        dsp.txb_init_levels(dev(coeff.reshape(n, -1)), w, h, buf)
+        got = buf.cpu().numpy()
+        assert np.array_equal(got[:, :size], g[f"lv_{w}x{h}_levels"])
+        assert (got[:, size:] == 0x55).all()                                  # slack between buffers untouched
 
 
 @pytest.mark.parametrize("w,h,bd", [(4, 4, 8), (8, 8, 8), (16, 16, 10), (32, 32, 8), (32, 32, 12), (16, 8, 8), (8, 32, 10), (4, 16, 12)])
@@ -101,7 +104,7 @@ def test_txb_init_levels_at_scale(dsp):
         n = 301
         coeff = rng.integers(-200, 201, size=(n, h * w)).astype(np.int32)
         coeff[::7] *= 1 << 16
-        pitch = (w + 4) * (h + 6) + 16 + 8       # a pitch larger than the buffer: the slack is not touched
+        pitch = ((w + 4) * (h + 6) + 16 + 8 + 15) // 16 * 16      # 16-byte-aligned buffers; the slack is not touched
         buf = torch.full((n, pitch), 0x77, dtype=torch.uint8, device="cuda")
         dsp.txb_init_levels(dev(coeff), w, h, buf)
         got = buf.cpu().numpy()
@@ -110,7 +113,7 @@ def test_txb_init_levels_at_scale(dsp):
             O.svt_oracle_txb_init_levels(ptr(coeff[i]), c_int(w), c_int(h), ctypes.c_void_p(lv.ctypes.data + 2 * (w + 4)))
             assert np.array_equal(got[i], lv), (w, h, i)
         # size-independent property on every block: the interior equals min(|c|, 127), everything else is zero
-        body = got[:, :pitch - 8 - 16].reshape(n, h + 6, w + 4)
+        body = got[:, :(w + 4) * (h + 6)].reshape(n, h + 6, w + 4)
         assert np.array_equal(body[:, 2:2 + h, :w], np.minimum(np.abs(coeff.astype(np.int64)), 127).astype(np.uint8).reshape(n, h, w))
         assert not body[:, :2].any() and not body[:, 2 + h:].any() and not body[:, :, w:].any()
 

@@ -159,6 +159,28 @@ if want("intra"):
         rec(f"intra_{nm}_32x32_u8", n, 1024 + 2 * 65, ms)
     del ab, lf, out
 # ME 85-PU search, 1080p worth of SBs
+if want("cfl"):
+    # K11 + level map: algorithmic bytes per chroma block, compact Q3 layout (line = W) for the chain
+    for (w, h, n) in ((16, 16, 1 << 21), (8, 8, 1 << 22), (32, 32, 1 << 19)):
+        luma = torch.randint(0, 256, (n, 2 * h, 2 * w), dtype=torch.uint8, device=dev)
+        q3 = torch.empty((n, h, w), dtype=torch.int16, device=dev)
+        pr = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=dev)
+        al = torch.randint(-16, 17, (n,), dtype=torch.int32, device=dev)
+        def f_ac():
+            dsp._check(dsp.lib.svt_hip_cfl_luma_subsampling_420_batch(dsp._p(luma), 2 * w, 4 * w * h, None, 0, dsp._p(q3), w, w * h,
+                                                                      2 * w, 2 * h, 1, n, dsp._stream()), "cfl_ac")
+        def f_pred():
+            dsp._check(dsp.lib.svt_hip_cfl_predict_batch(dsp._p(q3), w, w * h, dsp._p(pr), w, dsp._p(pr), w, None, dsp._p(al), 8, w, h, 0,
+                                                         n, dsp._stream()), "cfl_predict")
+        rec(f"cfl_luma_ac_{w}x{h}_u8(subsample+subtract_average)", n, 6 * w * h, timeit(f_ac))
+        rec(f"cfl_predict_{w}x{h}_u8(in place)", n, 4 * w * h + 4, timeit(f_pred))
+        del luma, q3, pr, al
+    for (w, h, n) in ((32, 32, 1 << 19), (16, 16, 1 << 21), (4, 4, 1 << 23)):
+        co = torch.randint(-300, 301, (n, w * h), dtype=torch.int32, device=dev)
+        size = (w + 4) * (h + 6) + 16
+        lv = torch.empty((n, (size + 15) // 16 * 16), dtype=torch.uint8, device=dev)       # 16-byte-aligned block buffers
+        rec(f"txb_init_levels_{w}x{h}", n, 4 * w * h + size, timeit(lambda: dsp.txb_init_levels(co, w, h, lv)))
+        del co, lv
 if want("me_sb"):
     for n, label in ((510, "1 ref"), (2040, "4 refs")):      # 510 SBs of a 1080p frame x reference pictures
         src = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 127, 128), dtype=torch.uint8, device=dev)
