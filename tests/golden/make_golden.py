@@ -289,6 +289,54 @@ def gen_cfl_levels():
     np.savez_compressed(os.path.join(HERE, "cfl_levels.npz"), **d)
 
 
+def ois_md_scan():
+    """(x, y, size) of the 85 blocks of a 64x64 SB in the reference's MD-scan (depth-first, z-order) order"""
+    out = []
+
+    def rec(x, y, s):
+        out.append((x, y, s))
+        if s > 8:
+            h = s // 2
+            for (dx, dy) in ((0, 0), (h, 0), (0, h), (h, h)):
+                rec(x + dx, y + dy, h)
+    rec(0, 0, 64)
+    return out
+
+
+def ois_raster_idx(x, y, s):
+    return {64: 0, 32: 1, 16: 5, 8: 21}[s] + (y // s) * (64 // s) + (x // s)
+
+
+OIS_CASES = [(0, 0, 0, 0, 1), (64, 64, 0, 0, 1), (192, 128, 0, 0, 1), (128, 64, 1, 0, 1), (64, 0, 0, 5, 1), (0, 64, 0, 4, 0),
+             (128, 128, 0, 0, 1), (192, 0, 0, 0, 1)]
+
+
+def gen_ois():
+    """Open-loop intra search: the outputs of the reference's OWN open_loop_intra_search_sb
+    (EbMotionEstimation.c:8694) run through oracle/ref_ois.c on a 200x136 picture (partial SBs at the right and
+    bottom edges), for SBs at the picture corner / edges / interior and the temporal-layer / preset switches."""
+    rng = np.random.default_rng(13601)
+    W, H, pad = 200, 136, 64
+    buf = rng.integers(0, 256, size=(H + 2 * pad, W + 2 * pad), dtype=np.uint8)
+    buf[pad + 64:pad + 128, pad + 64:pad + 128] //= 8           # a smooth region: ties between candidates
+    buf[pad:pad + 32, pad + 128:pad + 160] = 200
+    md = ois_md_scan()
+    d = {"pic": buf, "dims": np.array([W, H, pad], np.int32), "cases": np.array(OIS_CASES, np.int32)}
+    for k, (sx, sy, tl, ipm, isref) in enumerate(OIS_CASES):
+        valid = np.zeros(85, np.uint8)
+        for (x, y, s) in md:
+            valid[ois_raster_idx(x, y, s)] = sx + x + s <= W and sy + y + s <= H
+        cnt = np.zeros(85, np.uint8); best = np.zeros(85, np.int8); mode = np.zeros((85, 61), np.uint8)
+        delta = np.zeros((85, 61), np.int8); dist = np.zeros((85, 61), np.uint32)
+        rc = R.ref_ois_sb(ptr(buf), c_int(W + 2 * pad), c_int(pad), c_int(pad), c_int(W), c_int(H), c_int(sx), c_int(sy), ptr(valid),
+                          c_int(tl), c_int(ipm), c_int(isref), ptr(cnt), ptr(best), ptr(mode), ptr(delta), ptr(dist))
+        assert rc == 0
+        d[f"c{k}_valid"] = valid; d[f"c{k}_count"] = cnt; d[f"c{k}_best"] = best; d[f"c{k}_mode"] = mode
+        d[f"c{k}_delta"] = delta; d[f"c{k}_dist"] = dist
+    d["dr_intra_derivative"] = np.array((ctypes.c_uint16 * 90).in_dll(R, "dr_intra_derivative"), np.uint16)
+    np.savez_compressed(os.path.join(HERE, "ois.npz"), **d)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                    # one family only: python make_golden.py cfl_levels
         globals()["gen_" + sys.argv[1]]()
@@ -299,6 +347,7 @@ if __name__ == "__main__":
     gen_pixel()
     gen_intra()
     gen_cfl_levels()
+    gen_ois()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -184,3 +184,47 @@ def test_cfl_levels_golden():
                 assert np.array_equal(lv, g[base + "_levels"][i]), (base, i)
                 n_lv += 1
     assert n_cfl == 14 * 2 * 3 and n_lv == 14 * 3
+
+
+def ois_md_scan():
+    out = []
+
+    def rec(x, y, s):
+        out.append((x, y, s))
+        if s > 8:
+            h = s // 2
+            for (dx, dy) in ((0, 0), (h, 0), (0, h), (h, h)):
+                rec(x + dx, y + dy, h)
+    rec(0, 0, 64)
+    return out
+
+
+def ois_raster_idx(x, y, s):
+    return {64: 0, 32: 1, 16: 5, 8: 21}[s] + (y // s) * (64 // s) + (x // s)
+
+
+def test_ois_golden():
+    """oracle/ois.c against the reference's own open_loop_intra_search_sb outputs (tests/golden/ois.npz)."""
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "ois.npz"))
+    assert all(int(g["dr_intra_derivative"][a]) == O.svt_oracle_dr_intra_derivative(a) for a in range(90))
+    buf = np.ascontiguousarray(g["pic"]); W, H, pad = (int(v) for v in g["dims"])
+    stride = buf.shape[1]
+    pic = ctypes.c_void_p(buf.ctypes.data + pad * stride + pad)
+    md = ois_md_scan()
+    c_int = ctypes.c_int
+    blocks = 0
+    for k, (sx, sy, tl, ipm, isref) in enumerate(g["cases"].tolist()):
+        for i, (x, y, s) in enumerate(md):
+            if not g[f"c{k}_valid"][ois_raster_idx(x, y, s)]:
+                assert g[f"c{k}_count"][i] == 0
+                continue
+            m = np.zeros(61, np.uint8); d = np.zeros(61, np.int8); ds = np.zeros(61, np.uint32)
+            n = O.svt_oracle_ois_candidates(c_int(s), c_int(tl), c_int(ipm), c_int(isref), c_int(0), ptr(m), ptr(d))
+            bi = O.svt_oracle_ois_block(pic, c_int(stride), c_int(W), c_int(H), c_int(sx + x), c_int(sy + y), c_int(s), c_int(n),
+                                        ptr(m), ptr(d), ptr(ds))
+            assert n == int(g[f"c{k}_count"][i]) and bi == int(g[f"c{k}_best"][i]), (k, i)
+            assert np.array_equal(m[:n], g[f"c{k}_mode"][i, :n]) and np.array_equal(d[:n], g[f"c{k}_delta"][i, :n])
+            assert np.array_equal(ds[:n], g[f"c{k}_dist"][i, :n]), (k, i)
+            blocks += 1
+    assert blocks > 400
