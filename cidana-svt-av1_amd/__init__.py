@@ -95,6 +95,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
                                                  c_void_p]
     L.svt_hip_cfl_predict_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p,
                                             c_void_p, c_int, c_uint32, c_uint32, c_int, c_size_t, c_void_p]
+    L.svt_hip_ois_work_bytes.argtypes = [c_uint32, c_size_t]
+    L.svt_hip_ois_work_bytes.restype = c_size_t
+    L.svt_hip_ois_search_batch.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_int,
+                                           c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]
     L.svt_hip_txb_init_levels_batch.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_uint32, c_uint32, c_size_t, c_void_p]
     return L
 
@@ -341,6 +345,48 @@ class SvtHipDsp:
                                                               self._p(out), n, self._stream()),
                     "svt_hip_full_distortion32_batch")
         return out
+
+    # -- open-loop intra search (open_loop_intra_search_sb) --------------------------------
+    @staticmethod
+    def ois_candidates(bsize, temporal_layer_index=0, intra_pred_mode=0, is_used_as_reference=True):
+        """The candidate list the reference's loop enumerates for one block size (EbMotionEstimation.c:8747-8846,
+        8-bit): (modes uint8[], angle_deltas int8[]) in AV1 PredictionMode numbering."""
+        import numpy as np
+        last = 12
+        nd = 1 if intra_pred_mode >= 5 else (5 if bsize >= 8 else 1)
+        no_angular = temporal_layer_index > 0 or bsize > 16
+        if no_angular:
+            nd = 1
+        if not is_used_as_reference and intra_pred_mode >= 4:
+            last = 0
+        modes, deltas = [], []
+        for m in range(last + 1):
+            if 1 <= m <= 8:
+                if no_angular:
+                    continue
+                for k in range(nd):
+                    modes.append(m); deltas.append(0 if nd == 1 else k - (nd >> 1))
+            else:
+                modes.append(m); deltas.append(0)
+        return np.array(modes, np.uint8), np.array(deltas, np.int8)
+
+    def ois_search(self, pic, stride, width, height, xy, bsize, modes, angle_deltas):
+        """pic: uint8 tensor whose data_ptr() is picture sample (0, 0) (a view into the padded plane is fine);
+        xy: int32 [n] (x | y << 16).  -> (distortion int32 [n, ncand], best_index int8 [n])"""
+        import numpy as np
+        t = self.torch
+        n = xy.shape[0]
+        modes = np.ascontiguousarray(modes, np.uint8); angle_deltas = np.ascontiguousarray(angle_deltas, np.int8)
+        nc = int(modes.shape[0])
+        dist = t.zeros((n, nc), dtype=t.int32, device=xy.device)
+        best = t.zeros(n, dtype=t.int8, device=xy.device)
+        wb = self.lib.svt_hip_ois_work_bytes(bsize, n)
+        work = t.empty(max(wb, 1), dtype=t.uint8, device=xy.device)
+        self._check(self.lib.svt_hip_ois_search_batch(pic.data_ptr(), stride, width, height, self._p(xy), bsize,
+                                                       modes.ctypes.data, angle_deltas.ctypes.data, nc, self._p(dist),
+                                                       self._p(best), self._p(work), wb, n, self._stream()),
+                    "svt_hip_ois_search_batch")
+        return dist, best
 
     # -- K11 chroma from luma + level map ---------------------------------------------------
     CFL_BUF_LINE = 32

@@ -16,6 +16,7 @@
 #include "kernel_fused32.h"
 #include "kernel_intra.h"
 #include "kernel_me.h"
+#include "kernel_ois.h"
 #include "kernel_pixel.h"
 #include "kernel_txfm.h"
 #include "kernel_txfm_staged.h"
@@ -1364,6 +1365,96 @@ extern "C" void svt_hip_full_distortion_kernel_cbf_zero32_bits(int32_t* coeff, u
                                                                uint32_t area_width, uint32_t area_height) {
     dropin_dist32(1, coeff, coeff_stride, recon_coeff, recon_coeff_stride, distortion_result, area_width, area_height,
                   "svt_hip_full_distortion_kernel_cbf_zero32_bits");
+}
+
+// ---- open-loop intra search ----
+static size_t ois_nb_pitch(uint32_t bsize) { return (size_t)NB_ORIGIN + 4 * bsize + 16; }     // multiple of 16
+static size_t ois_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t svt_hip_ois_work_bytes(uint32_t bsize, size_t nblocks) {
+    if (bsize != 8 && bsize != 16 && bsize != 32 && bsize != 64) return 0;
+    return 2 * ois_align(nblocks * ois_nb_pitch(bsize)) + ois_align(nblocks) + ois_align(nblocks * (size_t)bsize * bsize);
+}
+
+// dr_intra_derivative (AV1 spec 7.11.2.4; reference EbIntraPrediction.c:299), non-zero entries
+static int ois_dr_derivative(int angle) {
+    static const uint16_t at[][2] = {{3, 1023}, {6, 547}, {9, 372}, {14, 273}, {17, 215}, {20, 178}, {23, 151}, {26, 132},
+                                     {29, 116}, {32, 102}, {36, 90}, {39, 80}, {42, 71}, {45, 64}, {48, 57}, {51, 51},
+                                     {54, 45}, {58, 40}, {61, 35}, {64, 31}, {67, 27}, {70, 23}, {73, 19}, {76, 15},
+                                     {81, 11}, {84, 7}, {87, 3}};
+    for (const auto& e : at)
+        if (e[0] == angle) return e[1];
+    return 0;
+}
+
+extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, uint32_t width, uint32_t height,
+                                        const uint32_t* d_xy, uint32_t bsize, const uint8_t* modes, const int8_t* angle_deltas,
+                                        int ncand, uint32_t* d_distortion, int8_t* d_best_index, void* d_work,
+                                        size_t work_bytes, size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_pic || !d_xy || !d_distortion || !d_best_index || !d_work || !modes || !angle_deltas) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (bsize != 8 && bsize != 16 && bsize != 32 && bsize != 64) return set_err(SVT_HIP_ERR_INVALID, "block size %u", bsize);
+    if (ncand <= 0 || ncand > 61) return set_err(SVT_HIP_ERR_INVALID, "%d candidates (1..61, MAX_OIS_CANDIDATES)", ncand);
+    if (width == 0 || height == 0 || width > 0xffffu || height > 0xffffu || stride < width) return set_err(SVT_HIP_ERR_INVALID, "picture %ux%u stride %u", width, height, stride);
+    if (work_bytes < svt_hip_ois_work_bytes(bsize, nblocks)) return set_err(SVT_HIP_ERR_INVALID, "work buffer: %zu B, need %zu", work_bytes, svt_hip_ois_work_bytes(bsize, nblocks));
+    if (nblocks > 0x7fffffffu / 256) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+    static const int mode_angle[13] = {0, 90, 180, 45, 135, 113, 157, 203, 67, 0, 0, 0, 0};      // mode_to_angle_map, EbCodingUnit.h:129
+    for (int c = 0; c < ncand; c++) {
+        if (modes[c] > 12) return set_err(SVT_HIP_ERR_INVALID, "candidate %d: prediction mode %u", c, modes[c]);
+        if (modes[c] >= 1 && modes[c] <= 8) {
+            const int a = mode_angle[modes[c]] + 3 * angle_deltas[c];
+            if (a <= 0 || a >= 270) return set_err(SVT_HIP_ERR_INVALID, "candidate %d: angle %d", c, a);
+            if (a != 90 && a != 180) {
+                const int d1 = a < 90 ? a : (a < 180 ? 180 - a : 270 - a), d2 = a < 180 && a > 90 ? a - 90 : d1;
+                if (!ois_dr_derivative(d1) || !ois_dr_derivative(d2)) return set_err(SVT_HIP_ERR_INVALID, "candidate %d: angle %d has no derivative", c, a);
+            }
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t pitch = ois_nb_pitch(bsize);
+    char* w = (char*)d_work;
+    uint8_t* d_above = (uint8_t*)w;
+    uint8_t* d_left = d_above + ois_align(nblocks * pitch);
+    uint8_t* d_dc = d_left + ois_align(nblocks * pitch);
+    uint8_t* d_pred = d_dc + ois_align(nblocks);
+    if (hipMemsetAsync(d_above, 0, 2 * ois_align(nblocks * pitch), st) != hipSuccess) return set_err(SVT_HIP_ERR_RUNTIME, "hipMemsetAsync");
+    {
+        const uint32_t slots = 256 / (2 * bsize);
+        hipLaunchKernelGGL(ois_gather_kernel, dim3((uint32_t)((nblocks + slots - 1) / slots)), dim3(256), 0, st, d_pic, stride, width,
+                           height, d_xy, bsize, d_above, d_left, (uint32_t)pitch, d_dc, (uint32_t)nblocks);
+        if (int rc = launch_status("ois_gather")) return rc;
+    }
+    const uint32_t sad_slots = 256 / (bsize * bsize / (bsize < 16 ? 8 : 16));
+    const uint32_t sad_grid = (uint32_t)((nblocks + sad_slots - 1) / sad_slots);
+    for (int c = 0; c < ncand; c++) {
+        const int m = modes[c];
+        if (m == 0) {        // DC_PRED under the availability rule: constant prediction
+            hipLaunchKernelGGL(ois_sad_kernel<1>, dim3(sad_grid), dim3(256), 0, st, d_pic, stride, d_xy, bsize, (const uint8_t*)nullptr,
+                               d_dc, d_distortion, (uint32_t)ncand, (uint32_t)c, (uint32_t)nblocks);
+        } else {
+            int mode, dx = 1, dy = 1;
+            if (m >= 1 && m <= 8) {                                           // dr_predictor, EbIntraPrediction.c:3352-3383
+                const int a = mode_angle[m] + 3 * angle_deltas[c];
+                if (a == 90) mode = SVT_INTRA_V;
+                else if (a == 180) mode = SVT_INTRA_H;
+                else if (a < 90) { mode = SVT_INTRA_Z1; dx = ois_dr_derivative(a); }
+                else if (a < 180) { mode = SVT_INTRA_Z2; dx = ois_dr_derivative(180 - a); dy = ois_dr_derivative(a - 90); }
+                else { mode = SVT_INTRA_Z3; dy = ois_dr_derivative(270 - a); }
+            } else {
+                mode = m == 9 ? SVT_INTRA_SMOOTH : m == 10 ? SVT_INTRA_SMOOTH_V : m == 11 ? SVT_INTRA_SMOOTH_H : SVT_INTRA_PAETH;
+            }
+            if (int rc = svt_hip_intra_pred_batch(d_pred, (int32_t)bsize, (size_t)bsize * bsize, nullptr, d_above, d_left, (int32_t)pitch,
+                                                  mode, (int)bsize, (int)bsize, 0, 0, dx, dy, 0, 8, nblocks, stream))
+                return rc;
+            hipLaunchKernelGGL(ois_sad_kernel<0>, dim3(sad_grid), dim3(256), 0, st, d_pic, stride, d_xy, bsize, d_pred,
+                               (const uint8_t*)nullptr, d_distortion, (uint32_t)ncand, (uint32_t)c, (uint32_t)nblocks);
+        }
+        if (int rc = launch_status("ois_sad")) return rc;
+    }
+    hipLaunchKernelGGL(ois_best_kernel, dim3((uint32_t)((nblocks + 255) / 256)), dim3(256), 0, st, d_distortion, (uint32_t)ncand,
+                       d_best_index, (uint32_t)nblocks);
+    return launch_status("ois_best");
 }
 
 // one intra block: stage [lo, hi) of above / left around the origin, predict, copy the block back

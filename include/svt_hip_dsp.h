@@ -293,6 +293,26 @@ int svt_hip_full_distortion32_batch(const int32_t *d_coeff, uint32_t coeff_strid
                                     uint32_t width, uint32_t height, int cbf_zero,
                                     uint64_t *d_out, size_t nblocks, void *stream);
 
+/* Open-loop intra search: open_loop_intra_search_sb, EbMotionEstimation.c:8694-8850,
+ * for all blocks of ONE size of a picture (or of many pictures' worth of blocks) in one call.
+ * d_pic points at picture sample (0, 0) (buffer_y + origin_y * stride_y + origin_x), width x height are
+ * the picture's; d_xy[i] = x | y << 16 is a block's origin (the reference's cu_origin_x / _y).  Per block:
+ * neighbour arrays gathered from the SOURCE picture exactly as update_neighbor_samples_array_open_loop does
+ * (EbIntraPrediction.c:4707-4773: 127 / 129 / 128 fill at picture borders), then for each of the ncand
+ * candidates (modes[c]: AV1 PredictionMode 0..12, angle_deltas[c]: -2..2 for the directional modes; HOST
+ * arrays - the list the reference's loop :8747-8846 enumerates for this block size) the prediction of
+ * intra_prediction_open_loop (:4778-4808: dr_predictor without edge filter / upsampling, DC by
+ * availability, the other predictors as is) and its SAD against the source block.
+ * d_distortion: uint32 [nblocks][ncand] (ois_candidate_t.distortion); d_best_index: int8 [nblocks]
+ * (ois_sb_results_t.best_distortion_index: first strict minimum below 64*64*255, else 0).
+ * d_work: scratch of svt_hip_ois_work_bytes(bsize, nblocks) bytes.  bsize 8 / 16 / 32 / 64, 8-bit. */
+size_t svt_hip_ois_work_bytes(uint32_t bsize, size_t nblocks);
+int svt_hip_ois_search_batch(const uint8_t *d_pic, uint32_t stride, uint32_t width, uint32_t height,
+                             const uint32_t *d_xy, uint32_t bsize, const uint8_t *modes,
+                             const int8_t *angle_deltas, int ncand, uint32_t *d_distortion,
+                             int8_t *d_best_index, void *d_work, size_t work_bytes, size_t nblocks,
+                             void *stream);
+
 /* K11 chroma-from-luma helpers of the encode pass (Av1EncodeLoop, EbCodingLoop.c:736-846) and the
  * entropy stage's level map - the remaining pieces of SURVEY.md 8(f) n3.
  *
