@@ -181,6 +181,21 @@ if want("cfl"):
         lv = torch.empty((n, (size + 15) // 16 * 16), dtype=torch.uint8, device=dev)       # 16-byte-aligned block buffers
         rec(f"txb_init_levels_{w}x{h}", n, 4 * w * h + size, timeit(lambda: dsp.txb_init_levels(co, w, h, lv)))
         del co, lv
+if want("ois"):
+    # open-loop intra search of a whole 1080p luma picture: every block of each size, the reference's candidate lists
+    W, H, pad = 1920, 1080, 64
+    plane = torch.randint(0, 256, (H + 2 * pad, W + 2 * pad), dtype=torch.uint8, device=dev)
+    pic = plane[pad:, pad:]
+    tot = 0.0
+    for bsize in (8, 16, 32, 64):
+        blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
+        xy = torch.from_numpy(np.array([(y << 16) | x for x, y in blocks], np.uint32).view(np.int32)).to(dev)
+        modes, deltas = dsp.ois_candidates(bsize)
+        ms = timeit(lambda: dsp.ois_search(pic, W + 2 * pad, W, H, xy, bsize, modes, deltas), iters=4)
+        tot += ms
+        rec(f"ois_search_1080p_{bsize}x{bsize}_{len(modes)}cand", len(blocks), bsize * bsize * (1 + 2 * len(modes)), ms,
+            {"candidate_predictions_per_s_M": round(len(blocks) * len(modes) / ms / 1e3, 1)})
+    print(json.dumps({"ois_search_1080p_all_sizes_ms": round(tot, 3)}), flush=True)
 if want("me_sb"):
     for n, label in ((510, "1 ref"), (2040, "4 refs")):      # 510 SBs of a 1080p frame x reference pictures
         src = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 127, 128), dtype=torch.uint8, device=dev)
