@@ -95,7 +95,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
                                                  c_void_p]
     L.svt_hip_cfl_predict_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p,
                                             c_void_p, c_int, c_uint32, c_uint32, c_int, c_size_t, c_void_p]
-    L.svt_hip_ois_work_bytes.argtypes = [c_uint32, c_size_t]
+    L.svt_hip_ois_work_bytes.argtypes = [c_uint32, c_int, c_size_t]
     L.svt_hip_ois_work_bytes.restype = c_size_t
     L.svt_hip_ois_search_batch.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_int,
                                            c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]
@@ -380,7 +380,7 @@ class SvtHipDsp:
         nc = int(modes.shape[0])
         dist = t.zeros((n, nc), dtype=t.int32, device=xy.device)
         best = t.zeros(n, dtype=t.int8, device=xy.device)
-        wb = self.lib.svt_hip_ois_work_bytes(bsize, n)
+        wb = self.lib.svt_hip_ois_work_bytes(bsize, nc, n)
         work = t.empty(max(wb, 1), dtype=t.uint8, device=xy.device)
         self._check(self.lib.svt_hip_ois_search_batch(pic.data_ptr(), stride, width, height, self._p(xy), bsize,
                                                        modes.ctypes.data, angle_deltas.ctypes.data, nc, self._p(dist),

@@ -4,8 +4,8 @@
 //                      a batch straight from the source picture, in the neighbour layout svt_hip_intra_pred_batch
 //                      reads, plus each block's DC value under the reference's availability rule
 //                      (dc_pred[x > 0][y > 0], EbIntraPrediction.c:4801);
-//   ois_sad_kernel     SAD of a dense prediction batch (or of the constant DC prediction) against the source
-//                      blocks in the picture -> one column of the [block][candidate] distortion matrix;
+//   ois_sad_kernel     SAD of every candidate's dense prediction batch (or of the constant DC prediction) against
+//                      the source blocks in the picture -> the [block][candidate] distortion matrix, one launch;
 //   ois_best_kernel    first strict minimum below 64*64*255 per block (EbMotionEstimation.c:8756, 8800-8803).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -60,11 +60,15 @@ __global__ __launch_bounds__(256) void ois_gather_kernel(const uint8_t* __restri
     }
 }
 
-// CONST = 1: the prediction is the block's DC value.  Lanes per block = B*B / min(B, 16) (8 .. 256).
-template <int CONST>
+// One launch for ALL candidates (blockIdx.y = candidate): pred holds ncand dense prediction batches back to back;
+// a candidate whose bit is set in const_mask is the block's DC value instead.  Lanes per block = B*B / min(B, 16).
 __global__ __launch_bounds__(256) void ois_sad_kernel(const uint8_t* __restrict__ pic, uint32_t stride, const uint32_t* __restrict__ xy,
-                                                      uint32_t bsize, const uint8_t* __restrict__ pred, const uint8_t* __restrict__ dc,
-                                                      uint32_t* __restrict__ dist, uint32_t ncand, uint32_t cand, uint32_t nblocks) {
+                                                      uint32_t bsize, const uint8_t* __restrict__ pred_all, size_t pred_cand_pitch,
+                                                      const uint8_t* __restrict__ dc, unsigned long long const_mask,
+                                                      uint32_t* __restrict__ dist, uint32_t ncand, uint32_t nblocks) {
+    const uint32_t cand = blockIdx.y;
+    const bool CONST = (const_mask >> cand) & 1ull;
+    const uint8_t* pred = pred_all + (size_t)cand * pred_cand_pitch;
     __shared__ uint32_t s_part[4];
     const uint32_t cs = bsize < 16 ? 8u : 16u;            // pixels per lane
     const uint32_t lpb = bsize * bsize / cs;

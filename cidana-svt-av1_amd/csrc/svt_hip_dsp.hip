@@ -1371,9 +1371,9 @@ extern "C" void svt_hip_full_distortion_kernel_cbf_zero32_bits(int32_t* coeff, u
 static size_t ois_nb_pitch(uint32_t bsize) { return (size_t)NB_ORIGIN + 4 * bsize + 16; }     // multiple of 16
 static size_t ois_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-extern "C" size_t svt_hip_ois_work_bytes(uint32_t bsize, size_t nblocks) {
-    if (bsize != 8 && bsize != 16 && bsize != 32 && bsize != 64) return 0;
-    return 2 * ois_align(nblocks * ois_nb_pitch(bsize)) + ois_align(nblocks) + ois_align(nblocks * (size_t)bsize * bsize);
+extern "C" size_t svt_hip_ois_work_bytes(uint32_t bsize, int ncand, size_t nblocks) {
+    if ((bsize != 8 && bsize != 16 && bsize != 32 && bsize != 64) || ncand <= 0 || ncand > 61) return 0;
+    return 2 * ois_align(nblocks * ois_nb_pitch(bsize)) + ois_align(nblocks) + (size_t)ncand * ois_align(nblocks * (size_t)bsize * bsize);
 }
 
 // dr_intra_derivative (AV1 spec 7.11.2.4; reference EbIntraPrediction.c:299), non-zero entries
@@ -1397,7 +1397,7 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
     if (bsize != 8 && bsize != 16 && bsize != 32 && bsize != 64) return set_err(SVT_HIP_ERR_INVALID, "block size %u", bsize);
     if (ncand <= 0 || ncand > 61) return set_err(SVT_HIP_ERR_INVALID, "%d candidates (1..61, MAX_OIS_CANDIDATES)", ncand);
     if (width == 0 || height == 0 || width > 0xffffu || height > 0xffffu || stride < width) return set_err(SVT_HIP_ERR_INVALID, "picture %ux%u stride %u", width, height, stride);
-    if (work_bytes < svt_hip_ois_work_bytes(bsize, nblocks)) return set_err(SVT_HIP_ERR_INVALID, "work buffer: %zu B, need %zu", work_bytes, svt_hip_ois_work_bytes(bsize, nblocks));
+    if (work_bytes < svt_hip_ois_work_bytes(bsize, ncand, nblocks)) return set_err(SVT_HIP_ERR_INVALID, "work buffer: %zu B, need %zu", work_bytes, svt_hip_ois_work_bytes(bsize, ncand, nblocks));
     if (nblocks > 0x7fffffffu / 256) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
     static const int mode_angle[13] = {0, 90, 180, 45, 135, 113, 157, 203, 67, 0, 0, 0, 0};      // mode_to_angle_map, EbCodingUnit.h:129
     for (int c = 0; c < ncand; c++) {
@@ -1425,31 +1425,32 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
                            height, d_xy, bsize, d_above, d_left, (uint32_t)pitch, d_dc, (uint32_t)nblocks);
         if (int rc = launch_status("ois_gather")) return rc;
     }
-    const uint32_t sad_slots = 256 / (bsize * bsize / (bsize < 16 ? 8 : 16));
-    const uint32_t sad_grid = (uint32_t)((nblocks + sad_slots - 1) / sad_slots);
+    // every candidate's prediction into its own dense batch, then ONE SAD launch over (block, candidate)
+    const size_t cand_pitch = ois_align(nblocks * (size_t)bsize * bsize);
+    unsigned long long const_mask = 0;
     for (int c = 0; c < ncand; c++) {
         const int m = modes[c];
-        if (m == 0) {        // DC_PRED under the availability rule: constant prediction
-            hipLaunchKernelGGL(ois_sad_kernel<1>, dim3(sad_grid), dim3(256), 0, st, d_pic, stride, d_xy, bsize, (const uint8_t*)nullptr,
-                               d_dc, d_distortion, (uint32_t)ncand, (uint32_t)c, (uint32_t)nblocks);
+        if (m == 0) { const_mask |= 1ull << c; continue; }     // DC_PRED under the availability rule: constant prediction
+        int mode, dx = 1, dy = 1;
+        if (m >= 1 && m <= 8) {                                               // dr_predictor, EbIntraPrediction.c:3352-3383
+            const int a = mode_angle[m] + 3 * angle_deltas[c];
+            if (a == 90) mode = SVT_INTRA_V;
+            else if (a == 180) mode = SVT_INTRA_H;
+            else if (a < 90) { mode = SVT_INTRA_Z1; dx = ois_dr_derivative(a); }
+            else if (a < 180) { mode = SVT_INTRA_Z2; dx = ois_dr_derivative(180 - a); dy = ois_dr_derivative(a - 90); }
+            else { mode = SVT_INTRA_Z3; dy = ois_dr_derivative(270 - a); }
         } else {
-            int mode, dx = 1, dy = 1;
-            if (m >= 1 && m <= 8) {                                           // dr_predictor, EbIntraPrediction.c:3352-3383
-                const int a = mode_angle[m] + 3 * angle_deltas[c];
-                if (a == 90) mode = SVT_INTRA_V;
-                else if (a == 180) mode = SVT_INTRA_H;
-                else if (a < 90) { mode = SVT_INTRA_Z1; dx = ois_dr_derivative(a); }
-                else if (a < 180) { mode = SVT_INTRA_Z2; dx = ois_dr_derivative(180 - a); dy = ois_dr_derivative(a - 90); }
-                else { mode = SVT_INTRA_Z3; dy = ois_dr_derivative(270 - a); }
-            } else {
-                mode = m == 9 ? SVT_INTRA_SMOOTH : m == 10 ? SVT_INTRA_SMOOTH_V : m == 11 ? SVT_INTRA_SMOOTH_H : SVT_INTRA_PAETH;
-            }
-            if (int rc = svt_hip_intra_pred_batch(d_pred, (int32_t)bsize, (size_t)bsize * bsize, nullptr, d_above, d_left, (int32_t)pitch,
-                                                  mode, (int)bsize, (int)bsize, 0, 0, dx, dy, 0, 8, nblocks, stream))
-                return rc;
-            hipLaunchKernelGGL(ois_sad_kernel<0>, dim3(sad_grid), dim3(256), 0, st, d_pic, stride, d_xy, bsize, d_pred,
-                               (const uint8_t*)nullptr, d_distortion, (uint32_t)ncand, (uint32_t)c, (uint32_t)nblocks);
+            mode = m == 9 ? SVT_INTRA_SMOOTH : m == 10 ? SVT_INTRA_SMOOTH_V : m == 11 ? SVT_INTRA_SMOOTH_H : SVT_INTRA_PAETH;
         }
+        if (int rc = svt_hip_intra_pred_batch(d_pred + (size_t)c * cand_pitch, (int32_t)bsize, (size_t)bsize * bsize, nullptr, d_above,
+                                              d_left, (int32_t)pitch, mode, (int)bsize, (int)bsize, 0, 0, dx, dy, 0, 8, nblocks, stream))
+            return rc;
+    }
+    {
+        const uint32_t sad_slots = 256 / (bsize * bsize / (bsize < 16 ? 8 : 16));
+        const uint32_t sad_grid = (uint32_t)((nblocks + sad_slots - 1) / sad_slots);
+        hipLaunchKernelGGL(ois_sad_kernel, dim3(sad_grid, (uint32_t)ncand), dim3(256), 0, st, d_pic, stride, d_xy, bsize, d_pred, cand_pitch,
+                           d_dc, const_mask, d_distortion, (uint32_t)ncand, (uint32_t)nblocks);
         if (int rc = launch_status("ois_sad")) return rc;
     }
     hipLaunchKernelGGL(ois_best_kernel, dim3((uint32_t)((nblocks + 255) / 256)), dim3(256), 0, st, d_distortion, (uint32_t)ncand,

@@ -305,8 +305,9 @@ int svt_hip_full_distortion32_batch(const int32_t *d_coeff, uint32_t coeff_strid
  * availability, the other predictors as is) and its SAD against the source block.
  * d_distortion: uint32 [nblocks][ncand] (ois_candidate_t.distortion); d_best_index: int8 [nblocks]
  * (ois_sb_results_t.best_distortion_index: first strict minimum below 64*64*255, else 0).
- * d_work: scratch of svt_hip_ois_work_bytes(bsize, nblocks) bytes.  bsize 8 / 16 / 32 / 64, 8-bit. */
-size_t svt_hip_ois_work_bytes(uint32_t bsize, size_t nblocks);
+ * d_work: scratch of svt_hip_ois_work_bytes(bsize, ncand, nblocks) bytes (neighbour arrays + one dense
+ * prediction batch per candidate: split very large batches).  bsize 8 / 16 / 32 / 64, 8-bit. */
+size_t svt_hip_ois_work_bytes(uint32_t bsize, int ncand, size_t nblocks);
 int svt_hip_ois_search_batch(const uint8_t *d_pic, uint32_t stride, uint32_t width, uint32_t height,
                              const uint32_t *d_xy, uint32_t bsize, const uint8_t *modes,
                              const int8_t *angle_deltas, int ncand, uint32_t *d_distortion,

@@ -81,9 +81,9 @@ def test_ois_argument_errors(dsp):
     z = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
     p = z.data_ptr()
     m = np.array([0, 1], np.uint8); d = np.array([0, 9], np.int8)
-    wb = L.svt_hip_ois_work_bytes(8, 4)
-    assert wb > 0 and L.svt_hip_ois_work_bytes(12, 4) == 0
+    wb = L.svt_hip_ois_work_bytes(8, 2, 4)
+    assert wb > 0 and L.svt_hip_ois_work_bytes(12, 2, 4) == 0 and L.svt_hip_ois_work_bytes(8, 62, 4) == 0
     assert L.svt_hip_ois_search_batch(p, 64, 64, 64, p, 12, m.ctypes.data, d.ctypes.data, 1, p, p, p, wb, 4, None) != 0       # size
     assert L.svt_hip_ois_search_batch(p, 64, 64, 64, p, 8, m.ctypes.data, d.ctypes.data, 2, p, p, p, wb, 4, None) != 0        # 90 + 27 has no derivative
-    assert L.svt_hip_ois_search_batch(p, 64, 64, 64, p, 8, m.ctypes.data, d.ctypes.data, 1, p, p, p, wb - 1, 4, None) != 0    # work buffer
+    assert L.svt_hip_ois_search_batch(p, 64, 64, 64, p, 8, m.ctypes.data, d.ctypes.data, 1, p, p, p, L.svt_hip_ois_work_bytes(8, 1, 4) - 1, 4, None) != 0    # work buffer
     assert L.svt_hip_ois_search_batch(p, 64, 64, 64, p, 8, m.ctypes.data, d.ctypes.data, 1, p, p, p, wb, 0, None) == 0        # empty
