@@ -244,11 +244,25 @@ __device__ __forceinline__ uint32_t dir_lerp2(uint32_t pair, uint32_t w) {      
     return r >> 5;
 }
 
+// Several angles of one zone in one launch (the open-loop intra search runs up to 19 per zone on the same
+// neighbours): blockIdx.y selects (dx, dy) and the dense output batch `slot * batch_pitch` samples into dst.
+struct DirMulti {
+    int n;                       // 0: single-angle launch (dx, dy arguments)
+    int16_t dx[20], dy[20];
+    uint8_t slot[20];
+    size_t batch_pitch;
+};
+
 template <typename PixT, int MODE>
 __global__ __launch_bounds__(256) void intra_dir_kernel(
     PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
     const PixT* __restrict__ above_all, const PixT* __restrict__ left_all, int32_t nb_pitch, int bw, int bh,
-    int up_above, int up_left, int dx, int dy, int lim_a, int lim_l, int n_pad, int bd, uint32_t nblocks) {
+    int up_above, int up_left, int dx, int dy, int lim_a, int lim_l, int n_pad, int bd, uint32_t nblocks, const DirMulti multi) {
+    if (multi.n) {
+        const int k = (int)blockIdx.y;
+        dx = multi.dx[k]; dy = multi.dy[k];
+        dst += (size_t)multi.slot[k] * multi.batch_pitch;
+    }
     // interpolated values of in-range samples are in range; 16-bit input may carry out-of-range
     // samples, which clip_pixel_highbd (EbIntraPrediction.c:3394-3506) would clip: keep that
     const uint32_t maxv = (1u << bd) - 1;

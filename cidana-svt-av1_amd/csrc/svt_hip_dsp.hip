@@ -1046,11 +1046,27 @@ static bool intra_size_ok(int bw, int bh) {
     return m <= 4 * mn;     // the 19 TX sizes
 }
 
+static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pitch,
+                           const uint32_t* d_dst_offsets, const void* d_above, const void* d_left,
+                           int32_t nb_pitch, int mode, int bw, int bh, int upsample_above,
+                           int upsample_left, int dx, int dy, int is_16bit, int bd, size_t nblocks,
+                           void* stream, const DirMulti* multi);
+
 extern "C" int svt_hip_intra_pred_batch(void* d_dst, int32_t dst_stride, size_t dst_block_pitch,
                                         const uint32_t* d_dst_offsets, const void* d_above, const void* d_left,
                                         int32_t nb_pitch, int mode, int bw, int bh, int upsample_above,
                                         int upsample_left, int dx, int dy, int is_16bit, int bd, size_t nblocks,
                                         void* stream) {
+    return intra_pred_impl(d_dst, dst_stride, dst_block_pitch, d_dst_offsets, d_above, d_left, nb_pitch, mode, bw, bh,
+                           upsample_above, upsample_left, dx, dy, is_16bit, bd, nblocks, stream, nullptr);
+}
+
+// multi (directional modes only): several (dx, dy) of the same zone in one launch, see DirMulti
+static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pitch,
+                           const uint32_t* d_dst_offsets, const void* d_above, const void* d_left,
+                           int32_t nb_pitch, int mode, int bw, int bh, int upsample_above,
+                           int upsample_left, int dx, int dy, int is_16bit, int bd, size_t nblocks,
+                           void* stream, const DirMulti* multi) {
     if (int rc = require_init()) return rc;
     if (nblocks == 0) return SVT_HIP_OK;
     if (!d_dst || !d_above || !d_left) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
@@ -1082,10 +1098,12 @@ extern "C" int svt_hip_intra_pred_batch(void* d_dst, int32_t dst_stride, size_t 
         const int n_pad = (lim_a > lim_l ? lim_a : lim_l) + ((16 / es) << up) + 3;
         const size_t slots = per_block >= 256 ? 1 : 256 / per_block;
         const size_t shmem = slots * 2 * (size_t)((n_pad + 7) & ~7) * 4;            // pair dwords (see the kernel)
+        DirMulti dm;
+        if (multi) dm = *multi; else dm.n = 0;
 #define IDL(T, M)                                                                                                     \
-    hipLaunchKernelGGL((intra_dir_kernel<T, M>), dim3((uint32_t)grid), dim3(256), shmem, s, (T*)d_dst, dst_stride,        \
+    hipLaunchKernelGGL((intra_dir_kernel<T, M>), dim3((uint32_t)grid, (uint32_t)(dm.n ? dm.n : 1)), dim3(256), shmem, s, (T*)d_dst, dst_stride, \
                        dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh,            \
-                       upsample_above, upsample_left, dx, dy, lim_a, lim_l, n_pad, bd, (uint32_t)nblocks)
+                       upsample_above, upsample_left, dx, dy, lim_a, lim_l, n_pad, bd, (uint32_t)nblocks, dm)
 #define IDM(T)                                                                                                        \
     switch (mode) {                                                                                                   \
     case SVT_INTRA_Z1: IDL(T, IM_Z1); break; case SVT_INTRA_Z2: IDL(T, IM_Z2); break; default: IDL(T, IM_Z3); break;  \
@@ -1425,27 +1443,48 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
                            height, d_xy, bsize, d_above, d_left, (uint32_t)pitch, d_dc, (uint32_t)nblocks);
         if (int rc = launch_status("ois_gather")) return rc;
     }
-    // every candidate's prediction into its own dense batch, then ONE SAD launch over (block, candidate)
+    // every candidate's prediction into its own dense batch, then ONE SAD launch over (block, candidate).  The
+    // directional candidates of one zone (up to 19) share one launch (DirMulti): 9 prediction launches for the
+    // reference's 45-candidate list instead of 44.
     const size_t cand_pitch = ois_align(nblocks * (size_t)bsize * bsize);
     unsigned long long const_mask = 0;
+    DirMulti zone[3];
+    for (auto& z : zone) { z.n = 0; z.batch_pitch = cand_pitch; }
     for (int c = 0; c < ncand; c++) {
         const int m = modes[c];
         if (m == 0) { const_mask |= 1ull << c; continue; }     // DC_PRED under the availability rule: constant prediction
-        int mode, dx = 1, dy = 1;
+        int mode = -1;
         if (m >= 1 && m <= 8) {                                               // dr_predictor, EbIntraPrediction.c:3352-3383
             const int a = mode_angle[m] + 3 * angle_deltas[c];
             if (a == 90) mode = SVT_INTRA_V;
             else if (a == 180) mode = SVT_INTRA_H;
-            else if (a < 90) { mode = SVT_INTRA_Z1; dx = ois_dr_derivative(a); }
-            else if (a < 180) { mode = SVT_INTRA_Z2; dx = ois_dr_derivative(180 - a); dy = ois_dr_derivative(a - 90); }
-            else { mode = SVT_INTRA_Z3; dy = ois_dr_derivative(270 - a); }
+            else {
+                const int zi = a < 90 ? 0 : (a < 180 ? 1 : 2);
+                DirMulti& z = zone[zi];
+                if (z.n == 20) {                                              // flush a full group (longer candidate lists)
+                    if (int rc = intra_pred_impl(d_pred, (int32_t)bsize, (size_t)bsize * bsize, nullptr, d_above, d_left, (int32_t)pitch,
+                                                 SVT_INTRA_Z1 + zi, (int)bsize, (int)bsize, 0, 0, 1, 1, 0, 8, nblocks, stream, &z))
+                        return rc;
+                    z.n = 0;
+                }
+                z.dx[z.n] = (int16_t)(zi == 0 ? ois_dr_derivative(a) : (zi == 1 ? ois_dr_derivative(180 - a) : 1));
+                z.dy[z.n] = (int16_t)(zi == 0 ? 1 : (zi == 1 ? ois_dr_derivative(a - 90) : ois_dr_derivative(270 - a)));
+                z.slot[z.n] = (uint8_t)c;
+                z.n++;
+                continue;
+            }
         } else {
             mode = m == 9 ? SVT_INTRA_SMOOTH : m == 10 ? SVT_INTRA_SMOOTH_V : m == 11 ? SVT_INTRA_SMOOTH_H : SVT_INTRA_PAETH;
         }
         if (int rc = svt_hip_intra_pred_batch(d_pred + (size_t)c * cand_pitch, (int32_t)bsize, (size_t)bsize * bsize, nullptr, d_above,
-                                              d_left, (int32_t)pitch, mode, (int)bsize, (int)bsize, 0, 0, dx, dy, 0, 8, nblocks, stream))
+                                              d_left, (int32_t)pitch, mode, (int)bsize, (int)bsize, 0, 0, 1, 1, 0, 8, nblocks, stream))
             return rc;
     }
+    for (int zi = 0; zi < 3; zi++)
+        if (zone[zi].n)
+            if (int rc = intra_pred_impl(d_pred, (int32_t)bsize, (size_t)bsize * bsize, nullptr, d_above, d_left, (int32_t)pitch,
+                                         SVT_INTRA_Z1 + zi, (int)bsize, (int)bsize, 0, 0, 1, 1, 0, 8, nblocks, stream, &zone[zi]))
+                return rc;
     {
         const uint32_t sad_slots = 256 / (bsize * bsize / (bsize < 16 ? 8 : 16));
         const uint32_t sad_grid = (uint32_t)((nblocks + sad_slots - 1) / sad_slots);
