@@ -245,7 +245,8 @@ __device__ __forceinline__ uint32_t dir_lerp2(uint32_t pair, uint32_t w) {      
 }
 
 // Several angles of one zone in one launch (the open-loop intra search runs up to 19 per zone on the same
-// neighbours): blockIdx.y selects (dx, dy) and the dense output batch `slot * batch_pitch` samples into dst.
+// neighbours): the block's edges are staged in LDS ONCE and the lanes loop over the angles; angle k goes to the dense
+// output batch `slot[k] * batch_pitch` samples into dst.
 struct DirMulti {
     int n;                       // 0: single-angle launch (dx, dy arguments)
     int16_t dx[20], dy[20];
@@ -258,11 +259,6 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
     PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
     const PixT* __restrict__ above_all, const PixT* __restrict__ left_all, int32_t nb_pitch, int bw, int bh,
     int up_above, int up_left, int dx, int dy, int lim_a, int lim_l, int n_pad, int bd, uint32_t nblocks, const DirMulti multi) {
-    if (multi.n) {
-        const int k = (int)blockIdx.y;
-        dx = multi.dx[k]; dy = multi.dy[k];
-        dst += (size_t)multi.slot[k] * multi.batch_pitch;
-    }
     // interpolated values of in-range samples are in range; 16-bit input may carry out-of-range
     // samples, which clip_pixel_highbd (EbIntraPrediction.c:3394-3506) would clip: keep that
     const uint32_t maxv = (1u << bd) - 1;
@@ -324,60 +320,64 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
     __syncthreads();
     const uint32_t* A = sa + NB_ORIGIN;
     const uint32_t* L = sl + NB_ORIGIN;
-    uint32_t px[PXL];
-    if (MODE == IM_Z1) {
-        const int x = dx * (r + 1);
-        const uint32_t sh = (uint32_t)(((x << up_above) & 0x3f) >> 1), w = (32u - sh) | (sh << 16);
-        // a start at or past max_base reads only padding (= above[max_base]), as the reference's tail fill does
-        const uint32_t* q = A + min((x >> (6 - up_above)) + (c0 << up_above), lim_a - NB_ORIGIN);
-        if (up_above == 0) {
+    auto emit = [&](const int dx, const int dy, PixT* __restrict__ dst) {
+        uint32_t px[PXL];
+        if (MODE == IM_Z1) {
+            const int x = dx * (r + 1);
+            const uint32_t sh = (uint32_t)(((x << up_above) & 0x3f) >> 1), w = (32u - sh) | (sh << 16);
+            // a start at or past max_base reads only padding (= above[max_base]), as the reference's tail fill does
+            const uint32_t* q = A + min((x >> (6 - up_above)) + (c0 << up_above), lim_a - NB_ORIGIN);
+            if (up_above == 0) {
 #pragma unroll
-            for (int k = 0; k < PXL; k++) px[k] = dir_lerp2(q[k], w);
-        } else {
+                for (int k = 0; k < PXL; k++) px[k] = dir_lerp2(q[k], w);
+            } else {
 #pragma unroll
-            for (int k = 0; k < PXL; k++) px[k] = dir_lerp2(q[2 * k], w);
+                for (int k = 0; k < PXL; k++) px[k] = dir_lerp2(q[2 * k], w);
+            }
+        } else if (MODE == IM_Z3) {
+            int y = dy * (c0 + 1);
+#pragma unroll
+            for (int k = 0; k < PXL; k++) {
+                const uint32_t sh = (uint32_t)(((y << up_left) & 0x3f) >> 1);
+                px[k] = dir_lerp2(L[min((y >> (6 - up_left)) + (r << up_left), lim_l - NB_ORIGIN)], (32u - sh) | (sh << 16));
+                y += dy;
+            }
+        } else {   // IM_Z2
+            const int x = -dx * (r + 1);
+            const uint32_t s1 = (uint32_t)(((x * (1 << up_above)) & 0x3f) >> 1);
+            const int lim = -(1 << up_above);
+            const int aoff = (int)(A - sm) + (x >> (6 - up_above)) + (c0 << up_above), loff = (int)(L - sm);
+            int y = (r << 6) - dy * (c0 + 1);
+#pragma unroll
+            for (int k = 0; k < PXL; k++) {
+                const int base1 = (x >> (6 - up_above)) + ((c0 + k) << up_above);
+                const bool ab = base1 >= lim;
+                const uint32_t s2 = (uint32_t)(((y * (1 << up_left)) & 0x3f) >> 1);
+                const int idx = ab ? aoff + (k << up_above) : loff + (y >> (6 - up_left));
+                const uint32_t sh = ab ? s1 : s2;
+                px[k] = dir_lerp2(sm[idx], (32u - sh) | (sh << 16));
+                y -= dy;
+            }
         }
-    } else if (MODE == IM_Z3) {
-        int y = dy * (c0 + 1);
+        if (live) {
+            if (sizeof(PixT) == 2) {
 #pragma unroll
-        for (int k = 0; k < PXL; k++) {
-            const uint32_t sh = (uint32_t)(((y << up_left) & 0x3f) >> 1);
-            px[k] = dir_lerp2(L[min((y >> (6 - up_left)) + (r << up_left), lim_l - NB_ORIGIN)], (32u - sh) | (sh << 16));
-            y += dy;
+                for (int k = 0; k < PXL; k++) px[k] = min(px[k], maxv);
+            }
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t v = px[q * PPW];
+#pragma unroll
+                for (int t = 1; t < PPW; t++) v |= px[q * PPW + t] << (8 * (int)sizeof(PixT) * t);
+                w[q] = v;
+            }
+            const size_t base_off = has_offs ? (size_t)off_word : (size_t)blk * dst_block_pitch;
+            intra_store<PixT>(dst + base_off + (size_t)r * dst_stride + c0, make_uint4(w[0], w[1], w[2], w[3]), ppl);
         }
-    } else {   // IM_Z2
-        const int x = -dx * (r + 1);
-        const uint32_t s1 = (uint32_t)(((x * (1 << up_above)) & 0x3f) >> 1);
-        const int lim = -(1 << up_above);
-        const int aoff = (int)(A - sm) + (x >> (6 - up_above)) + (c0 << up_above), loff = (int)(L - sm);
-        int y = (r << 6) - dy * (c0 + 1);
-#pragma unroll
-        for (int k = 0; k < PXL; k++) {
-            const int base1 = (x >> (6 - up_above)) + ((c0 + k) << up_above);
-            const bool ab = base1 >= lim;
-            const uint32_t s2 = (uint32_t)(((y * (1 << up_left)) & 0x3f) >> 1);
-            const int idx = ab ? aoff + (k << up_above) : loff + (y >> (6 - up_left));
-            const uint32_t sh = ab ? s1 : s2;
-            px[k] = dir_lerp2(sm[idx], (32u - sh) | (sh << 16));
-            y -= dy;
-        }
-    }
-    if (live) {
-        if (sizeof(PixT) == 2) {
-#pragma unroll
-            for (int k = 0; k < PXL; k++) px[k] = min(px[k], maxv);
-        }
-        uint32_t w[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t v = px[q * PPW];
-#pragma unroll
-            for (int t = 1; t < PPW; t++) v |= px[q * PPW + t] << (8 * (int)sizeof(PixT) * t);
-            w[q] = v;
-        }
-        const size_t base_off = has_offs ? (size_t)off_word : (size_t)blk * dst_block_pitch;
-        intra_store<PixT>(dst + base_off + (size_t)r * dst_stride + c0, make_uint4(w[0], w[1], w[2], w[3]), ppl);
-    }
+    };
+    if (multi.n == 0) emit(dx, dy, dst);
+    else for (int k = 0; k < multi.n; k++) emit(multi.dx[k], multi.dy[k], dst + (size_t)multi.slot[k] * multi.batch_pitch);
 }
 
 // av1_filter_intra_edge(_high) (:3539) — out-of-place on the device: every output

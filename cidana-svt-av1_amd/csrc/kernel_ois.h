@@ -5,8 +5,8 @@
 //                      reads, plus each block's DC value under the reference's availability rule
 //                      (dc_pred[x > 0][y > 0], EbIntraPrediction.c:4801);
 //   ois_sad_kernel     SAD of every candidate's dense prediction batch (or of the constant DC prediction) against
-//                      the source blocks in the picture -> the [block][candidate] distortion matrix, one launch;
-//   ois_best_kernel    first strict minimum below 64*64*255 per block (EbMotionEstimation.c:8756, 8800-8803).
+//                      the source blocks in the picture -> the [block][candidate] distortion matrix and the best
+//                      index (first strict minimum below 64*64*255, EbMotionEstimation.c:8756, 8800-8803), one launch.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -60,65 +60,71 @@ __global__ __launch_bounds__(256) void ois_gather_kernel(const uint8_t* __restri
     }
 }
 
-// One launch for ALL candidates (blockIdx.y = candidate): pred holds ncand dense prediction batches back to back;
-// a candidate whose bit is set in const_mask is the block's DC value instead.  Lanes per block = B*B / min(B, 16).
+// One launch for ALL candidates: pred_all holds ncand dense prediction batches back to back (a candidate whose bit
+// is set in const_mask is the block's DC value instead).  Lanes per block = B*B / min(B, 16).  A lane loads its
+// source chunk once and loops over the candidates; the block's ncand sums go through LDS so that they leave as one
+// contiguous run of dist[block][0 .. ncand), and the best index (first strict minimum below 64*64*255,
+// EbMotionEstimation.c:8756, 8800-8803) is taken from the same LDS row - no second pass over the matrix.
+constexpr int OIS_MAX_CAND = 61;       // MAX_OIS_CANDIDATES, EbCodingUnit.h:43
 __global__ __launch_bounds__(256) void ois_sad_kernel(const uint8_t* __restrict__ pic, uint32_t stride, const uint32_t* __restrict__ xy,
                                                       uint32_t bsize, const uint8_t* __restrict__ pred_all, size_t pred_cand_pitch,
                                                       const uint8_t* __restrict__ dc, unsigned long long const_mask,
-                                                      uint32_t* __restrict__ dist, uint32_t ncand, uint32_t nblocks) {
-    const uint32_t cand = blockIdx.y;
-    const bool CONST = (const_mask >> cand) & 1ull;
-    const uint8_t* pred = pred_all + (size_t)cand * pred_cand_pitch;
-    __shared__ uint32_t s_part[4];
+                                                      uint32_t* __restrict__ dist, int8_t* __restrict__ best_index, uint32_t ncand,
+                                                      uint32_t nblocks) {
+    extern __shared__ uint32_t s_dist[];                  // [slots][ncand] (+ [4][ncand] wave partials for 64x64)
     const uint32_t cs = bsize < 16 ? 8u : 16u;            // pixels per lane
-    const uint32_t lpb = bsize * bsize / cs;
+    const uint32_t lpb = bsize * bsize / cs;              // 8, 16, 64, 256
     const uint32_t lsh = __builtin_ctz(lpb);
+    const uint32_t slots = 256u >> lsh;
     const uint32_t slot = threadIdx.x >> lsh, l = threadIdx.x & (lpb - 1);
-    const uint32_t blk = blockIdx.x * (256u >> lsh) + slot;
+    const uint32_t blk = blockIdx.x * slots + slot;
     const bool valid = blk < nblocks;
-    uint32_t sad = 0;
+    uint32_t sv[4] = {0, 0, 0, 0};
+    uint32_t dcw = 0;
     if (valid) {
         const uint32_t q = xy[blk];
         const uint32_t cpr_sh = __builtin_ctz(bsize / cs);
         const uint32_t row = l >> cpr_sh, col = (l & ((1u << cpr_sh) - 1)) * cs;
         const uint8_t* s = pic + (size_t)((q >> 16) + row) * stride + (q & 0xffffu) + col;
-        uint32_t sv[4] = {0, 0, 0, 0}, pv[4] = {0, 0, 0, 0};
         if (cs == 16) __builtin_memcpy(sv, s, 16); else __builtin_memcpy(sv, s, 8);
-        if (CONST) {
-            const uint32_t d = dc[blk] * 0x01010101u;
-            pv[0] = pv[1] = d;
-            if (cs == 16) pv[2] = pv[3] = d;
-        } else {
-            const uint8_t* p = pred + (size_t)blk * bsize * bsize + (size_t)l * cs;
-            if (cs == 16) pv[0] = reinterpret_cast<const uint4*>(p)->x, pv[1] = reinterpret_cast<const uint4*>(p)->y,
-                          pv[2] = reinterpret_cast<const uint4*>(p)->z, pv[3] = reinterpret_cast<const uint4*>(p)->w;
-            else pv[0] = reinterpret_cast<const uint2*>(p)->x, pv[1] = reinterpret_cast<const uint2*>(p)->y;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) sad = __builtin_amdgcn_sad_u8(sv[i], pv[i], sad);
+        dcw = dc[blk] * 0x01010101u;
     }
+    const uint8_t* p = pred_all + (valid ? (size_t)blk * bsize * bsize + (size_t)l * cs : 0);
     const uint32_t span = lpb < 64 ? lpb : 64;
-    for (uint32_t m = span >> 1; m >= 1; m >>= 1) sad += __shfl_xor(sad, (int)m, 64);
-    if (lpb <= 64) {
-        if (valid && l == 0) dist[(size_t)blk * ncand + cand] = sad;
-    } else {                                              // 64x64: four waves per block
-        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sad;
-        __syncthreads();
-        if (valid && threadIdx.x == 0) dist[(size_t)blk * ncand + cand] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    }
-}
-
-__global__ __launch_bounds__(256) void ois_best_kernel(const uint32_t* __restrict__ dist, uint32_t ncand, int8_t* __restrict__ best_index,
-                                                       uint32_t nblocks) {
-    const uint32_t blk = blockIdx.x * 256u + threadIdx.x;
-    if (blk >= nblocks) return;
-    uint32_t best = 64u * 64u * 255u;
-    int bi = 0;
+    uint32_t* row_out = s_dist + (size_t)slot * ncand;
+    uint32_t* wave_part = s_dist + (size_t)slots * ncand;            // 64x64 only: [wave][cand]
     for (uint32_t c = 0; c < ncand; c++) {
-        const uint32_t d = dist[(size_t)blk * ncand + c];
-        if (d < best) { best = d; bi = (int)c; }
+        uint32_t pv[4];
+        if ((const_mask >> c) & 1ull) { pv[0] = pv[1] = pv[2] = pv[3] = dcw; }
+        else if (cs == 16) { const uint4 v = *reinterpret_cast<const uint4*>(p + (size_t)c * pred_cand_pitch); pv[0] = v.x; pv[1] = v.y; pv[2] = v.z; pv[3] = v.w; }
+        else { const uint2 v = *reinterpret_cast<const uint2*>(p + (size_t)c * pred_cand_pitch); pv[0] = v.x; pv[1] = v.y; pv[2] = pv[3] = 0; }
+        uint32_t sad = 0;
+        sad = __builtin_amdgcn_sad_u8(sv[0], pv[0], sad);
+        sad = __builtin_amdgcn_sad_u8(sv[1], pv[1], sad);
+        if (cs == 16) { sad = __builtin_amdgcn_sad_u8(sv[2], pv[2], sad); sad = __builtin_amdgcn_sad_u8(sv[3], pv[3], sad); }
+        for (uint32_t m = span >> 1; m >= 1; m >>= 1) sad += __shfl_xor(sad, (int)m, 64);
+        if (lpb <= 64) { if (l == 0) row_out[c] = sad; }
+        else if ((threadIdx.x & 63) == 0) wave_part[(threadIdx.x >> 6) * ncand + c] = sad;
     }
-    best_index[blk] = (int8_t)bi;
+    __syncthreads();
+    if (lpb > 64) {                                        // 64x64: one block per workgroup, add the four waves' partials
+        for (uint32_t c = threadIdx.x; c < ncand; c += 256) row_out[c] = wave_part[c] + wave_part[ncand + c] + wave_part[2 * ncand + c] + wave_part[3 * ncand + c];
+        __syncthreads();
+    }
+    // contiguous store of the workgroup's slots x ncand sums
+    const uint32_t first = blockIdx.x * slots;
+    const uint32_t nb_here = first < nblocks ? (nblocks - first < slots ? nblocks - first : slots) : 0;
+    for (uint32_t i = threadIdx.x; i < nb_here * ncand; i += 256) dist[(size_t)first * ncand + i] = s_dist[i];
+    if (threadIdx.x < nb_here) {
+        const uint32_t* r = s_dist + (size_t)threadIdx.x * ncand;
+        uint32_t best = 64u * 64u * 255u;
+        int bi = 0;
+        for (uint32_t c = 0; c < ncand; c++) {
+            const uint32_t d = r[c];
+            if (d < best) { best = d; bi = (int)c; }
+        }
+        best_index[first + threadIdx.x] = (int8_t)bi;
+    }
 }
 
 }  // namespace svtdev

@@ -1061,7 +1061,7 @@ extern "C" int svt_hip_intra_pred_batch(void* d_dst, int32_t dst_stride, size_t 
                            upsample_above, upsample_left, dx, dy, is_16bit, bd, nblocks, stream, nullptr);
 }
 
-// multi (directional modes only): several (dx, dy) of the same zone in one launch, see DirMulti
+// multi (directional modes only): several (dx, dy) of the same zone in one launch on edges staged once, see DirMulti
 static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pitch,
                            const uint32_t* d_dst_offsets, const void* d_above, const void* d_left,
                            int32_t nb_pitch, int mode, int bw, int bh, int upsample_above,
@@ -1101,7 +1101,7 @@ static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pit
         DirMulti dm;
         if (multi) dm = *multi; else dm.n = 0;
 #define IDL(T, M)                                                                                                     \
-    hipLaunchKernelGGL((intra_dir_kernel<T, M>), dim3((uint32_t)grid, (uint32_t)(dm.n ? dm.n : 1)), dim3(256), shmem, s, (T*)d_dst, dst_stride, \
+    hipLaunchKernelGGL((intra_dir_kernel<T, M>), dim3((uint32_t)grid), dim3(256), shmem, s, (T*)d_dst, dst_stride, \
                        dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh,            \
                        upsample_above, upsample_left, dx, dy, lim_a, lim_l, n_pad, bd, (uint32_t)nblocks, dm)
 #define IDM(T)                                                                                                        \
@@ -1486,15 +1486,14 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
                                          SVT_INTRA_Z1 + zi, (int)bsize, (int)bsize, 0, 0, 1, 1, 0, 8, nblocks, stream, &zone[zi]))
                 return rc;
     {
-        const uint32_t sad_slots = 256 / (bsize * bsize / (bsize < 16 ? 8 : 16));
+        const uint32_t lpb = bsize * bsize / (bsize < 16 ? 8 : 16);
+        const uint32_t sad_slots = 256 / lpb;
         const uint32_t sad_grid = (uint32_t)((nblocks + sad_slots - 1) / sad_slots);
-        hipLaunchKernelGGL(ois_sad_kernel, dim3(sad_grid, (uint32_t)ncand), dim3(256), 0, st, d_pic, stride, d_xy, bsize, d_pred, cand_pitch,
-                           d_dc, const_mask, d_distortion, (uint32_t)ncand, (uint32_t)nblocks);
-        if (int rc = launch_status("ois_sad")) return rc;
+        const size_t shmem = ((size_t)sad_slots + (lpb > 64 ? 4 : 0)) * (size_t)ncand * sizeof(uint32_t);
+        hipLaunchKernelGGL(ois_sad_kernel, dim3(sad_grid), dim3(256), shmem, st, d_pic, stride, d_xy, bsize, d_pred, cand_pitch,
+                           d_dc, const_mask, d_distortion, d_best_index, (uint32_t)ncand, (uint32_t)nblocks);
     }
-    hipLaunchKernelGGL(ois_best_kernel, dim3((uint32_t)((nblocks + 255) / 256)), dim3(256), 0, st, d_distortion, (uint32_t)ncand,
-                       d_best_index, (uint32_t)nblocks);
-    return launch_status("ois_best");
+    return launch_status("ois_sad");
 }
 
 // one intra block: stage [lo, hi) of above / left around the origin, predict, copy the block back
