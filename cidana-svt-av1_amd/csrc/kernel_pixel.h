@@ -342,24 +342,25 @@ __global__ __launch_bounds__(256) void sad_search_q_kernel(
                 }
         }
     }
-    __syncthreads();            // lanes of one block may live in different waves when lpb = 64 is not... (lpb <= 64: same wave; barrier kept for clarity/safety)
+    __syncthreads();            // staging -> search (a block's lanes share a wave, lpb <= 64; the barrier also orders the tail byte stores)
     unsigned long long best = ~0ull;
     if (valid) {
         const int gx = (search_w + 3) >> 2;
         const int ngroups = gx * search_h;
         const uint32_t flush = 257u / width > 0 ? 257u / width : 1u;
+        constexpr int ROW_UNROLL = CH ? (CH > 16 ? 4 : CH) : 1, COL_UNROLL = CW ? CW / 4 : 1;
         for (int g = (int)l; g < ngroups; g += (int)lpb) {
             const int ys = g / gx, xg = g - ys * gx;
             uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             unsigned long long acc = 0;
             uint32_t since = 0;
-#pragma unroll (CH ? (CH > 16 ? 4 : CH) : 1)
+#pragma unroll ROW_UNROLL
             for (uint32_t y = 0; y < height; y++) {
                 const uint32_t rr = plain ? (uint32_t)ys + y : (uint32_t)ys * height + y;
                 const uint32_t* rrow = reinterpret_cast<const uint32_t*>(s_ref + rr * wpitch) + xg;
                 const uint32_t* srow = reinterpret_cast<const uint32_t*>(s_src) + y * wq;
                 uint32_t lo = rrow[0];
-#pragma unroll (CW ? CW / 4 : 1)
+#pragma unroll COL_UNROLL
                 for (uint32_t q = 0; q < wq; q++) {
                     const uint32_t hi = rrow[q + 1];
                     acc = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)hi << 32) | lo, srow[q], acc);
