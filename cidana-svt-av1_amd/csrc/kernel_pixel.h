@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void sad_search_q_kernel(
 // LDS cycles).  A candidate's whole SAD fits its packed u16 accumulator (256 * 255 < 2^16).
 // Argmin key and outputs as in sad_search_q_kernel.
 // ---------------------------------------------------------------------------
-template <int CW, int CH>
+template <int CW, int CH, int Q2_SU>
 __global__ __launch_bounds__(256) void sad_search_q2_kernel(
     const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
     const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void sad_search_q2_kernel(
         // candidates can touch those bytes); the few that do not are fetched byte-wise afterwards.
         constexpr uint32_t CS = CW % 16 == 0 ? 16 : (CW % 8 == 0 ? 8 : 4);
         constexpr uint32_t NSRC = CW * CH / CS;
-        constexpr int SU = 4;
+        constexpr int SU = Q2_SU;
         const uint32_t cpr = (win_w + 15) >> 4;
         const uint32_t nref = nrows * cpr;
         const size_t span = (size_t)(nrows - 1) * ref_stride + win_w;
@@ -487,8 +487,12 @@ __global__ __launch_bounds__(256) void sad_search_q2_kernel(
             }
             // All loads are consumed here, so they are issued above and waited for once; without this the
             // predicated LDS writes below let LLVM sink each load into its branch (one latency per chunk).
-            static_assert(SU == 4, "operand list below");
-            asm volatile("" ::"v"(vs[0].x), "v"(vs[1].x), "v"(vs[2].x), "v"(vs[3].x), "v"(vr[0].x), "v"(vr[1].x), "v"(vr[2].x), "v"(vr[3].x));
+            static_assert(SU == 4 || SU == 8, "operand lists below");
+            if constexpr (SU == 4)
+                asm volatile("" ::"v"(vs[0].x), "v"(vs[1].x), "v"(vs[2].x), "v"(vs[3].x), "v"(vr[0].x), "v"(vr[1].x), "v"(vr[2].x), "v"(vr[3].x));
+            else
+                asm volatile("" ::"v"(vs[0].x), "v"(vs[1].x), "v"(vs[2].x), "v"(vs[3].x), "v"(vr[0].x), "v"(vr[1].x), "v"(vr[2].x), "v"(vr[3].x),
+                             "v"(vs[4 % SU].x), "v"(vs[5 % SU].x), "v"(vs[6 % SU].x), "v"(vs[7 % SU].x), "v"(vr[4 % SU].x), "v"(vr[5 % SU].x), "v"(vr[6 % SU].x), "v"(vr[7 % SU].x));
 #pragma unroll
             for (int k = 0; k < SU; k++) {
                 const uint32_t i = i0 + k * lpb;

@@ -40,6 +40,7 @@ int g_tune_no_staged = 0;
 int g_tune_no_qsad = 0;
 int g_tune_no_q2 = 0;
 int g_tune_no_q16 = 0;
+int g_tune_q2_su4 = 0;
 int g_tune_no_me16 = 0;
 int g_tune_no_f32p = 0;
 int g_tune_no_inv_planes = 0;
@@ -312,6 +313,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "no_qsad")) { g_tune_no_qsad = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_q2")) { g_tune_no_q2 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_q16")) { g_tune_no_q16 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "q2_su4")) { g_tune_q2_su4 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_me16")) { g_tune_no_me16 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_f32p")) { g_tune_no_f32p = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_inv_planes")) { g_tune_no_inv_planes = value; return SVT_HIP_OK; }
@@ -767,14 +769,19 @@ static int sad_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src
             while (threads > lpb && (size_t)(threads / lpb) * per_blk > 64 * 1024) threads >>= 1;
             const uint32_t slots = threads / lpb;
             const uint32_t grid = (uint32_t)((nblocks + slots - 1) / slots);
-#define SSQ2(CW, CH)                                                                                                    \
-    hipLaunchKernelGGL((sad_search_q2_kernel<CW, CH>), dim3(grid), dim3(threads), (size_t)slots * per_blk, (hipStream_t)stream, \
+#define SSQ2(CW, CH, SU)                                                                                                \
+    hipLaunchKernelGGL((sad_search_q2_kernel<CW, CH, SU>), dim3(grid), dim3(threads), (size_t)slots * per_blk, (hipStream_t)stream, \
                        d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, (int)search_area_width,         \
                        (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, ref_bytes, lpb, cpr_magic,           \
                        d_src_offs, d_ref_offs, (uint32_t)nblocks)
             // exact j / cpr for j < 2^16 chunks (cpr <= 8): floor(2^32 / cpr) + 1
             const uint32_t cpr_magic = (uint32_t)(0x100000000ull / ((win_w + 15) >> 4)) + 1u;
-            if (width == 16) SSQ2(16, 16); else SSQ2(8, 8);
+            // staging depth: all of a lane's chunks in ONE batch of loads when that takes at most 8 per lane (one memory
+            // latency per block instead of two: the kernel is latency-bound at 3 waves per SIMD)
+            const uint32_t nchunk = ((win_w + 15) >> 4) * nrows;
+            const bool deep = !g_tune_q2_su4 && nchunk > 4 * lpb;
+            if (width == 16) { if (deep) SSQ2(16, 16, 8); else SSQ2(16, 16, 4); }
+            else { if (deep) SSQ2(8, 8, 8); else SSQ2(8, 8, 4); }
 #undef SSQ2
             return launch_status("sad_search_q2");
         }

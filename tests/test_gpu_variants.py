@@ -91,7 +91,7 @@ def test_inverse_on_planes_variants(dsp, knob, tx_size, bd):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("knob,bw,sw,sh", [("no_q2", 16, 8, 8), ("no_q2", 8, 13, 5), ("no_qsad", 16, 8, 8), ("no_qsad", 32, 9, 6),
+@pytest.mark.parametrize("knob,bw,sw,sh", [("q2_su4", 16, 8, 8), ("q2_su4", 8, 16, 16), ("no_q2", 16, 8, 8), ("no_q2", 8, 13, 5), ("no_qsad", 16, 8, 8), ("no_qsad", 32, 9, 6),
                                              ("no_q16", 32, 9, 6), ("no_q16", 64, 16, 16), ("no_q16", 32, 37, 3)])
 def test_sad_search_variants(dsp, knob, bw, sw, sh):
     rng = np.random.default_rng(bw + sw)
