@@ -95,3 +95,86 @@ def test_roundtrip_idempotence_1m_8x8(dsp):
     diff = (recon.to(torch.int16) - src.to(torch.int16)).abs()
     assert int(diff.max()) <= 1          # integer DCT pair: at most one LSB of rounding noise
     assert float((diff != 0).float().mean()) < 0.2
+
+
+def test_wide_sad_search_full_size_properties(dsp):
+    """sad_search_q16_kernel at bench scale (2^17 32x32 and 2^15 64x64 blocks, 16x16 search areas): equal to the
+    4-candidate kernel, the reported SAD is the SAD at the reported candidate, and no candidate beats it."""
+    g = torch.Generator(device=DEV); g.manual_seed(7)
+    for (b, n) in ((32, 1 << 17), (64, 1 << 15)):
+        sw = sh = 16
+        src = torch.randint(0, 256, (n, b, b), dtype=torch.uint8, device=DEV, generator=g)
+        ref = torch.randint(0, 256, (n, b + sh - 1, b + sw - 1), dtype=torch.uint8, device=DEV, generator=g)
+        ref[::5, 3:3 + b, 9:9 + b] = src[::5]                    # planted exact matches
+        best, x, y = dsp.sad_search(src, ref, sw, sh)
+        assert dsp.lib.svt_hip_tune(b"no_q16", 1) == 0
+        try:
+            best2, x2, y2 = dsp.sad_search(src, ref, sw, sh)
+        finally:
+            dsp.lib.svt_hip_tune(b"no_q16", 0)
+        assert torch.equal(best, best2) and torch.equal(x, x2) and torch.equal(y, y2)
+        assert (best[::5] == 0).all() and (x[::5] == 9).all() and (y[::5] == 3).all()
+        # SAD at the reported candidate, recomputed with torch on a slice of the batch
+        m = 4096
+        xi, yi = x[:m].long(), y[:m].long()
+        rows = yi[:, None, None] + torch.arange(b, device=DEV)[None, :, None]
+        cols = xi[:, None, None] + torch.arange(b, device=DEV)[None, None, :]
+        win = ref[:m][torch.arange(m, device=DEV)[:, None, None], rows, cols]
+        sad = (win.to(torch.int32) - src[:m].to(torch.int32)).abs().sum(dim=(1, 2))
+        assert torch.equal(sad.to(torch.int64), best[:m])
+        at00 = (ref[:m, :b, :b].to(torch.int32) - src[:m].to(torch.int32)).abs().sum(dim=(1, 2))
+        assert (best[:m] <= at00.to(torch.int64)).all()
+
+
+def test_cfl_and_levels_full_size_properties(dsp):
+    n = 1 << 19
+    g = torch.Generator(device=DEV); g.manual_seed(11)
+    w = h = 16
+    luma = torch.randint(0, 256, (n, 2 * h, 2 * w), dtype=torch.uint8, device=DEV, generator=g)
+    q3 = dsp.cfl_luma_subsampling_420(luma, 2 * w, 2 * w, 2 * h, luma_block_pitch=4 * w * h, n=n)
+    want = (luma.to(torch.int32).reshape(n, h, 2, w, 2).sum(dim=(2, 4)) * 2).to(torch.int16)
+    assert torch.equal(q3[:, :h, :w], want)
+    ac = dsp.cfl_luma_subsampling_420(luma, 2 * w, 2 * w, 2 * h, luma_block_pitch=4 * w * h, n=n, subtract_average=True)
+    # the mean is removed to within the rounding of the average: |sum of AC| <= w*h/2 per block
+    assert (ac[:, :h, :w].to(torch.int32).sum(dim=(1, 2)).abs() <= w * h // 2).all()
+    pred = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=DEV, generator=g)
+    zero = torch.zeros(n, dtype=torch.int32, device=DEV)
+    out = torch.empty_like(pred)
+    dsp.cfl_predict(ac, pred, w, out, w, zero, 8, w, h)
+    assert torch.equal(out, pred)                                # alpha = 0: the DC prediction itself
+    # antisymmetry away from the clip: pred + t and pred - t for alpha and -alpha
+    mid = torch.full_like(pred, 128)
+    a = torch.full((n,), 3, dtype=torch.int32, device=DEV)
+    up = dsp.cfl_predict(ac, mid, w, torch.empty_like(mid), w, a, 8, w, h).to(torch.int32)
+    dn = dsp.cfl_predict(ac, mid, w, torch.empty_like(mid), w, -a, 8, w, h).to(torch.int32)
+    inside = (up > 0) & (up < 255) & (dn > 0) & (dn < 255)
+    assert torch.equal((up - 128)[inside], (128 - dn)[inside])
+    coeff = torch.randint(-400, 401, (n, w * h), dtype=torch.int32, device=DEV, generator=g)
+    size = (w + 4) * (h + 6) + 16
+    lv = dsp.txb_init_levels(coeff, w, h, torch.full((n, size + 8), 0x33, dtype=torch.uint8, device=DEV))
+    body = lv[:, :(w + 4) * (h + 6)].reshape(n, h + 6, w + 4)
+    assert torch.equal(body[:, 2:2 + h, :w], coeff.abs().clamp(max=127).to(torch.uint8).reshape(n, h, w))
+    assert not body[:, :2].any() and not body[:, 2 + h:].any() and not body[:, :, w:].any()
+    assert not lv[:, (w + 4) * (h + 6):size].any() and (lv[:, size:] == 0x33).all()
+
+
+def test_ois_1080p_properties(dsp):
+    """every 16x16 block of a 1080p picture: the best index is the first minimum of its distortion row, the DC
+    candidate equals the SAD against the block's DC value, and a vertically constant picture is predicted
+    exactly by V_PRED away from the top border."""
+    W, H, pad, b = 1920, 1080, 64, 16
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    plane = torch.randint(0, 256, (H + 2 * pad, W + 2 * pad), dtype=torch.uint8, device=DEV, generator=g)
+    plane[pad + 512:pad + 768] = plane[pad + 511:pad + 512]                      # rows 512..767 repeat row 511
+    blocks = [(x, y) for y in range(0, H - b + 1, b) for x in range(0, W - b + 1, b)]
+    xy = torch.from_numpy(np.array([(y << 16) | x for x, y in blocks], np.uint32).view(np.int32)).to(DEV)
+    modes, deltas = dsp.ois_candidates(b)
+    dist, best = dsp.ois_search(plane[pad:, pad:], W + 2 * pad, W, H, xy, b, modes, deltas)
+    dist = dist.to(torch.int64)
+    mn = dist.min(dim=1).values
+    first = (dist == mn[:, None]).int().argmax(dim=1)
+    assert torch.equal(first.to(torch.int8), best)
+    iv = int(np.nonzero((modes == 1) & (deltas == 0))[0][0])                     # V_PRED, angle 90
+    ys = torch.tensor([y for _, y in blocks], device=DEV)
+    inside = (ys >= 512) & (ys + b <= 768)
+    assert (dist[inside, iv] == 0).all() and inside.sum() > 1000
