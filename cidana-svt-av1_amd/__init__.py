@@ -348,11 +348,12 @@ class SvtHipDsp:
 
     # -- open-loop intra search (open_loop_intra_search_sb) --------------------------------
     @staticmethod
-    def ois_candidates(bsize, temporal_layer_index=0, intra_pred_mode=0, is_used_as_reference=True):
+    def ois_candidates(bsize, temporal_layer_index=0, intra_pred_mode=0, is_used_as_reference=True, is_16bit=False):
         """The candidate list the reference's loop enumerates for one block size (EbMotionEstimation.c:8747-8846,
-        8-bit): (modes uint8[], angle_deltas int8[]) in AV1 PredictionMode numbering."""
+        is_16bit = encoder_bit_depth > 8: PAETH_PRED is left out, the search itself stays on the 8-bit picture):
+        (modes uint8[], angle_deltas int8[]) in AV1 PredictionMode numbering."""
         import numpy as np
-        last = 12
+        last = 11 if is_16bit else 12
         nd = 1 if intra_pred_mode >= 5 else (5 if bsize >= 8 else 1)
         no_angular = temporal_layer_index > 0 or bsize > 16
         if no_angular:

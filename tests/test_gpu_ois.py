@@ -76,6 +76,19 @@ def test_ois_whole_picture_vs_oracle(dsp, bsize, tl):
         assert int(best[i]) == bi, (i, x, y)
 
 
+def test_ois_candidate_lists_match_oracle(dsp):
+    O = svtlibs.oracle()
+    for bsize in (8, 16, 32, 64):
+        for tl in (0, 2):
+            for ipm in (0, 4, 5):
+                for isref in (0, 1):
+                    for is16 in (0, 1):
+                        om = np.zeros(61, np.uint8); od = np.zeros(61, np.int8)
+                        n = O.svt_oracle_ois_candidates(c_int(bsize), c_int(tl), c_int(ipm), c_int(isref), c_int(is16), ptr(om), ptr(od))
+                        m, d = dsp.ois_candidates(bsize, tl, ipm, bool(isref), bool(is16))
+                        assert n == len(m) and np.array_equal(om[:n], m) and np.array_equal(od[:n], d)
+
+
 def test_ois_argument_errors(dsp):
     L = dsp.lib
     z = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
