@@ -252,6 +252,13 @@ struct DirMulti {
     int16_t dx[20], dy[20];
     uint8_t slot[20];
     size_t batch_pitch;
+    // SAD mode (8-bit, blocks of at most 64 lanes: 8x8, 16x16): no prediction is stored; angle k's prediction is
+    // compared with the source block at xy[blk] in sad_pic and its SAD goes to sad_dist[blk * sad_ncand + slot[k]]
+    const uint8_t* sad_pic;
+    uint32_t sad_stride;
+    const uint32_t* sad_xy;
+    uint32_t* sad_dist;
+    uint32_t sad_ncand;
 };
 
 template <typename PixT, int MODE>
@@ -320,7 +327,15 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
     __syncthreads();
     const uint32_t* A = sa + NB_ORIGIN;
     const uint32_t* L = sl + NB_ORIGIN;
-    auto emit = [&](const int dx, const int dy, PixT* __restrict__ dst) {
+    // SAD mode: this lane's chunk of the source block, loaded once for all angles
+    uint32_t srcw[4] = {0, 0, 0, 0};
+    const bool sad_mode = sizeof(PixT) == 1 && multi.n != 0 && multi.sad_dist != nullptr;
+    if (sad_mode && live) {
+        const uint32_t q = multi.sad_xy[blk];
+        const uint8_t* sp = multi.sad_pic + (size_t)((q >> 16) + (uint32_t)r) * multi.sad_stride + (q & 0xffffu) + (uint32_t)c0;
+        if (ppl == 16) __builtin_memcpy(srcw, sp, 16); else if (ppl == 8) __builtin_memcpy(srcw, sp, 8); else __builtin_memcpy(srcw, sp, 4);
+    }
+    auto emit = [&](const int dx, const int dy, PixT* __restrict__ dst, const int kslot) {
         uint32_t px[PXL];
         if (MODE == IM_Z1) {
             const int x = dx * (r + 1);
@@ -372,12 +387,21 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
                 for (int t = 1; t < PPW; t++) v |= px[q * PPW + t] << (8 * (int)sizeof(PixT) * t);
                 w[q] = v;
             }
-            const size_t base_off = has_offs ? (size_t)off_word : (size_t)blk * dst_block_pitch;
-            intra_store<PixT>(dst + base_off + (size_t)r * dst_stride + c0, make_uint4(w[0], w[1], w[2], w[3]), ppl);
+            if (!sad_mode) {
+                const size_t base_off = has_offs ? (size_t)off_word : (size_t)blk * dst_block_pitch;
+                intra_store<PixT>(dst + base_off + (size_t)r * dst_stride + c0, make_uint4(w[0], w[1], w[2], w[3]), ppl);
+            } else {
+                // lanes of a block are per_block (<= 64) consecutive lanes of one wave: butterfly sum, lane 0 writes
+                uint32_t sad = __builtin_amdgcn_sad_u8(srcw[0], w[0], 0u);
+                if (ppl >= 8) sad = __builtin_amdgcn_sad_u8(srcw[1], w[1], sad);
+                if (ppl == 16) { sad = __builtin_amdgcn_sad_u8(srcw[2], w[2], sad); sad = __builtin_amdgcn_sad_u8(srcw[3], w[3], sad); }
+                for (uint32_t m = per_block >> 1; m >= 1; m >>= 1) sad += __shfl_xor(sad, (int)m, 64);
+                if (j == 0) multi.sad_dist[(size_t)blk * multi.sad_ncand + (uint32_t)kslot] = sad;
+            }
         }
     };
-    if (multi.n == 0) emit(dx, dy, dst);
-    else for (int k = 0; k < multi.n; k++) emit(multi.dx[k], multi.dy[k], dst + (size_t)multi.slot[k] * multi.batch_pitch);
+    if (multi.n == 0) emit(dx, dy, dst, 0);
+    else for (int k = 0; k < multi.n; k++) emit(multi.dx[k], multi.dy[k], dst + (size_t)multi.slot[k] * multi.batch_pitch, (int)multi.slot[k]);
 }
 
 // av1_filter_intra_edge(_high) (:3539) — out-of-place on the device: every output

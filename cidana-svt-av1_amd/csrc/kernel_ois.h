@@ -63,13 +63,14 @@ __global__ __launch_bounds__(256) void ois_gather_kernel(const uint8_t* __restri
 // One launch for ALL candidates: pred_all holds ncand dense prediction batches back to back (a candidate whose bit
 // is set in const_mask is the block's DC value instead).  Lanes per block = B*B / min(B, 16).  A lane loads its
 // source chunk once and loops over the candidates; the block's ncand sums go through LDS so that they leave as one
-// contiguous run of dist[block][0 .. ncand), and the best index (first strict minimum below 64*64*255,
+// contiguous run of dist[block][0 .. ncand) (candidates in fold_mask were already summed by intra_dir_kernel's SAD mode
+// and are only picked up), and the best index (first strict minimum below 64*64*255,
 // EbMotionEstimation.c:8756, 8800-8803) is taken from the same LDS row - no second pass over the matrix.
 constexpr int OIS_MAX_CAND = 61;       // MAX_OIS_CANDIDATES, EbCodingUnit.h:43
 __global__ __launch_bounds__(256) void ois_sad_kernel(const uint8_t* __restrict__ pic, uint32_t stride, const uint32_t* __restrict__ xy,
                                                       uint32_t bsize, const uint8_t* __restrict__ pred_all, size_t pred_cand_pitch,
                                                       const uint8_t* __restrict__ dc, unsigned long long const_mask,
-                                                      uint32_t* __restrict__ dist, int8_t* __restrict__ best_index, uint32_t ncand,
+                                                      unsigned long long fold_mask, uint32_t* dist, int8_t* __restrict__ best_index, uint32_t ncand,
                                                       uint32_t nblocks) {
     extern __shared__ uint32_t s_dist[];                  // [slots][ncand] (+ [4][ncand] wave partials for 64x64)
     const uint32_t cs = bsize < 16 ? 8u : 16u;            // pixels per lane
@@ -94,6 +95,10 @@ __global__ __launch_bounds__(256) void ois_sad_kernel(const uint8_t* __restrict_
     uint32_t* row_out = s_dist + (size_t)slot * ncand;
     uint32_t* wave_part = s_dist + (size_t)slots * ncand;            // 64x64 only: [wave][cand]
     for (uint32_t c = 0; c < ncand; c++) {
+        if ((fold_mask >> c) & 1ull) {                     // already in dist: the directional kernels' SAD mode (blocks <= 64 lanes)
+            if (valid && l == 0) row_out[c] = dist[(size_t)blk * ncand + c];
+            continue;
+        }
         uint32_t pv[4];
         if ((const_mask >> c) & 1ull) { pv[0] = pv[1] = pv[2] = pv[3] = dcw; }
         else if (cs == 16) { const uint4 v = *reinterpret_cast<const uint4*>(p + (size_t)c * pred_cand_pitch); pv[0] = v.x; pv[1] = v.y; pv[2] = v.z; pv[3] = v.w; }

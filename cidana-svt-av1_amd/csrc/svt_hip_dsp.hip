@@ -41,6 +41,7 @@ int g_tune_no_qsad = 0;
 int g_tune_no_q2 = 0;
 int g_tune_no_q16 = 0;
 int g_tune_q2_su4 = 0;
+int g_tune_ois_no_fold = 0;
 int g_tune_no_me16 = 0;
 int g_tune_no_f32p = 0;
 int g_tune_no_inv_planes = 0;
@@ -314,6 +315,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "no_q2")) { g_tune_no_q2 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_q16")) { g_tune_no_q16 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "q2_su4")) { g_tune_q2_su4 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "ois_no_fold")) { g_tune_ois_no_fold = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_me16")) { g_tune_no_me16 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_f32p")) { g_tune_no_f32p = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_inv_planes")) { g_tune_no_inv_planes = value; return SVT_HIP_OK; }
@@ -1456,7 +1458,14 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
     const size_t cand_pitch = ois_align(nblocks * (size_t)bsize * bsize);
     unsigned long long const_mask = 0;
     DirMulti zone[3];
-    for (auto& z : zone) { z.n = 0; z.batch_pitch = cand_pitch; }
+    // 8x8 / 16x16 (a block's lanes share a wave): the directional kernels compare each angle's prediction with the source
+    // block themselves (DirMulti SAD mode) - no prediction scratch round trip for 38 of the 45 candidates
+    const bool fold = bsize <= 16 && !g_tune_ois_no_fold;
+    unsigned long long fold_mask = 0;
+    for (auto& z : zone) {
+        z.n = 0; z.batch_pitch = cand_pitch;
+        z.sad_pic = d_pic; z.sad_stride = stride; z.sad_xy = d_xy; z.sad_dist = fold ? d_distortion : nullptr; z.sad_ncand = (uint32_t)ncand;
+    }
     for (int c = 0; c < ncand; c++) {
         const int m = modes[c];
         if (m == 0) { const_mask |= 1ull << c; continue; }     // DC_PRED under the availability rule: constant prediction
@@ -1478,6 +1487,7 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
                 z.dy[z.n] = (int16_t)(zi == 0 ? 1 : (zi == 1 ? ois_dr_derivative(a - 90) : ois_dr_derivative(270 - a)));
                 z.slot[z.n] = (uint8_t)c;
                 z.n++;
+                if (fold) fold_mask |= 1ull << c;
                 continue;
             }
         } else {
@@ -1498,7 +1508,7 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
         const uint32_t sad_grid = (uint32_t)((nblocks + sad_slots - 1) / sad_slots);
         const size_t shmem = ((size_t)sad_slots + (lpb > 64 ? 4 : 0)) * (size_t)ncand * sizeof(uint32_t);
         hipLaunchKernelGGL(ois_sad_kernel, dim3(sad_grid), dim3(256), shmem, st, d_pic, stride, d_xy, bsize, d_pred, cand_pitch,
-                           d_dc, const_mask, d_distortion, d_best_index, (uint32_t)ncand, (uint32_t)nblocks);
+                           d_dc, const_mask, fold_mask, d_distortion, d_best_index, (uint32_t)ncand, (uint32_t)nblocks);
     }
     return launch_status("ois_sad");
 }

@@ -76,6 +76,25 @@ def test_ois_whole_picture_vs_oracle(dsp, bsize, tl):
         assert int(best[i]) == bi, (i, x, y)
 
 
+@pytest.mark.parametrize("bsize", [8, 16])
+def test_ois_fold_variant(dsp, bsize):
+    """SAD folded into the directional kernels (default for 8x8 / 16x16) == predictions through scratch + SAD kernel"""
+    rng = np.random.default_rng(bsize)
+    W, H, pad = 352, 288, 32
+    buf = rng.integers(0, 256, size=(H + 2 * pad, W + 2 * pad), dtype=np.uint8)
+    blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
+    modes, deltas = dsp.ois_candidates(bsize)
+    plane = dev(buf)
+    out = []
+    try:
+        for v in (0, 1):
+            assert dsp.lib.svt_hip_tune(b"ois_no_fold", v) == 0
+            out.append(dsp.ois_search(plane[pad:, pad:], W + 2 * pad, W, H, _xy(blocks), bsize, modes, deltas))
+    finally:
+        dsp.lib.svt_hip_tune(b"ois_no_fold", 0)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 def test_ois_candidate_lists_match_oracle(dsp):
     O = svtlibs.oracle()
     for bsize in (8, 16, 32, 64):
