@@ -363,6 +363,24 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
             const int lim = -(1 << up_above);
             const int aoff = (int)(A - sm) + (x >> (6 - up_above)) + (c0 << up_above), loff = (int)(L - sm);
             int y = (r << 6) - dy * (c0 + 1);
+            if ((up_above | up_left) == 0) {
+                // no upsampling (every block larger than 8x8, and the whole open-loop search): constant shifts, LDS byte
+                // addresses and the weight pair as one multiply-add - the kernel is VALU-bound on this per-pixel selection
+                const int b0 = (x >> 6) + c0;                                  // base1 of pixel k = b0 + k; above edge when >= -1
+                const uint32_t w1 = (32u - s1) | (s1 << 16);
+                const int aoffB = aoff * 4, loffB = loff * 4;
+                const char* smb = reinterpret_cast<const char*>(sm);
+#pragma unroll
+                for (int k = 0; k < PXL; k++) {
+                    const bool ab = b0 >= -1 - k;
+                    const uint32_t s2 = ((uint32_t)y >> 1) & 31u;              // (y & 0x3f) >> 1
+                    const uint32_t w2 = s2 * 0xffffu + 32u;                    // (32 - s2) | s2 << 16
+                    const int offL = loffB + ((y >> 4) & ~3);                  // 4 * (loff + (y >> 6))
+                    const int off = ab ? aoffB + 4 * k : offL;
+                    px[k] = dir_lerp2(*reinterpret_cast<const uint32_t*>(smb + off), ab ? w1 : w2);
+                    y -= dy;
+                }
+            } else
 #pragma unroll
             for (int k = 0; k < PXL; k++) {
                 const int base1 = (x >> (6 - up_above)) + ((c0 + k) << up_above);
