@@ -114,7 +114,6 @@ def main():
 
     import torch
     import __graft_entry__ as ge
-    import svtlibs
     pkg = ge.load_package()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,9 +133,9 @@ def main():
     g.manual_seed(13596 + rank)                   # seed constant of test/random.h:103
     src = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device=dev, generator=g)
     pred = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device=dev, generator=g)
-    qt = svtlibs.quant_tables(8)
+    qt = pkg.tables.quant_tables(8)               # the product's own host tables (oracle/ is used by the cpu_baseline leg only)
     qrow = {k: v[QINDEX].copy() for k, v in qt.items()}
-    _, iscan_np = svtlibs.scan_tables(pkg.TX_32X32, pkg.DCT_DCT)
+    _, iscan_np = pkg.tables.scan_tables(pkg.TX_32X32, pkg.DCT_DCT)
     iscan = torch.from_numpy(iscan_np).to(dev)
     outs = (torch.empty((n, 1024), dtype=torch.int32, device=dev), torch.empty((n, 1024), dtype=torch.int32, device=dev),
             torch.empty((n, 1024), dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int16, device=dev),

@@ -18,6 +18,8 @@ import ctypes
 import os
 from ctypes import c_int, c_int16, c_int32, c_size_t, c_uint32, c_void_p
 
+from . import tables  # noqa: F401  (host-side quantiser / scan tables for callers outside the encoder)
+
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libsvt_hip_dsp.so")
 

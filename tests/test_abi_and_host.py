@@ -81,3 +81,23 @@ def test_log_scale_rule(pkg):
     want = {0: 0, 1: 0, 2: 0, 3: 1, 4: 2, 9: 1, 10: 1, 11: 2, 12: 2, 15: 0, 17: 1, 18: 1}
     for s, ls in want.items():
         assert pkg.tx_log_scale(s) == ls
+
+
+def test_host_tables_match_oracle():
+    """cidana-svt-av1_amd/tables.py (what bench.py and the tools feed the quantiser with) against the oracle's
+    av1_build_quantizer / scan restatements, which tests/test_oracle_vs_ref_tables.py pins to the reference."""
+    import numpy as np
+    import __graft_entry__ as ge
+    import svtlibs
+    pkg = ge.load_package()
+    for bd in (8, 10, 12):
+        a, b = pkg.tables.quant_tables(bd), svtlibs.quant_tables(bd)
+        for k in b:
+            assert np.array_equal(a[k], b[k]), (bd, k)
+    for s in range(19):
+        for t in range(16):
+            if not svtlibs.txfm_allowed(s, t):
+                continue
+            sa, ia = pkg.tables.scan_tables(s, t)
+            sb, ib = svtlibs.scan_tables(s, t)
+            assert np.array_equal(sa, sb) and np.array_equal(ia, ib), (s, t)

@@ -8,10 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import __graft_entry__ as ge
-import svtlibs
 pkg = ge.load_package(); dsp = pkg.SvtHipDsp(0)
 dev = torch.device("cuda:0")
-qt = svtlibs.quant_tables(8); qrow = {k: v[100].copy() for k, v in qt.items()}
+qt = pkg.tables.quant_tables(8); qrow = {k: v[100].copy() for k, v in qt.items()}
 g = torch.Generator(device=dev); g.manual_seed(13596)
 planes = {"Y": (1080, 1920), "U": (540, 960), "V": (540, 960)}
 src = {k: torch.randint(0, 256, s, dtype=torch.uint8, device=dev, generator=g) for k, s in planes.items()}
@@ -35,7 +34,7 @@ for tx_size in (4, 3, 2, 1, 0):
         xs = np.arange(0, pw - s_c + 1, s_c); ys = np.arange(0, ph - s_c + 1, s_c)
         xy = torch.from_numpy(np.array([(y << 16) | x for y in ys for x in xs], np.uint32).view(np.int32)).to(dev)
         offs = torch.from_numpy(np.array([y * pw + x for y in ys for x in xs], np.uint32).view(np.int32)).to(dev)
-        _, isc = svtlibs.scan_tables(ts, 0)
+        _, isc = pkg.tables.scan_tables(ts, 0)
         work.append((name, ts, pw, xy, offs, torch.from_numpy(isc).to(dev), pred[name].clone()))
     nblk = sum(w[3].numel() for w in work)
     npx = sum(w[3].numel() * pkg.TX_W[w[1]] ** 2 for w in work)

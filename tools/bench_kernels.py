@@ -8,7 +8,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import __graft_entry__ as ge
-import svtlibs
 pkg = ge.load_package(); dsp = pkg.SvtHipDsp(0)
 dev = torch.device("cuda:0")
 TW, TH = pkg.TX_W, pkg.TX_H
@@ -26,7 +25,7 @@ def rec(name, n, bytes_per, ms, extra=None):
          "GBps": round(bytes_per * n / ms / 1e6, 1), "frac_hbm_peak": round(bytes_per * n / ms / 1e6 / 8000, 4)}
     if extra: r.update(extra)
     rows.append(r); print(json.dumps(r), flush=True)
-qt = svtlibs.quant_tables(8); qrow = {k: v[100].copy() for k, v in qt.items()}
+qt = pkg.tables.quant_tables(8); qrow = {k: v[100].copy() for k, v in qt.items()}
 only = sys.argv[1:] 
 def want(k): return not only or any(o in k for o in only)
 # forward transforms
@@ -43,7 +42,7 @@ if want("quantize"):
     for s, ls, n in ((3, 1, 1 << 20), (2, 0, 1 << 22)):
         w, h = TW[s], TH[s]
         c = torch.randint(-2000, 2001, (n, w * h), dtype=torch.int32, device=dev)
-        _, isc = svtlibs.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
+        _, isc = pkg.tables.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
         ms = timeit(lambda: dsp.quantize_b(c, qrow, iscan, ls))
         rec(f"quantize_b_{w}x{h}", n, 12 * w * h + 2, ms)
         del c
@@ -52,7 +51,7 @@ for s, n in ((1, 1 << 22), (2, 1 << 21), (4, 1 << 18), (0, 1 << 23)):
     if not want("fused_generic"): break
     w, h = TW[s], TH[s]
     src = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=dev); pred = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=dev)
-    _, isc = svtlibs.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
+    _, isc = pkg.tables.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
     nc = min(w, 32) * min(h, 32)
     outs = (torch.empty((n, nc), dtype=torch.int32, device=dev), torch.empty((n, nc), dtype=torch.int32, device=dev),
             torch.empty((n, nc), dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int16, device=dev), torch.zeros(n, dtype=torch.int32, device=dev))
@@ -92,11 +91,11 @@ if want("pixel"):
     del a, b
 # 10-bit (BASELINE configs[4]): fused chain and inverse on dense 16-bit blocks
 if want("bd10"):
-    qt10 = svtlibs.quant_tables(10); qrow10 = {k: v[100].copy() for k, v in qt10.items()}
+    qt10 = pkg.tables.quant_tables(10); qrow10 = {k: v[100].copy() for k, v in qt10.items()}
     for s, n in ((3, 1 << 20), (2, 1 << 21)):
         w, h = TW[s], TH[s]
         src = torch.randint(0, 1024, (n, h, w), dtype=torch.int16, device=dev); pred = torch.randint(0, 1024, (n, h, w), dtype=torch.int16, device=dev)
-        _, isc = svtlibs.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
+        _, isc = pkg.tables.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
         xy = None
         ms = timeit(lambda: dsp.fwd_quant_planes(src.view(n * h, w), w, pred.view(n * h, w), w,
                                                  torch.arange(n, dtype=torch.int32, device=dev) * (h << 16), s, 0, qrow10, iscan, bd=10), iters=4)
@@ -109,7 +108,7 @@ if want("bd10"):
 # BASELINE configs[4] shape: a shard of a 10-bit GOP, 16 luma frames of 1080p stacked in one plane, blocks addressed by
 # origin tables; forward+quant on planes, then inverse + reconstruction in place (15 B/px at 8-bit, 18 B/px at 10-bit)
 if want("gop"):
-    qt10 = svtlibs.quant_tables(10); qrow10 = {k: v[100].copy() for k, v in qt10.items()}
+    qt10 = pkg.tables.quant_tables(10); qrow10 = {k: v[100].copy() for k, v in qt10.items()}
     FR, PH, PW = 16, 1080, 1920
     srcp = torch.randint(0, 1024, (FR * PH, PW), dtype=torch.int16, device=dev)
     predp = (srcp + torch.randint(-12, 13, (FR * PH, PW), dtype=torch.int16, device=dev)).clamp(0, 1023)
@@ -118,7 +117,7 @@ if want("gop"):
         xs = np.arange(0, PW - S + 1, S); ys = np.concatenate([f * PH + np.arange(0, PH - S + 1, S) for f in range(FR)])
         xy = torch.from_numpy(np.array([(y << 16) | x for y in ys for x in xs], np.uint32).view(np.int32)).to(dev)
         offs = torch.from_numpy(np.array([y * PW + x for y in ys for x in xs], np.uint32).view(np.int32)).to(dev)
-        _, isc = svtlibs.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
+        _, isc = pkg.tables.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
         recon = predp.clone()
         def gop():
             co, q, dq, eob, _, _ = dsp.fwd_quant_planes(srcp, PW, predp, PW, xy, s, 0, qrow10, iscan, bd=10)
@@ -137,7 +136,7 @@ if want("encode_recon"):
     n = 1 << 20
     src = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device=dev)
     pred = (src.to(torch.int16) + torch.randint(-20, 21, (n, 32, 32), dtype=torch.int16, device=dev)).clamp(0, 255).to(torch.uint8)
-    _, isc = svtlibs.scan_tables(3, 0); iscan = torch.from_numpy(isc).to(dev)
+    _, isc = pkg.tables.scan_tables(3, 0); iscan = torch.from_numpy(isc).to(dev)
     rec(f"encode_recon_32x32_fused(qcoeff+recon)", n, 2048 + 4096 + 1024 + 6, timeit(lambda: dsp.encode_recon(src, pred, 3, 0, qrow, iscan, keep_coeff=False)))
     rec(f"encode_recon_32x32_fused(+coeff,dqcoeff)", n, 2048 + 3 * 4096 + 1024 + 6, timeit(lambda: dsp.encode_recon(src, pred, 3, 0, qrow, iscan, keep_coeff=True)))
     del src, pred
@@ -145,7 +144,7 @@ if want("encode_recon"):
         w, h = TW[s_], TH[s_]
         src = torch.randint(0, 256, (n, h, w), dtype=torch.uint8, device=dev)
         pred = (src.to(torch.int16) + torch.randint(-20, 21, (n, h, w), dtype=torch.int16, device=dev)).clamp(0, 255).to(torch.uint8)
-        _, isc = svtlibs.scan_tables(s_, 0); iscan = torch.from_numpy(isc).to(dev)
+        _, isc = pkg.tables.scan_tables(s_, 0); iscan = torch.from_numpy(isc).to(dev)
         kc = min(w, 32) * min(h, 32)
         rec(f"encode_recon_{w}x{h}_fused(qcoeff+recon)", n, 2 * w * h + 4 * kc + w * h + 6, timeit(lambda: dsp.encode_recon(src, pred, s_, 0, qrow, iscan, keep_coeff=False)))
         del src, pred

@@ -5,11 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import __graft_entry__ as ge
-import svtlibs
 pkg = ge.load_package(); dsp = pkg.SvtHipDsp(0)
 dev = torch.device("cuda:0")
 name = sys.argv[1]
-qt = svtlibs.quant_tables(8); qrow = {k: v[100].copy() for k, v in qt.items()}
+qt = pkg.tables.quant_tables(8); qrow = {k: v[100].copy() for k, v in qt.items()}
 if name == "sad_search":
     n = 1 << 20
     src = torch.randint(0, 256, (n, 16, 16), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 23, 23), dtype=torch.uint8, device=dev)

@@ -6,7 +6,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import __graft_entry__ as ge
-import svtlibs
 pkg = ge.load_package()
 dsp = pkg.SvtHipDsp(0)
 dev = torch.device("cuda:0")
@@ -14,8 +13,8 @@ n = 1 << 20
 g = torch.Generator(device=dev); g.manual_seed(13596)
 src = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device=dev, generator=g)
 pred = torch.randint(0, 256, (n, 32, 32), dtype=torch.uint8, device=dev, generator=g)
-qt = svtlibs.quant_tables(8); qrow = {k: v[100].copy() for k, v in qt.items()}
-_, isc = svtlibs.scan_tables(3, 0); iscan = torch.from_numpy(isc).to(dev)
+qt = pkg.tables.quant_tables(8); qrow = {k: v[100].copy() for k, v in qt.items()}
+_, isc = pkg.tables.scan_tables(3, 0); iscan = torch.from_numpy(isc).to(dev)
 outs = (torch.empty((n, 1024), dtype=torch.int32, device=dev), torch.empty((n, 1024), dtype=torch.int32, device=dev),
         torch.empty((n, 1024), dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int16, device=dev),
         torch.zeros(n, dtype=torch.int32, device=dev))
