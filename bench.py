@@ -43,15 +43,52 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(src_np, pred_np, qrow, gpu_out, budget_s=12.0):
-    """Time the reference's production AVX2 path (kind 'reference') on all host
-    cores over a bounded sample of the same workload; verify GPU == CPU on it."""
+def host_cpu_info():
+    """(model name, physical cores this process may run on) from /proc/cpuinfo; SMT siblings share a
+    (physical id, core id) pair."""
+    model, phys = "unknown", set()
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = None
+    try:
+        cpu = pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                cpu, pid, cid = int(v), 0, None
+            elif k == "model name":
+                model = v
+            elif k == "physical id":
+                pid = int(v)
+            elif k == "core id":
+                cid = int(v)
+            elif not k and cpu is not None:
+                if allowed is None or cpu in allowed:
+                    phys.add((pid, cid if cid is not None else cpu))
+                cpu = None
+    except OSError:
+        pass
+    return model, (len(phys) or host_cores())
+
+
+def cpu_baseline_child(in_path, out_path, budget_s):
+    """Runs in a CHILD process without torch / HIP (python bench.py --cpu-baseline-child ...): times the
+    reference's production AVX2 path (kind 'reference', oracle/_ref) or, when that build is absent, the
+    scalar oracle (kind 'port') over a bounded sample, and writes its outputs for the first blocks so
+    that the parent can compare the GPU run bit for bit.  A crash here costs the bench its cpu_baseline
+    object, never the GPU line."""
     import svtlibs
     P = svtlibs.ptr
+    z = np.load(in_path)
+    src_np, pred_np = z["src"], z["pred"]
+    tabs = [np.ascontiguousarray(z[k]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
     R = svtlibs.ref()
-    cores = host_cores()
-    tabs = [np.ascontiguousarray(qrow[k]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
+    logical = host_cores()
+    model, physical = host_cpu_info()
     navail = src_np.shape[0]
+    info = {"unit": "blocks/s", "cpu_model": model, "physical_cores": physical, "logical_cpus": logical}
 
     def run_ref(n, threads, keep):
         co = np.zeros((n, 1024), np.int32) if keep else None
@@ -61,26 +98,34 @@ def cpu_baseline(src_np, pred_np, qrow, gpu_out, budget_s=12.0):
         t = R.ref_bench_fwd_quant_sad(P(src_np), P(pred_np), ctypes.c_size_t(n), threads, 1, P(tabs[0]), P(tabs[1]),
                                       P(tabs[2]), P(tabs[3]), P(tabs[4]), P(co) if keep else None,
                                       P(q) if keep else None, P(dq) if keep else None, P(eob), P(sad))
-        return t, (co, q, dq, eob, sad)
+        if t <= 0:
+            raise RuntimeError("ref_bench_fwd_quant_sad reported a failed worker (see stderr)")
+        return t, int(R.ref_bench_threads_used()), (co, q, dq, eob, sad)
 
     if R is not None:
-        kind = "reference"
         ncal = min(4096, navail)
-        t1, _ = run_ref(ncal, 1, False)                       # calibrate, 1 thread
+        t1, _, _ = run_ref(ncal, 1, False)                    # calibrate, 1 thread
         rate1 = ncal / t1
-        n = int(min(navail, max(ncal, rate1 * cores * budget_s * 0.6)))
-        run_ref(min(n, 8192), cores, False)                   # warm the pool / caches
-        t, _ = run_ref(n, cores, False)
-        value = n / t
-        # parity of the GPU run against the reference on a verified sub-sample
-        nv = min(n, 16384)
-        _, (co, q, dq, eob, sad) = run_ref(nv, cores, True)
-        sample = f"{n} of the step's blocks, {cores} pthreads, reference AVX2 kernels (oracle/_ref), qindex {QINDEX}"
-        one = {"value_1thread": rate1}
+        counts = sorted({physical, logical})                  # one thread per core, then SMT siblings too
+        reps = 3                                              # best of 3 (a shared host is noisy; be fair to the CPU)
+        per_rep = budget_s / (len(counts) * reps + 0.5)
+        best = None
+        for threads in counts:
+            n = int(min(navail, max(ncal, rate1 * threads * per_rep * 0.6)))
+            run_ref(min(n, 8192), threads, False)             # warm the pool / caches
+            t, used = min(run_ref(n, threads, False)[:2] for _ in range(reps))
+            leg = {"threads_asked": threads, "threads": used, "blocks": n, "value": n / t, "reps": reps}
+            info.setdefault("legs", []).append(leg)
+            if best is None or leg["value"] > best["value"]:
+                best = leg
+        nv = min(navail, 16384)
+        _, _, (co, q, dq, eob, sad) = run_ref(nv, min(logical, 64), True)
+        info.update({"value": best["value"], "cores": best["threads"], "kind": "reference", "value_1thread": rate1,
+                     "sample": f"{best['blocks']} of the step's blocks on {best['threads']} pthreads ({physical} physical "
+                               f"cores / {logical} logical CPUs of {model}), reference AVX2 kernels (oracle/_ref), "
+                               f"qindex {QINDEX}"})
     else:                                                    # no reference build here: scalar port
-        kind = "port"
         O = svtlibs.oracle()
-        cores = 1
         n = nv = min(navail, 2048)
         co = np.zeros((n, 1024), np.int32); q = np.zeros((n, 1024), np.int32); dq = np.zeros((n, 1024), np.int32)
         eob = np.zeros(n, np.uint16); sad = np.zeros(n, np.uint32)
@@ -89,21 +134,48 @@ def cpu_baseline(src_np, pred_np, qrow, gpu_out, budget_s=12.0):
             O.svt_oracle_fwd_quant_sad(P(src_np[i]), 32, P(pred_np[i]), 32, 3, 0, P(tabs[0]), P(tabs[1]), P(tabs[2]),
                                        P(tabs[3]), P(tabs[4]), P(co[i]), P(q[i]), P(dq[i]), P(eob[i:i + 1]),
                                        P(sad[i:i + 1]))
-        value = n / (time.perf_counter() - t0)
-        sample = f"{n} blocks, 1 thread, scalar C oracle (oracle/_ref not present)"
-        one = {}
-    g_co, g_q, g_dq, g_eob, g_sad = gpu_out
-    ok = (np.array_equal(g_co[:nv].cpu().numpy(), co[:nv]) and np.array_equal(g_q[:nv].cpu().numpy(), q[:nv])
-          and np.array_equal(g_dq[:nv].cpu().numpy(), dq[:nv])
-          and np.array_equal(g_eob[:nv].cpu().numpy().view(np.uint16), eob[:nv])
-          and np.array_equal(g_sad[:nv].cpu().numpy().view(np.uint32), sad[:nv]))
-    out = {"value": value, "unit": "blocks/s", "cores": cores, "kind": kind, "sample": sample,
-           "gpu_equals_cpu_on_sample": bool(ok), "verified_blocks": int(nv)}
-    out.update(one)
-    return out
+        info.update({"value": n / (time.perf_counter() - t0), "cores": 1, "kind": "port",
+                     "sample": f"{n} blocks, 1 thread, scalar C oracle (oracle/_ref not present)"})
+    np.savez(out_path, co=co[:nv], q=q[:nv], dq=dq[:nv], eob=eob[:nv], sad=sad[:nv], info=json.dumps(info))
+
+
+def cpu_baseline(src_np, pred_np, qrow, gpu_out, budget_s=14.0):
+    """cpu_baseline object of the JSON line: the child above, run as a separate process (the GPU process never
+    loads oracle/ code), its stderr passed through, and the GPU outputs compared with its outputs."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="svt_cpu_baseline_") as td:
+        inp, outp = os.path.join(td, "in.npz"), os.path.join(td, "out.npz")
+        np.savez(inp, src=src_np, pred=pred_np, **{k: np.ascontiguousarray(qrow[k]) for k in
+                                                   ("zbin", "round", "quant", "quant_shift", "dequant")})
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", inp, outp,
+                             str(budget_s)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if pr.stderr:
+            sys.stderr.write("[cpu_baseline stderr]\n" + pr.stderr[-4000:] + "\n")
+        if pr.returncode != 0 or not os.path.exists(outp):
+            return {"value": None, "unit": "blocks/s", "cores": 0, "kind": "reference",
+                    "sample": "cpu baseline leg FAILED", "error": f"exit code {pr.returncode}",
+                    "stderr_tail": pr.stderr[-600:]}
+        z = np.load(outp)
+        out = json.loads(str(z["info"]))
+        nv = z["co"].shape[0]
+        g_co, g_q, g_dq, g_eob, g_sad = gpu_out
+        ok = (np.array_equal(g_co[:nv].cpu().numpy(), z["co"]) and np.array_equal(g_q[:nv].cpu().numpy(), z["q"])
+              and np.array_equal(g_dq[:nv].cpu().numpy(), z["dq"])
+              and np.array_equal(g_eob[:nv].cpu().numpy().view(np.uint16), z["eob"])
+              and np.array_equal(g_sad[:nv].cpu().numpy().view(np.uint32), z["sad"]))
+        out["gpu_equals_cpu_on_sample"] = bool(ok)
+        out["verified_blocks"] = int(nv)
+        return out
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-baseline-child":
+        cpu_baseline_child(sys.argv[2], sys.argv[3], float(sys.argv[4]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

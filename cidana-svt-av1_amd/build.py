@@ -14,8 +14,12 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libsvt_hip_dsp.so")
 SOURCES = ["csrc/svt_hip_dsp.hip"]
-DEPS = ["csrc/svt_hip_dsp.hip", "csrc/dev_common.h", "csrc/kernel_fused32.h", "csrc/kernel_txfm.h",
-        "csrc/kernel_pixel.h", "csrc/kernel_intra.h", "csrc/kernel_me.h", "csrc/kernel_txfm_staged.h", "csrc/gen/txfm1d_gen.h", "../include/svt_hip_dsp.h"]
+import glob as _glob
+# every header the translation unit can include (kernel_cfl.h / kernel_ois.h were missing from a hand-kept list)
+DEPS = (["csrc/svt_hip_dsp.hip", "../include/svt_hip_dsp.h"]
+        + sorted(os.path.relpath(p, os.path.dirname(os.path.abspath(__file__)))
+                 for p in _glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "*.h"))
+                 + _glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "gen", "*.h"))))
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-fwrapv",
                "-Wall", "-Wno-unused-function"]
 

@@ -52,6 +52,28 @@ void svt_oracle_full_distortion32(const int32_t *coeff, uint32_t coeff_stride, c
     out[0] = resid; out[1] = pred;
 }
 
+/* The same sums as the reference's AVX2 kernel forms them (full_distortion_kernel32_bits_avx2,
+ * EbPictureOperators_Intrinsic_AVX2.c:1955-2011): four 64-bit lanes, one per column mod 4; the squared difference is
+ * the signed product of the LOW 32 bits of the 64-bit difference (_mm256_mul_epi32) and is accumulated with
+ * _mm256_add_epi32, i.e. the low and the high 32-bit halves of a lane add separately, without a carry between them.
+ * The prediction sum (and the whole cbf_zero kernel) adds in 64 bits like the C code.  width % 4 == 0. */
+void svt_oracle_full_distortion32_avx2(const int32_t *coeff, uint32_t coeff_stride, const int32_t *recon,
+                                       uint32_t recon_stride, uint64_t out[2], uint32_t width, uint32_t height) {
+    uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    uint64_t pred = 0, resid = 0;
+    for (uint32_t y = 0; y < height; y++, coeff += coeff_stride, recon += recon_stride)
+        for (uint32_t x = 0; x < width; x++) {
+            const int64_t d = (int64_t)coeff[x] - (int64_t)recon[x], c = coeff[x];
+            const int64_t dl = (int32_t)(uint32_t)(uint64_t)d;            /* low 32 bits, sign-extended */
+            const uint64_t sq = (uint64_t)(dl * dl);
+            lo[x & 3] += (uint32_t)sq;
+            hi[x & 3] += (uint32_t)(sq >> 32);
+            pred += (uint64_t)(c * c);
+        }
+    for (int l = 0; l < 4; l++) resid += ((uint64_t)hi[l] << 32) | lo[l];
+    out[0] = resid; out[1] = pred;
+}
+
 /* residual_kernel_c, EbPictureOperators.c:166-193 */
 void svt_oracle_residual(const uint8_t *src, uint32_t src_stride, const uint8_t *pred,
                          uint32_t pred_stride, int16_t *res, uint32_t res_stride, uint32_t width,
@@ -165,4 +187,131 @@ void svt_oracle_fwd_quant_planes(const void *src, uint32_t src_stride, const voi
     if (sad) *sad = acc;
     if (energy) *energy = e;
     free(res); free(full); free(scan);
+}
+
+/* ---- K6 in the reference's own result layout, square + non-square PUs, both production flavours ---------------
+ * best_sad / best_mv: uint32[209] in EbMeTierZeroPu order (EbMotionEstimationContext.h:47-270), i.e. the reference's
+ * p_sb_best_sad[list][ref][...] / p_sb_best_mv[...]: 64x64 [0], 32x32 [1..4], 16x16 [5..20], 8x8 [21..84] and, when
+ * nsq != 0 (open_loop_me_fullpel_search_sblock, EbMotionEstimation.c:3251, used when nsq_search_level is between
+ * LEVEL1 and FULL, :7629), 64x32 [85..86], 32x16 [87..94], 16x8 [95..126], 32x64 [127..128], 16x32 [129..136],
+ * 8x16 [137..168], 32x8 [169..184], 8x32 [185..200], 64x16 [201..204], 16x64 [205..208]; sums as
+ * ext_eigth_sad_calculation_nsq_c (:1455-2490) / ext_sad_calculation (single search point) form them from the 8x8 /
+ * 16x16 / 32x32 SADs.  Search points in raster order, strict '<' against the running best.
+ *
+ * flavour 0 = the scalar C / SSE4.1 kernels (asm_type 0).  flavour 1 = what an AVX2 build made with GCC or clang
+ * really computes (asm_type 1, the only value production accepts, EbEncHandle.c:2676): in
+ * get_eight_horizontal_search_point_results_32x32_64x64_pu_avx2_intrin (EbComputeSAD_Intrinsic_AVX2.c:3696-4072) the
+ * `#ifdef __GNUC__` branch (:3989-4001) swaps the two 128-bit halves, so for the four 32x32 PUs, inside every full group
+ * of eight search points of FullPelSearch_LCU (:3220), the search point p of the group is taken as p ^ 4 - for the
+ * tie-break between equal SADs and for the motion vector that is stored (the SAD value stays the true minimum).
+ * The remainder points of a row (GetSearchPointResults, :2932) and every other PU size are unaffected.  The NSQ path's
+ * 8-point AVX2 kernels agree with the C ones; its single-search-point form (remainder points: production rounds the
+ * search width down to a multiple of 8 unless it is below 8, :8016-8021) has two more quirks, restated where they apply
+ * below: ExtSadCalculation's stale-`sad` test for 32x16_5 (both flavours) and the AVX2 kernel's source-stride row fetch. */
+static void me_update(uint32_t *bs, uint32_t *bm, int idx, uint32_t sad, uint32_t mv) {
+    if (sad < bs[idx]) { bs[idx] = sad; bm[idx] = mv; }
+}
+
+/* SADs of one search point: 64 8x8 (every other row, doubled: Compute8x4SAD_Kernel with 2x strides, :121-143, 208-262),
+ * 16 16x16 in the reference's z-order, 4 32x32, 64x64 */
+static void me_point_sads(const uint8_t *src, uint32_t src_stride, const uint8_t *r0, uint32_t ref_stride,
+                          uint32_t s8[64], uint32_t s16[16], uint32_t s32[4], uint32_t *s64, int avx2_row_bug) {
+    for (int by16 = 0; by16 < 4; by16++)
+        for (int bx16 = 0; bx16 < 4; bx16++) {
+            const int z = ((by16 >> 1) * 2 + (bx16 >> 1)) * 4 + (by16 & 1) * 2 + (bx16 & 1);
+            s16[z] = 0;
+            for (int k = 0; k < 4; k++) {
+                const int x0 = bx16 * 16 + (k & 1) * 8, y0 = by16 * 16 + (k >> 1) * 8;
+                uint32_t s = 0;
+                for (int rr = 0; rr < 4; rr++) {
+                    /* ext_sad_calculation_8x8_16x16_avx2_intrin (EbComputeSAD_Intrinsic_AVX2.c:50-52) fetches the first
+                     * sampled reference row of the lower 8x8 pair at `ref + 4 * src_stride` (strides already doubled):
+                     * 8 SOURCE strides below the 16x16 block's reference origin instead of 8 reference strides */
+                    const uint8_t *rrow = (avx2_row_bug && k >= 2 && rr == 0)
+                        ? r0 + (size_t)(by16 * 16) * ref_stride + (size_t)8 * src_stride
+                        : r0 + (size_t)(y0 + 2 * rr) * ref_stride;
+                    for (int c = 0; c < 8; c++)
+                        s += (uint32_t)abs((int)src[(size_t)(y0 + 2 * rr) * src_stride + x0 + c] - (int)rrow[x0 + c]);
+                }
+                s8[4 * z + k] = s << 1;
+                s16[z] += s8[4 * z + k];
+            }
+        }
+    *s64 = 0;
+    for (int q = 0; q < 4; q++) { s32[q] = s16[4 * q] + s16[4 * q + 1] + s16[4 * q + 2] + s16[4 * q + 3]; *s64 += s32[q]; }
+}
+
+static void me_nsq_update(const uint32_t s8[64], const uint32_t s16[16], const uint32_t s32[4], uint32_t mv,
+                          uint32_t *best_sad, uint32_t *best_mv, int single_point) {
+    uint32_t s32x16[8], s16x8[32], s16x32[8], s8x16[32];
+    for (int i = 0; i < 2; i++) me_update(best_sad, best_mv, 85 + i, s32[2 * i] + s32[2 * i + 1], mv);
+    for (int i = 0; i < 8; i++) {
+        s32x16[i] = s16[2 * i] + s16[2 * i + 1];
+        if (single_point && i == 5) {
+            /* ExtSadCalculation (EbMotionEstimation.c:732-736, the single-search-point form) tests the stale `sad`
+             * of the 64x32_1 sum here, not sad_32x16[5], and then stores sad_32x16[5] */
+            if (s32[2] + s32[3] < best_sad[87 + 5]) { best_sad[87 + 5] = s32x16[5]; best_mv[87 + 5] = mv; }
+        } else {
+            me_update(best_sad, best_mv, 87 + i, s32x16[i], mv);
+        }
+    }
+    for (int i = 0; i < 32; i++) { s16x8[i] = s8[2 * i] + s8[2 * i + 1]; me_update(best_sad, best_mv, 95 + i, s16x8[i], mv); }
+    for (int i = 0; i < 2; i++) me_update(best_sad, best_mv, 127 + i, s32[i] + s32[i + 2], mv);
+    for (int i = 0; i < 8; i++) {
+        const int b = (i >> 1) * 4 + (i & 1);
+        s16x32[i] = s16[b] + s16[b + 2];
+        me_update(best_sad, best_mv, 129 + i, s16x32[i], mv);
+    }
+    for (int i = 0; i < 32; i++) {
+        const int b = (i >> 1) * 4 + (i & 1);
+        s8x16[i] = s8[b] + s8[b + 2];
+        me_update(best_sad, best_mv, 137 + i, s8x16[i], mv);
+    }
+    for (int i = 0; i < 16; i++) {
+        const int b = (i >> 1) * 4 + (i & 1);
+        me_update(best_sad, best_mv, 169 + i, s16x8[b] + s16x8[b + 2], mv);
+    }
+    for (int i = 0; i < 16; i++) {
+        const int b = (i >> 2) * 8 + (i & 3);
+        me_update(best_sad, best_mv, 185 + i, s8x16[b] + s8x16[b + 4], mv);
+    }
+    for (int i = 0; i < 4; i++) {
+        const int b = (i >> 1) * 4 + (i & 1);
+        me_update(best_sad, best_mv, 201 + i, s32x16[b] + s32x16[b + 2], mv);
+    }
+    for (int i = 0; i < 4; i++) me_update(best_sad, best_mv, 205 + i, s16x32[i] + s16x32[i + 4], mv);
+}
+
+void svt_oracle_me_sb_search_full(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride,
+                                  int search_w, int search_h, int x_origin, int y_origin, int flavour, int nsq,
+                                  uint32_t *best_sad, uint32_t *best_mv) {
+    const int w8 = search_w & ~7;
+    const int quirk = flavour == 1 && !nsq;
+    for (int ys = 0; ys < search_h; ys++) {
+        const uint32_t mvy = ((uint32_t)(uint16_t)(ys + y_origin)) << 18;
+        for (int xg = 0; xg < search_w; xg += 8) {
+            const int np = search_w - xg < 8 ? search_w - xg : 8;
+            uint32_t g32[8][4];
+            for (int p = 0; p < np; p++) {
+                const int xs = xg + p;
+                const uint32_t mv = mvy | (uint32_t)(uint16_t)((xs + x_origin) << 2);
+                uint32_t s8[64], s16[16], s64;
+                const int single = xg >= w8;      /* GetSearchPointResults / open_loop_me_get_search_point_results_block */
+                me_point_sads(src, src_stride, ref + xs + (size_t)ys * ref_stride, ref_stride, s8, s16, g32[p], &s64,
+                              flavour == 1 && nsq && single);
+                me_update(best_sad, best_mv, 0, s64, mv);
+                if (!(quirk && xg < w8))
+                    for (int q = 0; q < 4; q++) me_update(best_sad, best_mv, 1 + q, g32[p][q], mv);
+                for (int i = 0; i < 16; i++) me_update(best_sad, best_mv, 5 + i, s16[i], mv);
+                for (int i = 0; i < 64; i++) me_update(best_sad, best_mv, 21 + i, s8[i], mv);
+                if (nsq) me_nsq_update(s8, s16, g32[p], mv, best_sad, best_mv, single);
+            }
+            if (quirk && xg < w8)
+                /* the swapped halves: the group's points are ranked, and reported, as p ^ 4 */
+                for (int pa = 0; pa < 8; pa++)
+                    for (int q = 0; q < 4; q++)
+                        me_update(best_sad, best_mv, 1 + q, g32[pa ^ 4][q],
+                                  mvy | (uint32_t)(uint16_t)((xg + pa + x_origin) << 2));
+        }
+    }
 }

@@ -16,6 +16,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <pthread.h>
 #include <time.h>
@@ -52,16 +53,22 @@ typedef struct {
     int32_t *coeff, *qcoeff, *dqcoeff; /* n x 1024 (may be NULL: per-thread scratch) */
     uint16_t *eob; uint32_t *sad;
     const int16_t *zbin, *round, *quant, *quant_shift, *dequant; /* int16[8], 16-B aligned */
-    size_t begin, end; int avx2;
+    size_t begin, end; int avx2; int failed;
 } ChainJob;
 
 static void *chain_worker(void *arg) {
     ChainJob *j = (ChainJob *)arg;
     const int16_t *scan = av1_scan_orders[TX_32X32][DCT_DCT].scan;
     const int16_t *iscan = av1_scan_orders[TX_32X32][DCT_DCT].iscan;
-    int16_t *res; int32_t *sc;
-    if (posix_memalign((void **)&res, 32, 1024 * sizeof(int16_t))) return NULL;
-    if (posix_memalign((void **)&sc, 32, 3 * 1024 * sizeof(int32_t))) return NULL;
+    int16_t *res = NULL; int32_t *sc = NULL;
+    if (posix_memalign((void **)&res, 32, 1024 * sizeof(int16_t)) ||
+        posix_memalign((void **)&sc, 32, 3 * 1024 * sizeof(int32_t))) {
+        /* fail loudly: the caller sees failed != 0 and reports no number */
+        fprintf(stderr, "ref_bench: posix_memalign failed in a worker (blocks %zu..%zu not computed)\n", j->begin, j->end);
+        free(res);
+        j->failed = 1;
+        return NULL;
+    }
     for (size_t b = j->begin; b < j->end; b++) {
         uint8_t *s = (uint8_t *)j->src + b * 1024, *p = (uint8_t *)j->pred + b * 1024;
         /* always compute into 32-B aligned scratch (the AVX2 kernels use aligned
@@ -90,25 +97,54 @@ static void *chain_worker(void *arg) {
     return NULL;
 }
 
-/* returns elapsed seconds for n blocks on `threads` pthreads */
+/* Threads the last ref_bench_fwd_quant_sad call really ran on (pthread_create can fail with EAGAIN on a box
+ * that limits processes / threads: round 1's first hardware run asked for 256 threads beside torch's own pools
+ * and joined pthread_t slots that had never been created). */
+static int g_threads_used;
+int ref_bench_threads_used(void) { return g_threads_used; }
+
+/* returns elapsed seconds for n blocks on up to `threads` pthreads (the calling thread works too, and takes
+ * over the share of every thread that could not be created); a negative value = a worker failed, no number. */
 double ref_bench_fwd_quant_sad(const uint8_t *src, const uint8_t *pred, size_t n, int threads, int avx2,
                                const int16_t *zbin, const int16_t *round, const int16_t *quant,
                                const int16_t *quant_shift, const int16_t *dequant,
                                int32_t *coeff, int32_t *qcoeff, int32_t *dqcoeff,
                                uint16_t *eob, uint32_t *sad) {
     if (threads < 1) threads = 1;
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
-    ChainJob *jobs = (ChainJob *)malloc(sizeof(ChainJob) * threads);
+    if (threads > 1024) threads = 1024;
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    char *created = (char *)calloc((size_t)threads, 1);
+    ChainJob *jobs = (ChainJob *)calloc((size_t)threads, sizeof(ChainJob));
+    if (!th || !created || !jobs) {
+        fprintf(stderr, "ref_bench: out of memory for %d job slots\n", threads);
+        free(th); free(created); free(jobs);
+        return -1.0;
+    }
     struct timespec t0, t1;
+    int used = 1, failed = 0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int t = 0; t < threads; t++) {
         ChainJob j = {src, pred, coeff, qcoeff, dqcoeff, eob, sad, zbin, round, quant, quant_shift, dequant,
-                      n * t / threads, n * (t + 1) / threads, avx2};
+                      n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads, avx2, 0};
         jobs[t] = j;
-        pthread_create(&th[t], NULL, chain_worker, &jobs[t]);
     }
-    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    /* slot 0 is the calling thread's own share */
+    for (int t = 1; t < threads; t++) {
+        int rc = pthread_create(&th[t], NULL, chain_worker, &jobs[t]);
+        if (rc == 0) { created[t] = 1; used++; }
+    }
+    chain_worker(&jobs[0]);
+    for (int t = 1; t < threads; t++)
+        if (!created[t]) chain_worker(&jobs[t]);      /* shares of threads that never started */
+    for (int t = 1; t < threads; t++)
+        if (created[t]) pthread_join(th[t], NULL);
     clock_gettime(CLOCK_MONOTONIC, &t1);
-    free(th); free(jobs);
+    for (int t = 0; t < threads; t++) failed |= jobs[t].failed;
+    if (used < threads)
+        fprintf(stderr, "ref_bench: only %d of %d threads could be created; the rest of the work ran on the caller\n",
+                used, threads);
+    g_threads_used = used;
+    free(th); free(created); free(jobs);
+    if (failed) return -1.0;
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

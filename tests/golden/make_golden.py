@@ -337,6 +337,176 @@ def gen_ois():
     np.savez_compressed(os.path.join(HERE, "ois.npz"), **d)
 
 
+
+def aligned(shape, dt, al=64):
+    """numpy array whose data pointer is `al`-byte aligned (the reference's AVX2 kernels use aligned loads / stores,
+    as the encoder's own buffers are aligned)"""
+    n = int(np.prod(shape)); it = np.dtype(dt).itemsize
+    raw = np.zeros(n * it + al, np.uint8)
+    off = (-raw.ctypes.data) % al
+    return raw[off:off + n * it].view(dt).reshape(shape)
+
+
+ME_PUS = 209
+ME_MAX_SAD = 128 * 128 * 255        # MAX_SAD_VALUE, EbMotionEstimation.h:79
+# (search_w, search_h, x_origin, y_origin, content): content 0 random, 1 coarse (many ties), 2 very coarse, 3 constant (max SAD)
+ME_CASES = [(8, 1, 0, 0, 0), (16, 3, -8, -1, 0), (24, 2, -12, -1, 1), (64, 4, -32, -2, 0), (8, 8, -4, -4, 2),
+            (7, 3, -3, -1, 0), (5, 2, 2, 3, 1), (1, 1, 0, 0, 0), (21, 2, -10, 0, 0), (13, 3, -40, -20, 1),
+            (16, 2, -8, -1, 3), (40, 5, -37, 6, 2), (3, 1, -1, 0, 3), (32, 2, 5, -9, 1)]
+
+
+def gen_me():
+    """K6: the reference's OWN full-pel search drivers FullPelSearch_LCU / open_loop_me_fullpel_search_sblock
+    (EbMotionEstimation.c:3199, 3251), reached through oracle/ref_me.c, for asm_type 0 (C / SSE4.1 kernels) and
+    asm_type 1 (the AVX2 8-search-point production kernels), square PUs only (nsq 0) and with the non-square PUs
+    (nsq 1), in the reference's p_sb_best_sad / p_sb_best_mv layout (209 entries).  The last two cases chain a second
+    search onto the running bests of the first (IN/OUT semantics).  Divergences between the two asm types are NOT
+    asserted away here - they are what `flavour` in the oracle / product restates."""
+    rng = np.random.default_rng(13602)
+    d = {"cases": np.array(ME_CASES, np.int32)}
+    ndiff = 0
+    for k, (sw, sh, xo, yo, content) in enumerate(ME_CASES):
+        stride = 64 + sw + 8 + (k % 5) * 3
+        rows = 64 + sh + 4
+        src = rng.integers(0, 256, size=(64, 64), dtype=np.uint8)
+        win = rng.integers(0, 256, size=(rows, stride), dtype=np.uint8)
+        if content == 1:
+            src = (src >> 6) << 6; win = (win >> 6) << 6
+        elif content == 2:
+            src = (src >> 7) << 7; win = (win >> 7) << 7
+        elif content == 3:
+            src[:] = 0; win[:] = 255
+        src = np.ascontiguousarray(src); win = np.ascontiguousarray(win)
+        d[f"c{k}_src"] = src; d[f"c{k}_win"] = win
+        res = {}
+        for asm in (0, 1):
+            for nsq in (0, 1):
+                bs = np.zeros(ME_PUS, np.uint32); bm = np.zeros(ME_PUS, np.uint32)
+                rc = R.ref_me_fullpel(ptr(src), 64, ptr(win), stride, xo, yo, sw, sh, asm, nsq, 1, ptr(bs), ptr(bm))
+                assert rc == 0
+                if k >= len(ME_CASES) - 2:      # chain: search again, shifted by one row / column, on the running bests
+                    rc = R.ref_me_fullpel(ptr(src), 64, ctypes.c_void_p(win.ctypes.data + stride + 1), stride, xo + 1, yo + 1,
+                                          max(1, sw - 1), sh, asm, nsq, 0, ptr(bs), ptr(bm))
+                    assert rc == 0
+                n = ME_PUS if nsq else 85
+                d[f"c{k}_sad_a{asm}_n{nsq}"] = bs[:n].copy(); d[f"c{k}_mv_a{asm}_n{nsq}"] = bm[:n].copy()
+                res[(asm, nsq)] = (bs[:n].copy(), bm[:n].copy())
+        for nsq in (0, 1):
+            ndiff += int(not (np.array_equal(res[(0, nsq)][0], res[(1, nsq)][0]) and np.array_equal(res[(0, nsq)][1], res[(1, nsq)][1])))
+    d["asm_divergent_cases"] = np.array([ndiff], np.int32)
+    np.savez_compressed(os.path.join(HERE, "me.npz"), **d)
+    print("me.npz: (case, nsq) pairs on which asm_type 0 and 1 disagree:", ndiff)
+
+
+def gen_pins():
+    """Caller-level functions of the transform path, through oracle/ref_pins.c (the reference's own functions, its own
+    RTCD dispatch):  av1_estimate_transform incl. the 64-point re-pack + three_quad_energy (EbTransforms.c:4918-5292,
+    4351-4408); the 8-bit reconstruction entry av1_inv_txfm_add_c (:8882) == av1_inv_txfm_add_ssse3 (production slot)
+    == av1_inv_transform_recon8bit (:8939); full_distortion_kernel32_bits / _cbf_zero32_bits (EbPictureOperators.c:283-346,
+    C == AVX2 asserted) and picture_full_distortion32_bits (:349); av1_inv_txfm2d_add_*_c at the clamp limits (bd 8/10/12)."""
+    rng = np.random.default_rng(13603)
+    d = {}
+    # ---- av1_estimate_transform
+    for s in (4, 11, 12, 17, 18, 3, 2, 9, 16):           # the five 64-point sizes, 32x32, 16x16, 16x32, 32x8
+        w, h = TX_W[s], TX_H[s]
+        n = min(w, 32) * min(h, 32)
+        for t in (0, 9):
+            if not txfm_allowed(s, t):
+                continue
+            for bi in (0, 1):
+                bd = 10 if bi else 8
+                m = (1 << bd) - 1
+                xs = np.stack([rng.integers(-m, m + 1, size=(h, w)), np.full((h, w), m),
+                               (np.indices((h, w)).sum(0) % 2 * 2 * m - m)]).astype(np.int16)
+                cos = np.zeros((3, n), np.int32); es = np.zeros(3, np.uint64)
+                for i in range(3):
+                    x = aligned((h, 64), np.int16); x[:, :w] = xs[i]
+                    co = aligned(w * h + 64, np.int32); e = np.zeros(1, np.uint64)
+                    rc = R.ref_estimate_transform(ptr(x), ctypes.c_uint32(64), ptr(co), c_int(s), c_int(t), c_int(bi), ptr(e))
+                    assert rc == 0
+                    cos[i] = co[:n]; es[i] = e[0]
+                key = f"est_{s}_{t}_{bd}"
+                d[key + "_in"] = xs; d[key + "_coeff"] = cos; d[key + "_energy"] = es
+    # ---- 8-bit inverse entry
+    for s in range(19):
+        w, h = TX_W[s], TX_H[s]
+        kw, kh = min(w, 32), min(h, 32)
+        for t in range(16):
+            if not txfm_allowed(s, t):
+                continue
+            x = aligned((h, 64), np.int16); x[:, :w] = rng.integers(-255, 256, size=(h, w))
+            full = aligned(w * h + 64, np.int32); e = np.zeros(1, np.uint64)
+            R.ref_estimate_transform(ptr(x), ctypes.c_uint32(64), ptr(full), c_int(s), c_int(t), c_int(0), ptr(e))
+            cos = np.zeros((2, kw * kh), np.int32)
+            cos[0] = full[:kw * kh]
+            cos[1] = full[:kw * kh]; cos[1, max(1, kw * kh // 5):] = 0
+            dst0 = rng.integers(0, 256, size=(2, h, w), dtype=np.uint8)
+            dst1 = np.zeros_like(dst0)
+            for i in range(2):
+                outs = []
+                for which in (0, 1, 2):
+                    co = aligned(kw * kh + 64, np.int32); co[:kw * kh] = cos[i]
+                    dd = aligned((h, 96), np.uint8); dd[:, :w] = dst0[i]
+                    R.ref_inv_txfm_add_u8(ptr(co), ptr(dd), c_int(96), c_int(t), c_int(s), c_int(kw * kh), c_int(which))
+                    outs.append(dd[:, :w].copy())
+                # production (SSSE3 low-bit-depth code) == C on transform-consistent input (InvTxfm2dAsmTest lowbd sub-test)
+                assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), (TX_SIZES[s], TX_TYPES[t], i)
+                dst1[i] = outs[0]
+            key = f"inv8_{s}_{t}"
+            d[key + "_coeff"] = cos; d[key + "_dst_in"] = dst0; d[key + "_dst_out"] = dst1
+    # ---- coefficient-domain distortion
+    for (w, h) in ((4, 4), (8, 8), (16, 16), (32, 32), (8, 16), (32, 8), (16, 64), (64, 64)):
+        mags = (8, 15, 20, 26)
+        a = np.stack([rng.integers(-(1 << m), 1 << m, size=(h, w + 8)) for m in mags]).astype(np.int32)
+        b = np.stack([rng.integers(-(1 << m), 1 << m, size=(h, w + 8)) for m in mags]).astype(np.int32)
+        out = np.zeros((4, 2, 2), np.uint64)        # [case][cbf_zero][2]: the C kernels
+        out_avx2 = np.zeros((4, 2, 2), np.uint64)   # the AVX2 kernels (production slot)
+        for i in range(4):
+            aa = aligned(a[i].shape, np.int32); aa[:] = a[i]
+            bb = aligned(b[i].shape, np.int32); bb[:] = b[i]
+            for z, names in enumerate((("full_distortion_kernel32_bits", "full_distortion_kernel32_bits_avx2"),
+                                       ("full_distortion_kernel_cbf_zero32_bits", "full_distortion_kernel_cbf_zero32_bits_avx2"))):
+                r = [np.zeros(2, np.uint64) for _ in names]
+                for rr, nm in zip(r, names):
+                    getattr(R, nm)(ptr(aa), ctypes.c_uint32(w + 8), ptr(bb), ctypes.c_uint32(w + 8), ptr(rr), ctypes.c_uint32(w), ctypes.c_uint32(h))
+                # full_distortion_kernel32_bits_avx2 adds the squared differences with _mm256_add_epi32
+                # (EbPictureOperators_Intrinsic_AVX2.c:1989): no carry from the low into the high half of its 64-bit lanes,
+                # so DIST_CALC_RESIDUAL differs from the C kernel once a lane's low halves sum past 2^32.  Both recorded.
+                if i == 0:
+                    assert np.array_equal(r[0], r[1]), (w, h, i, names)
+                if z == 1:
+                    assert np.array_equal(r[0], r[1]), (w, h, i, names)    # the cbf_zero kernel adds in 64 bits
+                out[i, z] = r[0]; out_avx2[i, z] = r[1]
+            if w == h:          # picture_full_distortion32_bits, luma: clamps the area of a 64x64 block to 32x32, stride = width
+                k = min(w, 32)
+                ca = aligned((k, k), np.int32); ca[:] = a[i][:k, :k]
+                cb = aligned((k, k), np.int32); cb[:] = b[i][:k, :k]
+                for nz in (1, 0):
+                    y = np.zeros(2, np.uint64)
+                    rc = R.ref_picture_full_distortion32(ptr(ca), 0, ptr(cb), 0, c_int(w), c_int(h), c_int(nz), c_int(0), ptr(y))
+                    assert rc == 0
+                    d[f"pdist_{w}_{i}_{nz}"] = y
+        d[f"dist_{w}x{h}_a"] = a; d[f"dist_{w}x{h}_b"] = b; d[f"dist_{w}x{h}_out"] = out; d[f"dist_{w}x{h}_out_avx2"] = out_avx2
+    # ---- inverse transform at the clamp limits (the add runs on 16-bit lanes in the product)
+    for (s, types) in ((3, (0, 9)), (9, (0, 9)), (15, (9,)), (2, (0, 3, 9, 12)), (4, (0,)), (1, (9, 0)), (11, (0,))):
+        w, h = TX_W[s], TX_H[s]
+        kw, kh = min(w, 32), min(h, 32)
+        f = getattr(R, f"av1_inv_txfm2d_add_{w}x{h}_c")
+        for t in types:
+            for bd in (8, 10, 12):
+                top = 1 << (bd + 7)
+                cos = np.stack([np.full(kw * kh, top), np.full(kw * kh, -top),
+                                rng.choice([-top, top], size=kw * kh), rng.integers(-(1 << 21), 1 << 21, size=kw * kh),
+                                np.r_[top * 4, np.zeros(kw * kh - 1, int)]]).astype(np.int32)
+                dst0 = rng.integers(0, 1 << bd, size=(5, h, w)).astype(np.uint16)
+                dst0[0] = (1 << bd) - 1; dst0[1] = 0
+                dst1 = dst0.copy()
+                for i in range(5):
+                    ref_inv(s, t, bd, np.ascontiguousarray(cos[i]), dst1[i])
+                key = f"sat_{s}_{t}_{bd}"
+                d[key + "_coeff"] = cos; d[key + "_dst_in"] = dst0; d[key + "_dst_out"] = dst1
+    np.savez_compressed(os.path.join(HERE, "pins.npz"), **d)
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                    # one family only: python make_golden.py cfl_levels
         globals()["gen_" + sys.argv[1]]()
@@ -348,6 +518,8 @@ if __name__ == "__main__":
     gen_intra()
     gen_cfl_levels()
     gen_ois()
+    gen_me()
+    gen_pins()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -85,7 +85,8 @@ def test_log_scale_rule(pkg):
 
 def test_host_tables_match_oracle():
     """cidana-svt-av1_amd/tables.py (what bench.py and the tools feed the quantiser with) against the oracle's
-    av1_build_quantizer / scan restatements, which tests/test_oracle_vs_ref_tables.py pins to the reference."""
+    av1_build_quantizer / scan restatements, which tests/test_oracle_golden.py (test_scan_tables, test_quantizer_tables:
+    tests/golden/tables.npz = the reference's own arrays) pins to the reference."""
     import numpy as np
     import __graft_entry__ as ge
     import svtlibs

@@ -138,7 +138,7 @@ def test_intra_golden():
             else: O.svt_oracle_intra_pred_hbd(m, ptr(o), S(bw), bw, bh, pa, pl, bd)
         else:
             zone, ang, ua, ul = int(parts[2][1:]), int(parts[3]), int(parts[4][0]), int(parts[4][1])
-            from test_oracle_vs_ref_tables import DR_DERIV
+            from dr_deriv_data import DR_DERIV
             dx = DR_DERIV[ang] if zone in (1, 2) else 1
             dy = DR_DERIV[90 - ang] if zone == 2 else (DR_DERIV[ang] if zone == 3 else 1)
             if bd == 8: O.svt_oracle_dr_prediction(zone, ptr(o), S(bw), bw, bh, pa, pl, ua, ul, dx, dy)
@@ -228,3 +228,123 @@ def test_ois_golden():
             assert np.array_equal(ds[:n], g[f"c{k}_dist"][i, :n]), (k, i)
             blocks += 1
     assert blocks > 400
+
+
+# ---- round 2: K6 (reference's own full-pel search drivers) and the caller-level pins (oracle/ref_me.c, ref_pins.c) ----
+ME_MAX_SAD = 128 * 128 * 255
+
+
+def me_oracle(src, win, stride, sw, sh, xo, yo, flavour, nsq, chain):
+    O = svtlibs.oracle()
+    bs = np.full(209, ME_MAX_SAD, np.uint32); bm = np.zeros(209, np.uint32)
+    O.svt_oracle_me_sb_search_full(ptr(src), 64, ptr(win), stride, sw, sh, xo, yo, flavour, nsq, ptr(bs), ptr(bm))
+    if chain:
+        O.svt_oracle_me_sb_search_full(ptr(src), 64, ctypes.c_void_p(win.ctypes.data + stride + 1), stride, max(1, sw - 1), sh,
+                                       xo + 1, yo + 1, flavour, nsq, ptr(bs), ptr(bm))
+    n = 209 if nsq else 85
+    return bs[:n], bm[:n]
+
+
+def test_me_fullpel_golden_both_flavours_and_nsq():
+    """oracle K6 == the reference's FullPelSearch_LCU / open_loop_me_fullpel_search_sblock for asm_type 0 and 1"""
+    g = np.load(os.path.join(G, "me.npz"))
+    cases = g["cases"]
+    assert int(g["asm_divergent_cases"][0]) > 0      # the AVX2 build really diverges from the C kernels (DESIGN.md)
+    for k, (sw, sh, xo, yo, _) in enumerate(cases):
+        src = np.ascontiguousarray(g[f"c{k}_src"]); win = np.ascontiguousarray(g[f"c{k}_win"])
+        for asm in (0, 1):
+            for nsq in (0, 1):
+                bs, bm = me_oracle(src, win, win.shape[1], int(sw), int(sh), int(xo), int(yo), asm, nsq, k >= len(cases) - 2)
+                assert np.array_equal(bs, g[f"c{k}_sad_a{asm}_n{nsq}"]), (k, asm, nsq)
+                assert np.array_equal(bm, g[f"c{k}_mv_a{asm}_n{nsq}"]), (k, asm, nsq)
+
+
+def test_me_legacy_layout_equals_full_layout():
+    """svt_oracle_me_sb_search (8x8 | 16x16 | 32x32 | 64x64 back to back) == flavour 0 of the pinned function"""
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "me.npz"))
+    for k, (sw, sh, xo, yo, _) in enumerate(g["cases"][:10]):
+        src = np.ascontiguousarray(g[f"c{k}_src"]); win = np.ascontiguousarray(g[f"c{k}_win"])
+        bs = np.full(85, ME_MAX_SAD, np.uint32); bm = np.zeros(85, np.uint32)
+        O.svt_oracle_me_sb_search(ptr(src), 64, ptr(win), win.shape[1], int(sw), int(sh), int(xo), int(yo), ptr(bs), ptr(bm))
+        reorder = lambda a: np.concatenate([a[84:85], a[80:84], a[64:80], a[0:64]])
+        assert np.array_equal(reorder(bs), g[f"c{k}_sad_a0_n0"]) and np.array_equal(reorder(bm), g[f"c{k}_mv_a0_n0"]), k
+
+
+def test_estimate_transform_pack64_energy_golden():
+    """a5: forward transform + 64-point re-pack + three_quad_energy == the reference's av1_estimate_transform"""
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "pins.npz"))
+    n = 0
+    for key in [k[:-3] for k in g.files if k.startswith("est_") and k.endswith("_in")]:
+        _, s, t, bd = key.split("_"); s, t, bd = int(s), int(t), int(bd)
+        w, h = TX_W[s], TX_H[s]
+        for i in range(3):
+            x = np.ascontiguousarray(g[key + "_in"][i]); full = np.zeros(w * h, np.int32)
+            O.svt_oracle_fwd_txfm2d(ptr(x), ptr(full), ctypes.c_uint32(w), t, s, bd)
+            e = O.svt_oracle_fwd_txfm2d_pack64(ptr(full), s)
+            m = min(w, 32) * min(h, 32)
+            assert np.array_equal(full[:m], g[key + "_coeff"][i]), key
+            assert int(e) == int(g[key + "_energy"][i]), key
+            n += 1
+    assert n >= 60
+
+
+def test_inv_txfm_add_u8_entry_golden():
+    """a6: svt_oracle_inv_txfm2d_add_u8 == av1_inv_txfm_add_c == av1_inv_txfm_add_ssse3 == av1_inv_transform_recon8bit"""
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "pins.npz"))
+    n = 0
+    for s in range(19):
+        w = TX_W[s]
+        for t in range(16):
+            if not txfm_allowed(s, t):
+                continue
+            co, d0, d1 = g[f"inv8_{s}_{t}_coeff"], g[f"inv8_{s}_{t}_dst_in"], g[f"inv8_{s}_{t}_dst_out"]
+            for i in range(2):
+                d = np.ascontiguousarray(d0[i])
+                O.svt_oracle_inv_txfm2d_add_u8(ptr(np.ascontiguousarray(co[i])), ptr(d), ctypes.c_int(w), t, s)
+                assert np.array_equal(d, d1[i]), (TX_SIZES[s], TX_TYPES[t], i)
+                n += 1
+    assert n == 2 * 159
+
+
+def test_full_distortion32_golden_c_and_avx2_flavours():
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "pins.npz"))
+    diverged = 0
+    for key in [k[:-2] for k in g.files if k.startswith("dist_") and k.endswith("_a")]:
+        w, h = (int(v) for v in key.split("_")[1].split("x"))
+        a, b, out, out2 = g[key + "_a"], g[key + "_b"], g[key + "_out"], g[key + "_out_avx2"]
+        for i in range(4):
+            aa = np.ascontiguousarray(a[i]); bb = np.ascontiguousarray(b[i])
+            r = np.zeros(2, np.uint64); r2 = np.zeros(2, np.uint64)
+            O.svt_oracle_full_distortion32(ptr(aa), ctypes.c_uint32(w + 8), ptr(bb), ctypes.c_uint32(w + 8), ptr(r), ctypes.c_uint32(w), ctypes.c_uint32(h))
+            O.svt_oracle_full_distortion32_avx2(ptr(aa), ctypes.c_uint32(w + 8), ptr(bb), ctypes.c_uint32(w + 8), ptr(r2), ctypes.c_uint32(w), ctypes.c_uint32(h))
+            assert np.array_equal(r, out[i, 0]), (key, i)
+            assert np.array_equal(r2, out_avx2 := out2[i, 0]), (key, i)
+            assert r[1] == out[i, 1, 0] == out[i, 1, 1]                    # cbf_zero: both outputs = prediction energy
+            diverged += int(not np.array_equal(out[i, 0], out2[i, 0]))
+            if w == h:                                                     # picture_full_distortion32_bits (luma)
+                k = min(w, 32)
+                ca = np.ascontiguousarray(a[i][:k, :k]); cb = np.ascontiguousarray(b[i][:k, :k])
+                y = np.zeros(2, np.uint64)
+                O.svt_oracle_full_distortion32(ptr(ca), ctypes.c_uint32(k), ptr(cb), ctypes.c_uint32(k), ptr(y), ctypes.c_uint32(k), ctypes.c_uint32(k))
+                assert np.array_equal(y, g[f"pdist_{w}_{i}_1"]), (key, i)
+                assert y[1] == g[f"pdist_{w}_{i}_0"][0] == g[f"pdist_{w}_{i}_0"][1]
+    assert diverged > 0      # the reference's AVX2 kernel loses carries (DESIGN.md); both flavours are pinned
+
+
+def test_inv_txfm2d_add_at_clamp_limits_golden():
+    """bd 8 / 10 / 12 coefficients at +-2^(bd+7) and beyond: av1_inv_txfm2d_add_*_c (saturation of the final add)"""
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "pins.npz"))
+    n = 0
+    for key in [k[:-6] for k in g.files if k.startswith("sat_") and k.endswith("_coeff")]:
+        _, s, t, bd = key.split("_"); s, t, bd = int(s), int(t), int(bd)
+        for i in range(5):
+            d = np.ascontiguousarray(g[key + "_dst_in"][i])
+            O.svt_oracle_inv_txfm2d_add(ptr(np.ascontiguousarray(g[key + "_coeff"][i])), ptr(d), ctypes.c_int(TX_W[s]), t, s, bd)
+            assert np.array_equal(d, g[key + "_dst_out"][i]), (key, i)
+            n += 1
+    assert n == 195
