@@ -102,6 +102,9 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_ois_search_batch.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_int,
                                            c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]
     L.svt_hip_txb_init_levels_batch.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_uint32, c_uint32, c_size_t, c_void_p]
+    L.svt_hip_me_fullpel_search_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_void_p, c_uint32, c_size_t, c_void_p,
+                                                  c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_uint32,
+                                                  c_size_t, c_void_p]
     return L
 
 
@@ -487,6 +490,34 @@ class SvtHipDsp:
                                                          search_h, self._p(origins) if origins is not None else None,
                                                          x_origin, y_origin, self._p(best_sad), self._p(best_mv), n,
                                                          self._stream()), "svt_hip_me_sb_search_batch")
+        return best_sad, best_mv
+
+    ME_PUS_ALL = 209
+    FLAVOUR_C, FLAVOUR_AVX2 = 0, 1
+
+    def me_fullpel_search(self, src, ref, search_w, search_h, x_origin=0, y_origin=0, origins=None, flavour=0, nsq=False,
+                          best_sad=None, best_mv=None, src_stride=64, src_offsets=None, ref_stride=None, ref_offsets=None,
+                          n=None):
+        """K6 in the reference's p_sb_best_sad / p_sb_best_mv layout (svt_hip_me_fullpel_search_batch).  Dense form: src uint8
+        [n, 64, 64], ref uint8 [n, rows, RW] private windows.  Plane form: src / ref are planes, *_offsets int32 byte offsets.
+        -> (best_sad, best_mv) int32 [n, 85 or 209] (uint32 values), updated in place when given."""
+        t = self.torch
+        if src_offsets is None:
+            n = src.shape[0]
+            _, rh, rw = ref.shape
+            ref_stride, spitch, rpitch = rw, 64 * 64, rw * rh
+        else:
+            n = n if n is not None else src_offsets.numel()
+            spitch = rpitch = 0
+        npu = self.ME_PUS_ALL if nsq else 85
+        if best_sad is None:
+            best_sad = t.full((n, npu), self.MAX_SAD_VALUE, dtype=t.int32, device=src.device)
+            best_mv = t.zeros((n, npu), dtype=t.int32, device=src.device)
+        self._check(self.lib.svt_hip_me_fullpel_search_batch(
+            self._p(src), src_stride, spitch, self._p(src_offsets) if src_offsets is not None else None, self._p(ref), ref_stride,
+            rpitch, self._p(ref_offsets) if ref_offsets is not None else None, search_w, search_h,
+            self._p(origins) if origins is not None else None, x_origin, y_origin, flavour, 1 if nsq else 0, self._p(best_sad),
+            self._p(best_mv), best_sad.shape[1], n, self._stream()), "svt_hip_me_fullpel_search_batch")
         return best_sad, best_mv
 
     # -- general fused chain on planes ------------------------------------------------------

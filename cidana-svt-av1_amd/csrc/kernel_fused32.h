@@ -369,15 +369,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(5)))
         // sigma ^ ((sigma >> 4) & (SPL-1)) = (c/4) ^ ((r>>1) & (SPL-1)) to keep its b128 reads conflict-free.
 #pragma unroll
         for (int r = 0; r < 32; r++)
-        {
-            // shift[1] = -4.  The residual is added to the sample on 16-bit lanes below; the reference adds in int32
-            // (highbd_clip_pixel_add, EbTransforms.c:8180-8265).  Every column kernel ends in a clamp to col_bits
-            // (<= 18 bits -> <= 14 bits here) except iidentity32 (x4, no clamp): at bd 12 its 18-bit input gives up to
-            // 2^15, which would wrap.  Anything beyond +-maxpix clips anyway, so saturate there (bd 12 only).
-            int v = (x[r] + 8) >> 4;
-            if (BD > 10) v = svtgen::svt_clamp(v, -((1 << BD) - 1), (1 << BD) - 1);
-            *reinterpret_cast<int*>(tile + (c_w ^ (((r >> 1) & (SPL - 1)) << 4)) + r * 128) = v;
-        }
+            // shift[1] = -4.  The residual is added to the sample on 16-bit lanes below (the reference adds in int32): exact for
+            // BD <= 10 (column outputs <= 16 bits, 12-14 after the shift); bd 12 takes the general kernel
+            *reinterpret_cast<int*>(tile + (c_w ^ (((r >> 1) & (SPL - 1)) << 4)) + r * 128) = (x[r] + 8) >> 4;
         wave_lds_fence();
         if (valid) {
 #pragma unroll

@@ -260,7 +260,11 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
     const int16_t* __restrict__ origins /* [n][2] x,y or NULL */, int x_origin, int y_origin,
     uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t wpitch,
-    const uint32_t* __restrict__ src_offs, const uint32_t* __restrict__ ref_offs, uint32_t nblocks) {
+    const uint32_t* __restrict__ src_offs, const uint32_t* __restrict__ ref_offs, uint32_t nblocks,
+    // w8q > 0: SVT_HIP_FLAVOUR_AVX2 - inside the full groups of eight search points of a row (xs < w8q = search_w & ~7) the four
+    // 32x32 PUs rank and report point p of the group as p ^ 4 (see me_fullpel_exact_kernel).  ref_layout: results in the
+    // reference's EbMeTierZeroPu order with pu_pitch words per SB instead of 8x8 | 16x16 | 32x32 | 64x64 back to back.
+    int w8q = 0, int ref_layout = 0, uint32_t pu_pitch = ME_PUS) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_src = reinterpret_cast<uint32_t*>(smem);            // [32 even rows][16 dwords]
     uint8_t* s_ref = smem + 32 * 64;                                // [(64+sh-1)][wpitch], wpitch % 16 == 0
@@ -327,6 +331,7 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const unsigned idb = (unsigned)(ys * search_w + xs0);         // point index of the lane's first point (< 4096)
         const unsigned nvalid = MASKED ? (unsigned)min(16, search_w - xs0) : 16u;
         const unsigned dead = act ? 0u : 0xffffffffu;
+        const unsigned q4[2] = {xs0 < w8q ? 4u : 0u, xs0 + 8 < w8q ? 4u : 0u};      // per group of eight of the lane's 16 points
         const uint8_t* rbase = s_ref + (size_t)ys * wpitch + xs0;
         unsigned s64[16];
 #pragma unroll
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         const unsigned a = (unsigned)((PA[c32][g] >> (16 * jj)) & 0xffffu), b = (unsigned)((PB[c32][g] >> (16 * jj)) & 0xffffu);
                         const unsigned s = (a + b) << 1;
                         s64[4 * g + jj] += s;
-                        const unsigned key = (s << 12) | (idb + 4 * g + jj);
+                        const unsigned key = (s << 12) | (idb + ((unsigned)(4 * g + jj) ^ q4[g >> 1]));
                         best = min(best, (MASKED && (unsigned)(4 * g + jj) >= nvalid) ? 0xffffffffu : key);
                     }
                 const unsigned k = wave_min_u32_to_lane63(best | dead);
@@ -434,12 +439,139 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const unsigned cand = key & 0xfffu;
         const int ys = (int)cand / search_w, xs = (int)cand - ys * search_w;
         const int ox = origins ? origins[2 * blk] : x_origin, oy = origins ? origins[2 * blk + 1] : y_origin;
-        uint32_t* bs = best_sad + (size_t)blk * ME_PUS;
-        uint32_t* bm = best_mv + (size_t)blk * ME_PUS;
-        if (sad < bs[tid]) {
-            bs[tid] = sad;
-            bm[tid] = (((uint32_t)(uint16_t)(ys + oy)) << 18) | (uint32_t)(uint16_t)((xs + ox) << 2);
+        // legacy order 8x8 [0..63] | 16x16 [64..79] | 32x32 [80..83] | 64x64 [84] -> EbMeTierZeroPu order
+        const int o = !ref_layout ? tid : (tid < 64 ? 21 + tid : (tid < 80 ? 5 + (tid - 64) : (tid < 84 ? 1 + (tid - 80) : 0)));
+        uint32_t* bs = best_sad + (size_t)blk * pu_pitch;
+        uint32_t* bm = best_mv + (size_t)blk * pu_pitch;
+        if (sad < bs[o]) {
+            bs[o] = sad;
+            bm[o] = (((uint32_t)(uint16_t)(ys + oy)) << 18) | (uint32_t)(uint16_t)((xs + ox) << 2);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6 in the reference's own result layout: 209 PUs in EbMeTierZeroPu order (EbMotionEstimationContext.h:47-270),
+// i.e. the encoder's p_sb_best_sad / p_sb_best_mv rows: 64x64 [0], 32x32 [1..4], 16x16 [5..20], 8x8 [21..84], and the
+// non-square shapes of open_loop_me_fullpel_search_sblock (EbMotionEstimation.c:3251): 64x32 [85..86], 32x16 [87..94],
+// 16x8 [95..126], 32x64 [127..128], 16x32 [129..136], 8x16 [137..168], 32x8 [169..184], 8x32 [185..200], 64x16 [201..204],
+// 16x64 [205..208].  me_pu_rect gives a PU's rectangle in units of 8 pixels, derived from how ext_eigth_sad_calculation_nsq_c
+// (:1455-2490) / ExtSadCalculation (:655-1440) build the sums out of the z-ordered 8x8 / 16x16 / 32x32 SADs.
+// ---------------------------------------------------------------------------
+constexpr int ME_PUS_ALL = 209;
+
+__host__ __device__ inline void me_pu_rect(int pu, int& x, int& y, int& w, int& h) {
+    // z-order index of a 16x16 -> its position in 16-pixel units
+    auto z16 = [](int z, int& bx16, int& by16) { bx16 = ((z >> 2) & 1) * 2 + (z & 1); by16 = (z >> 3) * 2 + ((z >> 1) & 1); };
+    int bx, by;
+    if (pu == 0) { x = 0; y = 0; w = 8; h = 8; }
+    else if (pu < 5) { const int q = pu - 1; x = (q & 1) * 4; y = (q >> 1) * 4; w = 4; h = 4; }
+    else if (pu < 21) { z16(pu - 5, bx, by); x = bx * 2; y = by * 2; w = 2; h = 2; }
+    else if (pu < 85) { const int i = pu - 21; z16(i >> 2, bx, by); x = bx * 2 + (i & 1); y = by * 2 + ((i >> 1) & 1); w = 1; h = 1; }
+    else if (pu < 87) { x = 0; y = (pu - 85) * 4; w = 8; h = 4; }                                         // 64x32
+    else if (pu < 95) { const int i = pu - 87, q = i >> 1; x = (q & 1) * 4; y = (q >> 1) * 4 + (i & 1) * 2; w = 4; h = 2; }   // 32x16
+    else if (pu < 127) { const int i = pu - 95; z16(i >> 1, bx, by); x = bx * 2; y = by * 2 + (i & 1); w = 2; h = 1; }          // 16x8
+    else if (pu < 129) { x = (pu - 127) * 4; y = 0; w = 4; h = 8; }                                       // 32x64
+    else if (pu < 137) { const int i = pu - 129, q = i >> 1; x = (q & 1) * 4 + (i & 1) * 2; y = (q >> 1) * 4; w = 2; h = 4; }  // 16x32
+    else if (pu < 169) { const int i = pu - 137; z16(i >> 1, bx, by); x = bx * 2 + (i & 1); y = by * 2; w = 1; h = 2; }         // 8x16
+    else if (pu < 185) { const int i = pu - 169, m = i >> 1, q = m >> 1; x = (q & 1) * 4; y = (q >> 1) * 4 + (m & 1) * 2 + (i & 1); w = 4; h = 1; }  // 32x8
+    else if (pu < 201) { const int i = pu - 185, q = i >> 2; x = (q & 1) * 4 + (i & 3); y = (q >> 1) * 4; w = 1; h = 4; }       // 8x32
+    else if (pu < 205) { x = 0; y = (pu - 201) * 2; w = 8; h = 2; }                                       // 64x16
+    else { x = (pu - 205) * 2; y = 0; w = 2; h = 8; }                                                     // 16x64
+}
+
+// me_fullpel_exact_kernel — the reference's search, search point by search point, in its own order: every width, both
+// result flavours (0 = its C / SSE4.1 kernels, 1 = what its AVX2 build compiled by GCC / clang computes), square PUs only
+// or all 209.  This is the general path behind svt_hip_me_fullpel_search_batch; the fast kernels take the shapes they
+// cover (me_sb_search16_kernel: square PUs, any width; me_nsq16_kernel: all PUs, widths that are a multiple of 8).
+// One workgroup per SB; a step = the (up to) eight search points of one group of FullPelSearch_LCU's row loop (:3210-3243):
+//   phase 1  256 lanes compute the 8 x 64 8x8 SADs of the step (every other row, doubled: Compute8x4SAD_Kernel with
+//            2x strides) from the even source rows in LDS and the reference window in global memory / L2;
+//   phase 2  lane p < npus owns PU p: its SAD per point is the sum over its rectangle of 8x8 SADs, its running best is
+//            updated in the reference's order with strict '<'.
+// Restated quirks (oracle/pixel.c holds the same, pinned to the reference by tests/golden/me.npz):
+//   * flavour 1, square-PU search, full group of 8: the four 32x32 PUs rank and report the group's point p as p ^ 4
+//     (EbComputeSAD_Intrinsic_AVX2.c:3989-4001, the `#ifdef __GNUC__` lane swap);
+//   * NSQ search, points outside a full group (single-search-point form): 32x16_5 is replaced when the 64x32_1 SAD (not its
+//     own) beats its best (ExtSadCalculation's stale `sad`, EbMotionEstimation.c:732-736) - both flavours;
+//   * the same points, flavour 1: the lower 8x8 pair of every 16x16 reads its first reference row 8 SOURCE strides below
+//     the 16x16's reference origin (ext_sad_calculation_8x8_16x16_avx2_intrin, EbComputeSAD_Intrinsic_AVX2.c:50-52).
+__global__ __launch_bounds__(ME_THREADS) void me_fullpel_exact_kernel(
+    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch, const uint32_t* __restrict__ src_offs,
+    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, const uint32_t* __restrict__ ref_offs,
+    int search_w, int search_h, const int16_t* __restrict__ origins, int x_origin, int y_origin, int flavour, int nsq,
+    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t pu_pitch, uint32_t nblocks) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_src[32 * 16];      // even source rows
+    __shared__ uint32_t s_s8[8][64];                                       // [point of the step][8x8 block, raster]
+    const uint32_t blk = blockIdx.x;
+    if (blk >= nblocks) return;
+    const int tid = threadIdx.x;
+    const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
+    const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
+    if (tid < 128) {
+        const int r = tid >> 2, c = tid & 3;
+        uint4 v;
+        __builtin_memcpy(&v, gs + (size_t)(2 * r) * src_stride + c * 16, 16);
+        reinterpret_cast<uint4*>(s_src)[tid] = v;
+    }
+    const int npus = nsq ? ME_PUS_ALL : ME_PUS;
+    const int ox = origins ? origins[2 * blk] : x_origin, oy = origins ? origins[2 * blk + 1] : y_origin;
+    int px = 0, py = 0, pw = 0, ph = 0;
+    uint32_t bsad = 0, bmv = 0;
+    if (tid < npus) {
+        me_pu_rect(tid, px, py, pw, ph);
+        bsad = best_sad[(size_t)blk * pu_pitch + tid];
+        bmv = best_mv[(size_t)blk * pu_pitch + tid];
+    }
+    const int w8 = search_w & ~7;
+    __syncthreads();
+    for (int ys = 0; ys < search_h; ys++) {
+        const uint32_t mvy = ((uint32_t)(uint16_t)(ys + oy)) << 18;
+        for (int xg = 0; xg < search_w; xg += 8) {
+            const int np = min(8, search_w - xg);
+            const bool single = xg >= w8;                 // GetSearchPointResults / open_loop_me_get_search_point_results_block
+            const bool row_bug = flavour == 1 && nsq && single;
+            for (int item = tid; item < np * 64; item += ME_THREADS) {
+                const int p = item >> 6, b8 = item & 63, by = b8 >> 3, bx = b8 & 7;
+                const uint8_t* r0 = gr + (size_t)ys * ref_stride + (xg + p);
+                unsigned sad = 0;
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const uint8_t* rrow = r0 + (size_t)(by * 8 + 2 * rr) * ref_stride;
+                    if (row_bug && (by & 1) && rr == 0) rrow = r0 + (size_t)((by >> 1) * 16) * ref_stride + (size_t)8 * src_stride;
+                    uint2 rv;
+                    __builtin_memcpy(&rv, rrow + bx * 8, 8);
+                    const uint32_t* sp = s_src + (by * 4 + rr) * 16 + bx * 2;
+                    sad = __builtin_amdgcn_sad_u8(sp[0], rv.x, sad);
+                    sad = __builtin_amdgcn_sad_u8(sp[1], rv.y, sad);
+                }
+                s_s8[p][b8] = sad << 1;
+            }
+            __syncthreads();
+            if (tid < npus) {
+                const bool swap32 = flavour == 1 && !nsq && !single && tid >= 1 && tid <= 4;
+                for (int pa = 0; pa < np; pa++) {
+                    const int p = swap32 ? (pa ^ 4) : pa;        // the point whose SAD is attributed to position pa
+                    unsigned sum = 0;
+                    for (int yy = 0; yy < ph; yy++)
+                        for (int xx = 0; xx < pw; xx++) sum += s_s8[p][(py + yy) * 8 + px + xx];
+                    unsigned test = sum;
+                    if (nsq && single && tid == 87 + 5) {       // the stale `sad` of the 64x32_1 sum
+                        test = 0;
+                        for (int i = 32; i < 64; i++) test += s_s8[p][i];
+                    }
+                    if (test < bsad) {
+                        bsad = sum;
+                        bmv = mvy | (uint32_t)(uint16_t)((xg + pa + ox) << 2);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < npus) {
+        best_sad[(size_t)blk * pu_pitch + tid] = bsad;
+        best_mv[(size_t)blk * pu_pitch + tid] = bmv;
     }
 }
 

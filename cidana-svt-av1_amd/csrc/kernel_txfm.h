@@ -64,23 +64,24 @@ __device__ __forceinline__ void fwd1d(int kind, int (&x)[N]) {
         svt_fdct64<BIT>(x);
     }
 }
-template <int N>
+// WIDE: half_btf sums in 64 bits (bd 12, see csrc/gen/txfm1d_gen.h)
+template <int N, bool WIDE = false>
 __device__ __forceinline__ void inv1d(int kind, int (&x)[N], int lo, int hi) {
     using namespace svtgen;
     lo = svt_vgpr(lo); hi = svt_vgpr(hi);     // clamp bounds live in two VGPRs (see svt_clamp)
     constexpr int BIT = 12;   // inv_cos_bit_* are all INV_COS_BIT = 12 (EbTransforms.h:252-267)
     if constexpr (N == 4) {
-        if (kind == K1D_DCT) svt_idct4<BIT>(x, lo, hi); else if (kind == K1D_IDTX) svt_iidentity4<BIT>(x, lo, hi); else svt_iadst4<BIT>(x, lo, hi);
+        if (kind == K1D_DCT) svt_idct4<BIT, WIDE>(x, lo, hi); else if (kind == K1D_IDTX) svt_iidentity4<BIT, WIDE>(x, lo, hi); else svt_iadst4<BIT, WIDE>(x, lo, hi);
     } else if constexpr (N == 8) {
-        if (kind == K1D_DCT) svt_idct8<BIT>(x, lo, hi); else if (kind == K1D_IDTX) svt_iidentity8<BIT>(x, lo, hi); else svt_iadst8<BIT>(x, lo, hi);
+        if (kind == K1D_DCT) svt_idct8<BIT, WIDE>(x, lo, hi); else if (kind == K1D_IDTX) svt_iidentity8<BIT, WIDE>(x, lo, hi); else svt_iadst8<BIT, WIDE>(x, lo, hi);
     } else if constexpr (N == 16) {
-        if (kind == K1D_DCT) svt_idct16<BIT>(x, lo, hi); else if (kind == K1D_IDTX) svt_iidentity16<BIT>(x, lo, hi); else svt_iadst16<BIT>(x, lo, hi);
+        if (kind == K1D_DCT) svt_idct16<BIT, WIDE>(x, lo, hi); else if (kind == K1D_IDTX) svt_iidentity16<BIT, WIDE>(x, lo, hi); else svt_iadst16<BIT, WIDE>(x, lo, hi);
     } else if constexpr (N == 32) {
-        if (kind == K1D_IDTX) svt_iidentity32<BIT>(x, lo, hi); else svt_idct32<BIT>(x, lo, hi);
+        if (kind == K1D_IDTX) svt_iidentity32<BIT, WIDE>(x, lo, hi); else svt_idct32<BIT, WIDE>(x, lo, hi);
     } else {
         // elements 32..63 of every 64-point inverse input are zero in AV1 (only 32x32 coefficients are
         // coded, EbTransforms.c:8226-8240; the callers zero-fill them): zero-propagated network
-        svt_idct64_low32<BIT>(x, lo, hi);
+        svt_idct64_low32<BIT, WIDE>(x, lo, hi);
     }
 }
 
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(TX_WAVES * 64) void fwd_quant_generic_kernel(
 // (dense), dst = PixT samples; block b at dst + (dst_offsets ? dst_offsets[b]
 // : b * dst_block_pitch), row stride dst_stride (elements).
 // ---------------------------------------------------------------------------
-template <int W, int H, typename PixT>
+template <int W, int H, typename PixT, bool WIDE = false>
 __global__ __launch_bounds__(TX_WAVES * 64) void inv_txfm2d_add_kernel(
     const int32_t* __restrict__ in, PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch,
     const uint32_t* __restrict__ dst_offsets, int tx_type, int bd, uint32_t nblocks) {
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(TX_WAVES * 64) void inv_txfm2d_add_kernel(
                 if (G::RECT2) v = mul_q12(v, 2896);          // x 1/sqrt(2)
                 x[c] = svtgen::svt_clamp(v, -(1 << (in_bits - 1)), (1 << (in_bits - 1)) - 1);
             }
-            inv1d<W>(hk, x, -(1 << (row_bits - 1)), (1 << (row_bits - 1)) - 1);
+            inv1d<W, WIDE>(hk, x, -(1 << (row_bits - 1)), (1 << (row_bits - 1)) - 1);
 #pragma unroll
             for (int c = 0; c < W; c++) tile[l * G::PITCH + c] = round_shift_c<-S0>(x[c]);
         } else {
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(TX_WAVES * 64) void inv_txfm2d_add_kernel(
 #pragma unroll
         for (int r = 0; r < H; r++)
             y[r] = svtgen::svt_clamp(tile[r * G::PITCH + csrc], -(1 << (colin_bits - 1)), (1 << (colin_bits - 1)) - 1);
-        inv1d<H>(vk, y, -(1 << (col_bits - 1)), (1 << (col_bits - 1)) - 1);
+        inv1d<H, WIDE>(vk, y, -(1 << (col_bits - 1)), (1 << (col_bits - 1)) - 1);
         if (valid) {
             const size_t base = dst_offsets ? (size_t)dst_offsets[blk] : (size_t)blk * dst_block_pitch;
             PixT* d = dst + base + l;

@@ -338,15 +338,10 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
     if (l < W) {
         short* res = reinterpret_cast<short*>(wl) + sub * (W * H);
 #pragma unroll
-        for (int r = 0; r < H; r++) {
-            // the add to the sample runs on 16-bit lanes; the reference adds in int32 (highbd_clip_pixel_add,
-            // EbTransforms.c:8180-8265).  Column outputs are clamped to col_bits (<= 14 bits after the shift) by every
-            // kernel except the identities, whose x4 / x2.83 on an 18-bit input (bd 12) reaches 2^15: saturate at
-            // +-maxpix there (anything beyond clips anyway).  Wave-uniform branch, not taken for bd <= 10.
-            int v = round_shift_c<4>(y[ud ? H - 1 - r : r]);
-            if (bd > 10) v = svtgen::svt_clamp(v, -((1 << bd) - 1), (1 << bd) - 1);
-            res[r * W + l] = (short)v;
-        }
+        // the add to the sample below runs on 16-bit lanes (the reference adds in int32, highbd_clip_pixel_add): exact for
+        // bd <= 10, where every column kernel's output is at most 16 bits (12 after this shift, identities 14); bd 12 takes
+        // the general kernel (svt_hip_inv_txfm2d_add_batch), so no wrap can occur here
+        for (int r = 0; r < H; r++) res[r * W + l] = (short)round_shift_c<4>(y[ud ? H - 1 - r : r]);
     }
     wave_lds_fence();
     // ---- destination on a plane: chunks of CS bytes that never cross a block row ---------------------

@@ -43,6 +43,7 @@ int g_tune_no_q16 = 0;
 int g_tune_q2_su4 = 0;
 int g_tune_ois_no_fold = 0;
 int g_tune_no_me16 = 0;
+int g_tune_me_exact = 0;
 int g_tune_no_f32p = 0;
 int g_tune_no_inv_planes = 0;
 int g_tune_no_enc_staged = 0;
@@ -64,9 +65,18 @@ int set_err(int code, const char* fmt, ...) {
                            __FILE__, __LINE__);                                                  \
     } while (0)
 
+// The HIP "current device" is a per-THREAD setting and the encoder calls from many pthreads (Threading):
+// every entry point passes through here, so every thread is bound to the library's device once.
+thread_local int t_device_bound = -1;
 int require_init() {
-    if (g_inited.load(std::memory_order_acquire)) return SVT_HIP_OK;
-    return svt_hip_init(0);
+    if (!g_inited.load(std::memory_order_acquire)) {
+        if (int rc = svt_hip_init(0)) return rc;
+    }
+    if (t_device_bound != g_device) {
+        HIP_TRY(hipSetDevice(g_device));
+        t_device_bound = g_device;
+    }
+    return SVT_HIP_OK;
 }
 int launch_status(const char* what) {
     hipError_t e = hipGetLastError();
@@ -196,8 +206,7 @@ int launch_inv_staged(const int32_t* in, void* dst, int is16, size_t n, int tx_t
     // 64-point sizes at bd <= 10: 16-bit transpose tile (the column input is clamped to 16 bits there anyway), which lifts
     // their LDS-limited 2 waves per SIMD to 4; smaller sizes are not LDS-limited and sub-dword LDS writes are slower
     constexpr bool T16 = W >= 64 || H >= 64;
-    if (is16 && bd > 10) hipLaunchKernelGGL((inv_staged_kernel<W, H, uint16_t, false>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint16_t*)dst, tx_type, bd, (uint32_t)n, offs, stride);
-    else if (is16) hipLaunchKernelGGL((inv_staged_kernel<W, H, uint16_t, T16>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint16_t*)dst, tx_type, bd, (uint32_t)n, offs, stride);
+    if (is16) hipLaunchKernelGGL((inv_staged_kernel<W, H, uint16_t, T16>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint16_t*)dst, tx_type, bd, (uint32_t)n, offs, stride);
     else hipLaunchKernelGGL((inv_staged_kernel<W, H, uint8_t, T16>), dim3(grid), dim3(SG::WAVES * 64), 0, s, in, (uint8_t*)dst, tx_type, bd, (uint32_t)n, offs, stride);
     return launch_status("inv_staged");
 }
@@ -207,7 +216,10 @@ int launch_inv(const int32_t* in, void* dst, int is16, int32_t stride, size_t pi
     constexpr int BPW = TxGeom<W, H>::BPW;
     const uint32_t per_wg = TX_WAVES * BPW;
     const uint32_t grid = (uint32_t)((n + per_wg - 1) / per_wg);
-    if (is16)
+    if (is16 && bd > 10)      // bd 12: half_btf sums need 64 bits (txfm1d_gen.h, WIDE)
+        hipLaunchKernelGGL((inv_txfm2d_add_kernel<W, H, uint16_t, true>), dim3(grid), dim3(TX_WAVES * 64), 0, s, in,
+                           (uint16_t*)dst, stride, pitch, offs, tx_type, bd, (uint32_t)n);
+    else if (is16)
         hipLaunchKernelGGL((inv_txfm2d_add_kernel<W, H, uint16_t>), dim3(grid), dim3(TX_WAVES * 64), 0, s, in,
                            (uint16_t*)dst, stride, pitch, offs, tx_type, bd, (uint32_t)n);
     else
@@ -281,7 +293,11 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // ===========================================================================
 extern "C" int svt_hip_init(int device) {
     std::lock_guard<std::mutex> lk(g_init_mu);
-    if (g_inited.load(std::memory_order_acquire)) return SVT_HIP_OK;
+    if (g_inited.load(std::memory_order_acquire)) {
+        if (device != g_device)
+            return set_err(SVT_HIP_ERR_INVALID, "already initialised on device %d (asked for %d): one device per process", g_device, device);
+        return SVT_HIP_OK;
+    }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -317,6 +333,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "q2_su4")) { g_tune_q2_su4 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "ois_no_fold")) { g_tune_ois_no_fold = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_me16")) { g_tune_no_me16 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "me_exact")) { g_tune_me_exact = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_f32p")) { g_tune_no_f32p = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_inv_planes")) { g_tune_no_inv_planes = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_enc_staged")) { g_tune_no_enc_staged = value; return SVT_HIP_OK; }
@@ -409,6 +426,13 @@ extern "C" int svt_hip_inv_txfm2d_add_batch(const int32_t* d_coeff, void* d_dst,
     if (!dst_is_16bit && bd != 8) return set_err(SVT_HIP_ERR_INVALID, "8-bit destination needs bd = 8");
     if (nblocks == 0) return SVT_HIP_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (bd > 10) {
+        // bd 12 (not an encoder configuration, only the C inverse kernels define it): the general kernel with 64-bit
+        // half_btf sums; the tuned kernels' 32-bit multiply-accumulate chains are exact for bd <= 10 only
+#define CALL(W, H) launch_inv<W, H>(d_coeff, d_dst, dst_is_16bit, dst_stride, dst_block_pitch, d_dst_offsets, nblocks, tx_type, bd, s)
+        TX_SWITCH(tx_size, CALL)
+#undef CALL
+    }
     if (tx_size == SVT_TX_32X32 && ((uintptr_t)d_coeff & 15) == 0 && (tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX)) {
         if (!dst_is_16bit && (g_tune_inv32_waves != 4 || g_tune_inv32_var != 0)) {     // tuning probes (tools/tune_inv32.py)
 #define INVV(WV, VR) if (g_tune_inv32_waves == WV && g_tune_inv32_var == VR) { \
@@ -422,7 +446,7 @@ extern "C" int svt_hip_inv_txfm2d_add_batch(const int32_t* d_coeff, void* d_dst,
         const uint32_t grid = (uint32_t)((nblocks + 2 * F32_WAVES - 1) / (2 * F32_WAVES));
 #define INV32(T, B) hipLaunchKernelGGL((inv32_kernel<T, B>), dim3(grid), dim3(F32_WAVES * 64), 0, s, d_coeff, (T*)d_dst, dst_stride, \
                                       dst_block_pitch, d_dst_offsets, tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks)
-        if (dst_is_16bit) { if (bd == 8) INV32(uint16_t, 8); else if (bd == 10) INV32(uint16_t, 10); else INV32(uint16_t, 12); }
+        if (dst_is_16bit) { if (bd == 8) INV32(uint16_t, 8); else INV32(uint16_t, 10); }
         else INV32(uint8_t, 8);
 #undef INV32
         return launch_status("inv32");
@@ -929,6 +953,47 @@ extern "C" int svt_hip_me_sb_search_planes_batch(const uint8_t* d_src_plane, uin
     if (nblocks && (!d_src_offsets || !d_ref_offsets)) { if (int rc = require_init()) return rc; return set_err(SVT_HIP_ERR_INVALID, "NULL offset table"); }
     return me_sb_search_impl(d_src_plane, src_stride, 0, d_src_offsets, d_ref_plane, ref_stride, 0, d_ref_offsets, search_w,
                              search_h, d_origins, x_origin, y_origin, d_best_sad, d_best_mv, nblocks, stream);
+}
+
+// K6 in the reference's result layout, both result flavours, square or all 209 PUs (include/svt_hip_dsp.h)
+extern "C" int svt_hip_me_fullpel_search_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                               const uint32_t* d_src_offsets, const uint8_t* d_ref, uint32_t ref_stride,
+                                               size_t ref_block_pitch, const uint32_t* d_ref_offsets, int search_w,
+                                               int search_h, const int16_t* d_origins, int x_origin, int y_origin,
+                                               int flavour, int nsq, uint32_t* d_best_sad, uint32_t* d_best_mv,
+                                               uint32_t pu_pitch, size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_src || !d_ref || !d_best_sad || !d_best_mv) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (flavour != SVT_HIP_FLAVOUR_C && flavour != SVT_HIP_FLAVOUR_AVX2) return set_err(SVT_HIP_ERR_INVALID, "flavour %d", flavour);
+    const uint32_t npus = nsq ? SVT_HIP_ME_PUS_ALL : SVT_HIP_ME_PUS;
+    if (pu_pitch < npus) return set_err(SVT_HIP_ERR_INVALID, "pu_pitch %u < %u PUs", pu_pitch, npus);
+    if (search_w <= 0 || search_h <= 0 || search_w * search_h > 4096)
+        return set_err(SVT_HIP_ERR_INVALID, "search area %dx%d (1..4096 points)", search_w, search_h);
+    if (!nsq && !g_tune_me_exact) {
+        // square PUs: the 16-points-per-lane kernel, any width; the AVX2 flavour only re-labels the 32x32 keys
+        const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
+        const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+        const size_t lds = 32 * 64 + (size_t)wpitch * win_h;
+        if (lds <= 60 * 1024) {
+            const int w8q = flavour == SVT_HIP_FLAVOUR_AVX2 ? (search_w & ~7) : 0;
+            if ((search_w & 15) == 0)
+                hipLaunchKernelGGL(me_sb_search16_kernel<false>, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
+                                   src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
+                                   x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offsets, d_ref_offsets, (uint32_t)nblocks,
+                                   w8q, 1, pu_pitch);
+            else
+                hipLaunchKernelGGL(me_sb_search16_kernel<true>, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
+                                   src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
+                                   x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offsets, d_ref_offsets, (uint32_t)nblocks,
+                                   w8q, 1, pu_pitch);
+            return launch_status("me_sb_search16 (reference layout)");
+        }
+    }
+    hipLaunchKernelGGL(me_fullpel_exact_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), 0, (hipStream_t)stream, d_src, src_stride,
+                       src_block_pitch, d_src_offsets, d_ref, ref_stride, ref_block_pitch, d_ref_offsets, search_w, search_h,
+                       d_origins, x_origin, y_origin, flavour, nsq ? 1 : 0, d_best_sad, d_best_mv, pu_pitch, (uint32_t)nblocks);
+    return launch_status("me_fullpel_exact");
 }
 
 extern "C" int svt_hip_full_distortion32_batch(const int32_t* d_coeff, uint32_t coeff_stride, size_t coeff_block_pitch,

@@ -82,7 +82,7 @@ const char *svt_hip_device_name(void);
  *   "f32_min_waves" (1|4: register cap of the fused 32x32 kernel), "f32_wg_per_cu" (persistent grid = CUs x
  *   this; 0 = one-shot grid), "f32_nt" (non-temporal stores), "f32_qmode1" (general 24-bit quantiser form),
  *   "no_staged", "no_f32p", "no_enc_staged", "no_inv_planes" (1 = take the general un-staged / two-kernel path),
- *   "no_qsad", "no_q2", "no_q16", "no_me16" (1 = take the first-generation search kernels), "q2_su4" (1 = two-step window staging), "ois_no_fold" (1 = directional predictions through scratch),
+ *   "no_qsad", "no_q2", "no_q16", "no_me16" (1 = take the first-generation search kernels), "me_exact" (1 = svt_hip_me_fullpel_search_batch always takes its general search-point-by-search-point kernel), "q2_su4" (1 = two-step window staging), "ois_no_fold" (1 = directional predictions through scratch),
  *   "inv32_waves", "inv32_var" (probe variants of the inverse 32x32 kernel, tools/tune_inv32.py).
  * Unknown keys return SVT_HIP_ERR_INVALID. */
 int svt_hip_tune(const char *key, int value);
@@ -282,6 +282,34 @@ int svt_hip_me_sb_search_planes_batch(const uint8_t *d_src_plane, uint32_t src_s
                                       int search_h, const int16_t *d_origins, int x_origin, int y_origin,
                                       uint32_t *d_best_sad, uint32_t *d_best_mv, size_t nblocks,
                                       void *stream);
+
+/* K6 with the encoder's own result rows: d_best_sad / d_best_mv hold, per SB, pu_pitch uint32 whose first 85 (nsq = 0)
+ * or 209 (nsq != 0) entries are MeContext_t.p_sb_best_sad[list][ref][..] / p_sb_best_mv[..] in EbMeTierZeroPu order
+ * (EbMotionEstimationContext.h:47-270): 64x64, 32x32 x4, 16x16 x16, 8x8 x64 and, for the non-square search
+ * open_loop_me_fullpel_search_sblock (EbMotionEstimation.c:3251; picked at :8114 when nsq_search_level is between LEVEL1 and
+ * FULL), 64x32 x2, 32x16 x8, 16x8 x32, 32x64 x2, 16x32 x8, 8x16 x32, 32x8 x16, 8x32 x16, 64x16 x4, 16x64 x4.  IN/OUT running
+ * bests as in svt_hip_me_sb_search_batch (initialise with MAX_SAD_VALUE = 128*128*255).  Sources / windows are dense
+ * (d_*_offsets == NULL: block b at b * *_block_pitch) or addressed on planes by byte offsets.
+ *
+ * flavour: which of the reference's kernel sets the results are bit-identical to.
+ *   SVT_HIP_FLAVOUR_C     its scalar C / SSE4.1 kernels (asm_type 0) - the parity target BASELINE.json names;
+ *   SVT_HIP_FLAVOUR_AVX2  its AVX2 kernels as GCC / clang compile them (asm_type 1, the only value the encoder accepts,
+ *                         EbEncHandle.c:2676).  They differ from the C kernels in three places, all restated exactly
+ *                         (oracle/pixel.c, pinned by tests/golden/me.npz): the 32x32 motion vectors of the 8-search-point
+ *                         kernel (lane swap under __GNUC__, EbComputeSAD_Intrinsic_AVX2.c:3989-4001) and, for the
+ *                         non-square search on widths that are not a multiple of 8, ExtSadCalculation's stale-`sad` test
+ *                         (both flavours, EbMotionEstimation.c:732-736) and the AVX2 single-point kernel's source-stride
+ *                         row fetch (EbComputeSAD_Intrinsic_AVX2.c:50-52).  With the last one the kernel reads reference
+ *                         bytes up to 8 * src_stride + 64 past a 16x16 block's window origin: the caller's reference
+ *                         buffer must cover that, as the encoder's padded pictures do. */
+enum { SVT_HIP_FLAVOUR_C = 0, SVT_HIP_FLAVOUR_AVX2 = 1 };
+#define SVT_HIP_ME_PUS_ALL 209
+int svt_hip_me_fullpel_search_batch(const uint8_t *d_src, uint32_t src_stride, size_t src_block_pitch,
+                                    const uint32_t *d_src_offsets, const uint8_t *d_ref, uint32_t ref_stride,
+                                    size_t ref_block_pitch, const uint32_t *d_ref_offsets, int search_w,
+                                    int search_h, const int16_t *d_origins, int x_origin, int y_origin,
+                                    int flavour, int nsq, uint32_t *d_best_sad, uint32_t *d_best_mv,
+                                    uint32_t pu_pitch, size_t nblocks, void *stream);
 
 /* K7 coefficient-domain distortion (full_distortion_kernel32_bits_func_ptr_array /
  * full_distortion_kernel_cbf_zero32_bits_func_ptr_array, EbPictureOperators.h:268-280;
