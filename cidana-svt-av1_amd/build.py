@@ -13,15 +13,9 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libsvt_hip_dsp.so")
-SOURCES = ["csrc/svt_hip_dsp.hip"]
-import glob as _glob
-# every header the translation unit can include (kernel_cfl.h / kernel_ois.h were missing from a hand-kept list)
-DEPS = (["csrc/svt_hip_dsp.hip", "../include/svt_hip_dsp.h"]
-        + sorted(os.path.relpath(p, os.path.dirname(os.path.abspath(__file__)))
-                 for p in _glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "*.h"))
-                 + _glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "gen", "*.h"))))
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-fwrapv",
-               "-Wall", "-Wno-unused-function"]
+SOURCES = ["csrc/svt_hip_core.hip", "csrc/svt_hip_txfm.hip", "csrc/svt_hip_pixel.hip", "csrc/svt_hip_intra.hip"]
+OBJ_DIR = os.path.join(PKG, "build_obj")            # git-ignored; objects do not travel, the linked .so does
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fwrapv", "-Wall", "-Wno-unused-function"]
 
 
 def _stale(target, deps):
@@ -31,15 +25,40 @@ def _stale(target, deps):
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def _deps_of(obj):
+    """headers a translation unit really included, from hipcc's -MD depfile (every listed file that exists)"""
+    d = obj[:-2] + ".d"
+    if not os.path.exists(d):
+        return None
+    toks = open(d).read().replace("\\\n", " ").split()
+    return [t for t in toks[1:] if os.path.exists(t)]
+
+
 def build_product(force=False, verbose=True):
+    """One hipcc job per translation unit, all in parallel (the 1-D transform headers alone take a minute to compile),
+    then one link.  A unit is rebuilt when its source, any header of its depfile, or this file changed."""
     gen = os.path.join(PKG, "csrc", "gen", "txfm1d_gen.h")
     tools = [os.path.join(PKG, "tools", f) for f in ("txfm_net.py", "gen_device.py")]
     if _stale(gen, tools):
         subprocess.check_call([sys.executable, os.path.join(PKG, "tools", "gen_device.py")])
-    deps = [os.path.join(PKG, d) for d in DEPS]
-    if force or _stale(LIB, deps):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB] + [os.path.join(PKG, s) for s in SOURCES]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    jobs, objs = [], []
+    for src in SOURCES:
+        sp = os.path.join(PKG, src)
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        deps = _deps_of(obj)
+        if force or deps is None or _stale(obj, deps + [sp, os.path.abspath(__file__)]):
+            cmd = [hipcc] + HIPCC_FLAGS + ["-MD", "-c", sp, "-o", obj]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            jobs.append((src, subprocess.Popen(cmd, cwd=PKG)))
+    failed = [src for src, p in jobs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for " + ", ".join(failed))
+    if jobs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=PKG)

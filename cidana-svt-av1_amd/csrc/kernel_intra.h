@@ -467,38 +467,5 @@ __global__ __launch_bounds__(64) void upsample_edge_kernel(PixT* __restrict__ ed
     }
 }
 
-// full_distortion_kernel32_bits / _cbf_zero32_bits (EbPictureOperators.c:283-346):
-// out[blk][0] = sum (c - r)^2 (or sum c^2 when cbf_zero), out[blk][1] = sum c^2.
-// 16 lanes per block, 4 blocks per wave.
-__global__ __launch_bounds__(256) void full_distortion32_kernel(
-    const int32_t* __restrict__ coeff, uint32_t coeff_stride, size_t coeff_block_pitch,
-    const int32_t* __restrict__ recon, uint32_t recon_stride, size_t recon_block_pitch, uint32_t width,
-    uint32_t height, int cbf_zero, unsigned long long* __restrict__ out, uint32_t nblocks) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane >> 4, l = lane & 15;
-    const uint32_t blk = (blockIdx.x * 4 + wave) * 4 + sub;
-    const bool valid = blk < nblocks;
-    unsigned long long resid = 0, pred = 0;
-    if (valid) {
-        const int32_t* pc = coeff + (size_t)blk * coeff_block_pitch;
-        const int32_t* pr = cbf_zero ? nullptr : recon + (size_t)blk * recon_block_pitch;
-        const uint32_t total = width * height;
-        for (uint32_t i = l; i < total; i += 16) {
-            const uint32_t y = i / width, x = i - y * width;
-            const long long c = pc[(size_t)y * coeff_stride + x];
-            pred += (unsigned long long)(c * c);
-            if (!cbf_zero) {
-                const long long d = c - (long long)pr[(size_t)y * recon_stride + x];
-                resid += (unsigned long long)(d * d);
-            }
-        }
-    }
-    resid = group_sum64<16>(resid);
-    pred = group_sum64<16>(pred);
-    if (valid && l == 0) {
-        out[(size_t)blk * 2 + 0] = cbf_zero ? pred : resid;
-        out[(size_t)blk * 2 + 1] = pred;
-    }
-}
 
 }  // namespace svtdev

@@ -1,0 +1,191 @@
+// svt_hip_core.hip — library state, initialisation, tuning knobs, device-memory helpers and the RTCD override table of
+// libsvt_hip_dsp.so (C ABI: include/svt_hip_dsp.h).  No kernels live here.
+#include "host_common.h"
+
+namespace svthost {
+
+
+thread_local char g_err[512] = "";
+std::atomic<int> g_inited{0};
+std::mutex g_init_mu;
+int g_device = -1;
+char g_devname[300] = "";
+int g_num_cu = 256;
+// tuning knobs (svt_hip_tune): fused 32x32 kernel occupancy / grid
+int g_tune_f32_min_waves = 1;
+int g_tune_f32_wg_per_cu = 0;
+int g_tune_f32_nt = 0;
+int g_tune_f32_qmode1 = 0;
+int g_tune_no_staged = 0;
+int g_tune_no_qsad = 0;
+int g_tune_no_q2 = 0;
+int g_tune_no_q16 = 0;
+int g_tune_q2_su4 = 0;
+int g_tune_ois_no_fold = 0;
+int g_tune_no_me16 = 0;
+int g_tune_me_exact = 0;
+int g_tune_no_f32p = 0;
+int g_tune_no_inv_planes = 0;
+int g_tune_no_enc_staged = 0;
+int g_tune_inv32_waves = 4;
+int g_tune_inv32_var = 0;
+
+int set_err(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// The HIP "current device" is a per-THREAD setting and the encoder calls from many pthreads (Threading):
+// every entry point passes through here, so every thread is bound to the library's device once.
+thread_local int t_device_bound = -1;
+int require_init() {
+    if (!g_inited.load(std::memory_order_acquire)) {
+        if (int rc = svt_hip_init(0)) return rc;
+    }
+    if (t_device_bound != g_device) {
+        HIP_TRY(hipSetDevice(g_device));
+        t_device_bound = g_device;
+    }
+    return SVT_HIP_OK;
+}
+int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(SVT_HIP_ERR_RUNTIME, "launch %s: %s", what, hipGetErrorString(e));
+    return SVT_HIP_OK;
+}
+
+const int kTxW[SVT_TX_SIZES_ALL] = {4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64};
+const int kTxH[SVT_TX_SIZES_ALL] = {4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16};
+
+// is_txfm_allowed (test/TxfmCommon.h:172-181; av1_estimate_transform's switch)
+bool txfm_allowed(int tx_size, int tx_type) {
+    if (tx_size < 0 || tx_size >= SVT_TX_SIZES_ALL || tx_type < 0 || tx_type >= SVT_TX_TYPES) return false;
+    const int m = kTxW[tx_size] > kTxH[tx_size] ? kTxW[tx_size] : kTxH[tx_size];
+    if (m == 64) return tx_type == SVT_DCT_DCT;
+    if (m == 32) return tx_type == SVT_DCT_DCT || tx_type == SVT_IDTX;
+    return true;
+}
+
+
+thread_local ThreadCtx t_ctx;
+
+[[noreturn]] void die(const char* fn) {
+    fprintf(stderr, "libsvt_hip_dsp: %s: %s — no CPU fallback exists; aborting\n", fn, g_err);
+    abort();
+}
+
+}  // namespace svthost
+using namespace svthost;
+
+// ===========================================================================
+// init / misc
+// ===========================================================================
+extern "C" int svt_hip_init(int device) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    if (g_inited.load(std::memory_order_acquire)) {
+        if (device != g_device)
+            return set_err(SVT_HIP_ERR_INVALID, "already initialised on device %d (asked for %d): one device per process", g_device, device);
+        return SVT_HIP_OK;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return set_err(SVT_HIP_ERR_NO_DEVICE, "no HIP device (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return set_err(SVT_HIP_ERR_INVALID, "device %d out of range (%d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(g_devname, sizeof(g_devname), "%s %s (%d CUs)", prop.gcnArchName, prop.name, prop.multiProcessorCount);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_err(SVT_HIP_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
+                       prop.gcnArchName);
+    g_num_cu = prop.multiProcessorCount;
+    g_device = device;
+    g_inited.store(1, std::memory_order_release);
+    return SVT_HIP_OK;
+}
+extern "C" void svt_hip_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    g_inited.store(0, std::memory_order_release);
+}
+extern "C" const char* svt_hip_last_error(void) { return g_err; }
+extern "C" int svt_hip_tune(const char* key, int value) {
+    if (!key) return SVT_HIP_ERR_INVALID;
+    if (!strcmp(key, "f32_min_waves")) { g_tune_f32_min_waves = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "f32_wg_per_cu")) { g_tune_f32_wg_per_cu = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "f32_nt")) { g_tune_f32_nt = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "f32_qmode1")) { g_tune_f32_qmode1 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_staged")) { g_tune_no_staged = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_qsad")) { g_tune_no_qsad = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_q2")) { g_tune_no_q2 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_q16")) { g_tune_no_q16 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "q2_su4")) { g_tune_q2_su4 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "ois_no_fold")) { g_tune_ois_no_fold = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_me16")) { g_tune_no_me16 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "me_exact")) { g_tune_me_exact = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_f32p")) { g_tune_no_f32p = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_inv_planes")) { g_tune_no_inv_planes = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_enc_staged")) { g_tune_no_enc_staged = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "inv32_waves")) { g_tune_inv32_waves = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "inv32_var")) { g_tune_inv32_var = value; return SVT_HIP_OK; }
+    return set_err(SVT_HIP_ERR_INVALID, "unknown tuning key %s", key);
+}
+extern "C" const char* svt_hip_device_name(void) { return g_devname; }
+
+extern "C" void* svt_hip_malloc(size_t bytes) {
+    if (require_init() != SVT_HIP_OK) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { set_err(SVT_HIP_ERR_RUNTIME, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+extern "C" void svt_hip_free(void* p) { if (p) (void)hipFree(p); }
+extern "C" int svt_hip_memcpy_h2d(void* d, const void* h, size_t n, void* s) {
+    HIP_TRY(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, (hipStream_t)s));
+    return SVT_HIP_OK;
+}
+extern "C" int svt_hip_memcpy_d2h(void* h, const void* d, size_t n, void* s) {
+    HIP_TRY(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, (hipStream_t)s));
+    return SVT_HIP_OK;
+}
+extern "C" int svt_hip_stream_sync(void* s) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+    return SVT_HIP_OK;
+}
+
+extern "C" int svt_hip_rtcd_override(const svt_hip_rtcd_table* t) {
+    if (!t) return set_err(SVT_HIP_ERR_INVALID, "NULL table");
+    if (int rc = require_init()) return rc;
+    void* fwd[SVT_TX_SIZES_ALL] = {
+        (void*)svt_hip_av1_fwd_txfm2d_4x4, (void*)svt_hip_av1_fwd_txfm2d_8x8, (void*)svt_hip_av1_fwd_txfm2d_16x16,
+        (void*)svt_hip_av1_fwd_txfm2d_32x32, (void*)svt_hip_av1_fwd_txfm2d_64x64, (void*)svt_hip_av1_fwd_txfm2d_4x8,
+        (void*)svt_hip_av1_fwd_txfm2d_8x4, (void*)svt_hip_av1_fwd_txfm2d_8x16, (void*)svt_hip_av1_fwd_txfm2d_16x8,
+        (void*)svt_hip_av1_fwd_txfm2d_16x32, (void*)svt_hip_av1_fwd_txfm2d_32x16, (void*)svt_hip_av1_fwd_txfm2d_32x64,
+        (void*)svt_hip_av1_fwd_txfm2d_64x32, (void*)svt_hip_av1_fwd_txfm2d_4x16, (void*)svt_hip_av1_fwd_txfm2d_16x4,
+        (void*)svt_hip_av1_fwd_txfm2d_8x32, (void*)svt_hip_av1_fwd_txfm2d_32x8, (void*)svt_hip_av1_fwd_txfm2d_16x64,
+        (void*)svt_hip_av1_fwd_txfm2d_64x16};
+    void* inv[SVT_TX_SIZES_ALL] = {
+        (void*)svt_hip_av1_inv_txfm2d_add_4x4, (void*)svt_hip_av1_inv_txfm2d_add_8x8, (void*)svt_hip_av1_inv_txfm2d_add_16x16,
+        (void*)svt_hip_av1_inv_txfm2d_add_32x32, (void*)svt_hip_av1_inv_txfm2d_add_64x64, (void*)svt_hip_av1_inv_txfm2d_add_4x8,
+        (void*)svt_hip_av1_inv_txfm2d_add_8x4, (void*)svt_hip_av1_inv_txfm2d_add_8x16, (void*)svt_hip_av1_inv_txfm2d_add_16x8,
+        (void*)svt_hip_av1_inv_txfm2d_add_16x32, (void*)svt_hip_av1_inv_txfm2d_add_32x16, (void*)svt_hip_av1_inv_txfm2d_add_32x64,
+        (void*)svt_hip_av1_inv_txfm2d_add_64x32, (void*)svt_hip_av1_inv_txfm2d_add_4x16, (void*)svt_hip_av1_inv_txfm2d_add_16x4,
+        (void*)svt_hip_av1_inv_txfm2d_add_8x32, (void*)svt_hip_av1_inv_txfm2d_add_32x8, (void*)svt_hip_av1_inv_txfm2d_add_16x64,
+        (void*)svt_hip_av1_inv_txfm2d_add_64x16};
+    for (int i = 0; i < SVT_TX_SIZES_ALL; i++) {
+        if (t->av1_fwd_txfm2d[i]) *t->av1_fwd_txfm2d[i] = fwd[i];
+        if (t->av1_inv_txfm2d_add[i]) *t->av1_inv_txfm2d_add[i] = inv[i];
+    }
+    if (t->av1_inv_txfm_add) *t->av1_inv_txfm_add = (void*)svt_hip_av1_inv_txfm_add;
+    if (t->aom_quantize_b) *t->aom_quantize_b = (void*)svt_hip_aom_quantize_b;
+    if (t->aom_quantize_b_32x32) *t->aom_quantize_b_32x32 = (void*)svt_hip_aom_quantize_b_32x32;
+    if (t->aom_quantize_b_64x64) *t->aom_quantize_b_64x64 = (void*)svt_hip_aom_quantize_b_64x64;
+    if (t->aom_highbd_quantize_b) *t->aom_highbd_quantize_b = (void*)svt_hip_aom_highbd_quantize_b;
+    if (t->aom_highbd_quantize_b_32x32) *t->aom_highbd_quantize_b_32x32 = (void*)svt_hip_aom_highbd_quantize_b_32x32;
+    if (t->aom_highbd_quantize_b_64x64) *t->aom_highbd_quantize_b_64x64 = (void*)svt_hip_aom_highbd_quantize_b_64x64;
+    if (t->ResidualKernel) *t->ResidualKernel = (void*)svt_hip_residual_kernel;
+    return SVT_HIP_OK;
+}
+

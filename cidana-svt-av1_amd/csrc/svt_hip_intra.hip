@@ -1,0 +1,426 @@
+// svt_hip_intra.hip — entry points of the intra family of libsvt_hip_dsp.so (include/svt_hip_dsp.h): intra prediction, edge
+// filters, chroma-from-luma helpers, txb_init_levels, the open-loop intra search and their drop-ins.
+#include "host_common.h"
+#include "kernel_cfl.h"
+#include "kernel_intra.h"
+#include "kernel_ois.h"
+
+using namespace svtdev;
+using namespace svthost;
+
+// ---- K11 chroma-from-luma helpers + av1_txb_init_levels ----
+static bool cfl_dim_ok(uint32_t v) { return v == 4 || v == 8 || v == 16 || v == 32; }
+
+static int cfl_ac_launch(int in_mode, const void* d_luma, uint32_t luma_stride, size_t luma_block_pitch, const uint32_t* d_xy,
+                         int16_t* d_q3, uint32_t q3_line, size_t q3_block_pitch, uint32_t w, uint32_t h, int subtract,
+                         int round_offset, int num_pel_log2, size_t nblocks, void* stream, const char* what) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_q3 || (in_mode != 2 && !d_luma)) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (!cfl_dim_ok(w) || !cfl_dim_ok(h)) return set_err(SVT_HIP_ERR_INVALID, "chroma block %ux%u", w, h);
+    if (q3_line < w || q3_block_pitch < (size_t)q3_line * (h - 1) + w) return set_err(SVT_HIP_ERR_INVALID, "q3 layout: line %u, block pitch %zu", q3_line, q3_block_pitch);
+    if (num_pel_log2 < 0 || num_pel_log2 > 31) return set_err(SVT_HIP_ERR_INVALID, "num_pel_log2 %d", num_pel_log2);
+    const uint32_t nchunks = (w / (w < 8 ? 4 : 8)) * h;
+    const uint32_t lpb = nchunks < 64 ? nchunks : 64;
+    const size_t lanes = nblocks * lpb;
+    const size_t grid = (lanes + 255) / 256;
+    if (grid > 0x7fffffffu || nblocks > 0x7fffffffu / 64) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+#define CFL_AC(IN)                                                                                                          \
+    hipLaunchKernelGGL((cfl_ac_kernel<IN>), dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_luma, luma_stride,   \
+                       luma_block_pitch, d_xy, d_q3, q3_line, q3_block_pitch, w, h, lpb, subtract, round_offset, num_pel_log2, \
+                       (uint32_t)nblocks)
+    if (in_mode == 0) CFL_AC(0); else if (in_mode == 1) CFL_AC(1); else CFL_AC(2);
+#undef CFL_AC
+    return launch_status(what);
+}
+
+extern "C" int svt_hip_cfl_luma_subsampling_420_batch(const void* d_luma, uint32_t luma_stride, size_t luma_block_pitch,
+                                                      const uint32_t* d_xy, int is_16bit, int16_t* d_q3, uint32_t q3_line,
+                                                      size_t q3_block_pitch, uint32_t width, uint32_t height,
+                                                      int subtract_average, size_t nblocks, void* stream) {
+    if ((width & 1) || (height & 1)) return set_err(SVT_HIP_ERR_INVALID, "luma block %ux%u", width, height);
+    const uint32_t w = width >> 1, h = height >> 1;
+    int lg = 0;
+    while ((1u << lg) < w * h) lg++;
+    return cfl_ac_launch(is_16bit ? 1 : 0, d_luma, luma_stride, luma_block_pitch, d_xy, d_q3, q3_line, q3_block_pitch, w, h,
+                         subtract_average ? 1 : 0, (int)(w * h / 2), lg, nblocks, stream, "cfl_luma_subsampling_420");
+}
+
+extern "C" int svt_hip_subtract_average_batch(int16_t* d_q3, uint32_t q3_line, size_t q3_block_pitch, uint32_t width,
+                                              uint32_t height, int32_t round_offset, int32_t num_pel_log2, size_t nblocks,
+                                              void* stream) {
+    return cfl_ac_launch(2, nullptr, 0, 0, nullptr, d_q3, q3_line, q3_block_pitch, width, height, 1, round_offset,
+                         num_pel_log2, nblocks, stream, "subtract_average");
+}
+
+extern "C" int svt_hip_cfl_predict_batch(const int16_t* d_ac_q3, uint32_t q3_line, size_t q3_block_pitch, const void* d_pred,
+                                         uint32_t pred_stride, void* d_dst, uint32_t dst_stride, const uint32_t* d_xy,
+                                         const int32_t* d_alpha_q3, int bit_depth, uint32_t width, uint32_t height,
+                                         int is_16bit, size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_ac_q3 || !d_pred || !d_dst || !d_alpha_q3) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (!cfl_dim_ok(width) || !cfl_dim_ok(height)) return set_err(SVT_HIP_ERR_INVALID, "chroma block %ux%u", width, height);
+    if ((is_16bit && bit_depth != 8 && bit_depth != 10 && bit_depth != 12) || (!is_16bit && bit_depth != 8))
+        return set_err(SVT_HIP_ERR_INVALID, "bit depth %d", bit_depth);
+    if (q3_line < width || pred_stride < width || dst_stride < width) return set_err(SVT_HIP_ERR_INVALID, "stride smaller than the block");
+    const uint32_t nchunks = (width / (width < 8 ? 4 : 8)) * height;
+    uint32_t sh = 0;
+    while ((1u << sh) < nchunks) sh++;
+    const size_t grid = ((nblocks << sh) + 255) / 256;
+    if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+    const int hi = (1 << bit_depth) - 1;
+    if (is_16bit)
+        hipLaunchKernelGGL((cfl_predict_kernel<uint16_t>), dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_ac_q3, q3_line,
+                           q3_block_pitch, (const uint16_t*)d_pred, pred_stride, (uint16_t*)d_dst, dst_stride, d_xy, d_alpha_q3, hi,
+                           width, height, sh, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL((cfl_predict_kernel<uint8_t>), dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_ac_q3, q3_line,
+                           q3_block_pitch, (const uint8_t*)d_pred, pred_stride, (uint8_t*)d_dst, dst_stride, d_xy, d_alpha_q3, hi,
+                           width, height, sh, (uint32_t)nblocks);
+    return launch_status("cfl_predict");
+}
+
+extern "C" int svt_hip_txb_init_levels_batch(const int32_t* d_coeff, size_t coeff_block_pitch, uint8_t* d_levels_buf,
+                                             size_t levels_block_pitch, uint32_t width, uint32_t height, size_t nblocks,
+                                             void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_coeff || !d_levels_buf) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    auto ok = [](uint32_t v) { return v == 4 || v == 8 || v == 16 || v == 32 || v == 64; };
+    if (!ok(width) || !ok(height)) return set_err(SVT_HIP_ERR_INVALID, "block %ux%u", width, height);
+    const uint32_t bytes = (width + 4) * (height + 6) + 16;      // (W + TX_PAD_HOR) * (H + TX_PAD_VER) + TX_PAD_END
+    if (levels_block_pitch < bytes || (levels_block_pitch & 3) || ((uintptr_t)d_levels_buf & 3))
+        return set_err(SVT_HIP_ERR_INVALID, "levels buffer: %zu B per block (need >= %u, multiple of 4, 4-byte aligned)", levels_block_pitch, bytes);
+    if (coeff_block_pitch < (size_t)width * height) return set_err(SVT_HIP_ERR_INVALID, "coeff_block_pitch %zu", coeff_block_pitch);
+    const uint32_t ndw = bytes >> 2, dpr = (width + 4) >> 2;
+    const bool wide = (levels_block_pitch & 15) == 0 && ((uintptr_t)d_levels_buf & 15) == 0;
+    const uint32_t items = wide ? (ndw + 3) / 4 : ndw;
+    uint32_t lpb = 1;
+    while (lpb < items && lpb < 256) lpb <<= 1;
+    const uint32_t slots = 256 / lpb;
+    const size_t grid = (nblocks + slots - 1) / slots;
+    if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+    const uint32_t row_magic = (uint32_t)(0x100000000ull / dpr) + 1u;
+    if (wide)
+        hipLaunchKernelGGL(txb_init_levels_kernel<true>, dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_coeff, coeff_block_pitch,
+                           d_levels_buf, levels_block_pitch, width, height, lpb, ndw, row_magic, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL(txb_init_levels_kernel<false>, dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_coeff, coeff_block_pitch,
+                           d_levels_buf, levels_block_pitch, width, height, lpb, ndw, row_magic, (uint32_t)nblocks);
+    return launch_status("txb_init_levels");
+}
+
+static bool intra_size_ok(int bw, int bh) {
+    auto ok1 = [](int v) { return v == 4 || v == 8 || v == 16 || v == 32 || v == 64; };
+    if (!ok1(bw) || !ok1(bh)) return false;
+    const int m = bw > bh ? bw : bh, mn = bw < bh ? bw : bh;
+    return m <= 4 * mn;     // the 19 TX sizes
+}
+
+static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pitch,
+                           const uint32_t* d_dst_offsets, const void* d_above, const void* d_left,
+                           int32_t nb_pitch, int mode, int bw, int bh, int upsample_above,
+                           int upsample_left, int dx, int dy, int is_16bit, int bd, size_t nblocks,
+                           void* stream, const DirMulti* multi);
+
+extern "C" int svt_hip_intra_pred_batch(void* d_dst, int32_t dst_stride, size_t dst_block_pitch,
+                                        const uint32_t* d_dst_offsets, const void* d_above, const void* d_left,
+                                        int32_t nb_pitch, int mode, int bw, int bh, int upsample_above,
+                                        int upsample_left, int dx, int dy, int is_16bit, int bd, size_t nblocks,
+                                        void* stream) {
+    return intra_pred_impl(d_dst, dst_stride, dst_block_pitch, d_dst_offsets, d_above, d_left, nb_pitch, mode, bw, bh,
+                           upsample_above, upsample_left, dx, dy, is_16bit, bd, nblocks, stream, nullptr);
+}
+
+// multi (directional modes only): several (dx, dy) of the same zone in one launch on edges staged once, see DirMulti
+static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pitch,
+                           const uint32_t* d_dst_offsets, const void* d_above, const void* d_left,
+                           int32_t nb_pitch, int mode, int bw, int bh, int upsample_above,
+                           int upsample_left, int dx, int dy, int is_16bit, int bd, size_t nblocks,
+                           void* stream, const DirMulti* multi) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_dst || !d_above || !d_left) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (mode < 0 || mode >= SVT_INTRA_MODES) return set_err(SVT_HIP_ERR_INVALID, "intra mode %d", mode);
+    if (!intra_size_ok(bw, bh)) return set_err(SVT_HIP_ERR_INVALID, "block %dx%d is not an AV1 transform size", bw, bh);
+    if ((is_16bit && bd != 10 && bd != 12 && bd != 8) || (!is_16bit && bd != 8)) return set_err(SVT_HIP_ERR_INVALID, "bit depth %d", bd);
+    if ((upsample_above | upsample_left) & ~1) return set_err(SVT_HIP_ERR_INVALID, "upsample flags");
+    if (mode >= SVT_INTRA_Z1) {
+        if (dx <= 0 || dy <= 0) return set_err(SVT_HIP_ERR_INVALID, "dx/dy must be positive");
+        const int need = NB_ORIGIN + (((bw + bh) << 1) + 2);
+        if (nb_pitch < need) return set_err(SVT_HIP_ERR_INVALID, "nb_pitch %d < %d", nb_pitch, need);
+    } else if (nb_pitch < NB_ORIGIN + (bw > bh ? bw : bh)) {
+        return set_err(SVT_HIP_ERR_INVALID, "nb_pitch %d too small", nb_pitch);
+    }
+    const int es = is_16bit ? 2 : 1;
+    const int pxl = 16 / es, ppl = bw < pxl ? bw : pxl;
+    const size_t per_block = (size_t)(bw / ppl) * bh;            // lanes per block: power of two, 4..512
+    const size_t items = per_block * nblocks;
+    size_t grid = (items + 255) / 256;
+    if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+    // grid * 256 must be a multiple of per_block so that a lane keeps its (row, column) across iterations
+    if (per_block > 256) grid = (grid + 1) & ~(size_t)1;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode >= SVT_INTRA_Z1) {
+        // last edge sample the reference may read: index max_base = (bw + bh - 1) << upsample; the LDS copy
+        // continues with copies of it for one lane-row (+2) so the pixel loop needs no bounds test
+        const int lim_a = NB_ORIGIN + ((bw + bh - 1) << upsample_above), lim_l = NB_ORIGIN + ((bw + bh - 1) << upsample_left);
+        const int up = upsample_above > upsample_left ? upsample_above : upsample_left;
+        const int n_pad = (lim_a > lim_l ? lim_a : lim_l) + ((16 / es) << up) + 3;
+        const size_t slots = per_block >= 256 ? 1 : 256 / per_block;
+        const size_t shmem = slots * 2 * (size_t)((n_pad + 7) & ~7) * 4;            // pair dwords (see the kernel)
+        DirMulti dm;
+        if (multi) dm = *multi; else dm.n = 0;
+#define IDL(T, M)                                                                                                     \
+    hipLaunchKernelGGL((intra_dir_kernel<T, M>), dim3((uint32_t)grid), dim3(256), shmem, s, (T*)d_dst, dst_stride, \
+                       dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh,            \
+                       upsample_above, upsample_left, dx, dy, lim_a, lim_l, n_pad, bd, (uint32_t)nblocks, dm)
+#define IDM(T)                                                                                                        \
+    switch (mode) {                                                                                                   \
+    case SVT_INTRA_Z1: IDL(T, IM_Z1); break; case SVT_INTRA_Z2: IDL(T, IM_Z2); break; default: IDL(T, IM_Z3); break;  \
+    }
+        if (is_16bit) { IDM(uint16_t) } else { IDM(uint8_t) }
+#undef IDM
+#undef IDL
+        return launch_status("intra_dir");
+    }
+    const int cnt = mode == SVT_INTRA_DC ? bw + bh : (mode == SVT_INTRA_DC_TOP ? bw : bh);
+    const uint32_t dc_magic = (uint32_t)(0x100000000ull / (uint64_t)cnt) + 1u;
+    constexpr int INTRA_IU = 2;                                    // blocks per lane in the wide kernels
+    const size_t grid_w = (grid + INTRA_IU - 1) / INTRA_IU;
+#define IPL(T, M)                                                                                                     \
+    if (bw >= 16 / (int)sizeof(T))                                                                                    \
+        hipLaunchKernelGGL((intra_pred_kernel<T, M, true, INTRA_IU>), dim3((uint32_t)(per_block > 256 ? (grid_w + 1) & ~(size_t)1 : grid_w)), dim3(256), 0, s, (T*)d_dst, dst_stride, \
+                           dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh, bd,    \
+                           dc_magic, (uint32_t)nblocks);                                                              \
+    else                                                                                                              \
+        hipLaunchKernelGGL((intra_pred_kernel<T, M, false, 1>), dim3((uint32_t)grid), dim3(256), 0, s, (T*)d_dst, dst_stride, \
+                           dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh, bd,    \
+                           dc_magic, (uint32_t)nblocks)
+#define IPM(T)                                                                                                        \
+    switch (mode) {                                                                                                   \
+    case SVT_INTRA_DC: IPL(T, IM_DC); break; case SVT_INTRA_V: IPL(T, IM_V); break; case SVT_INTRA_H: IPL(T, IM_H); break; \
+    case SVT_INTRA_SMOOTH: IPL(T, IM_SMOOTH); break; case SVT_INTRA_SMOOTH_V: IPL(T, IM_SMOOTH_V); break;             \
+    case SVT_INTRA_SMOOTH_H: IPL(T, IM_SMOOTH_H); break; case SVT_INTRA_PAETH: IPL(T, IM_PAETH); break;               \
+    case SVT_INTRA_DC_TOP: IPL(T, IM_DC_TOP); break; case SVT_INTRA_DC_LEFT: IPL(T, IM_DC_LEFT); break;               \
+    default: IPL(T, IM_DC_128); break;                                                                                \
+    }
+    if (is_16bit) { IPM(uint16_t) } else { IPM(uint8_t) }
+#undef IPM
+#undef IPL
+    return launch_status("intra_pred");
+}
+
+extern "C" int svt_hip_filter_intra_edge_batch(void* d_edges, int32_t nb_pitch, int sz, int strength, int is_16bit,
+                                               size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0 || strength == 0) return SVT_HIP_OK;
+    if (!d_edges) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (sz < 1 || sz > 129 || strength < 0 || strength > 3 || nb_pitch < NB_ORIGIN + sz)
+        return set_err(SVT_HIP_ERR_INVALID, "edge sz %d strength %d pitch %d", sz, strength, nb_pitch);
+    hipStream_t s = (hipStream_t)stream;
+    if (is_16bit)
+        hipLaunchKernelGGL((filter_edge_kernel<uint16_t>), dim3((uint32_t)nblocks), dim3(256), 0, s, (uint16_t*)d_edges, nb_pitch, NB_ORIGIN, sz, strength, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL((filter_edge_kernel<uint8_t>), dim3((uint32_t)nblocks), dim3(256), 0, s, (uint8_t*)d_edges, nb_pitch, NB_ORIGIN, sz, strength, (uint32_t)nblocks);
+    return launch_status("filter_intra_edge");
+}
+extern "C" int svt_hip_upsample_intra_edge_batch(void* d_edges, int32_t nb_pitch, int sz, int is_16bit, int bd,
+                                                 size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_edges) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (sz < 1 || sz > 16 || nb_pitch < NB_ORIGIN + 2 * sz) return set_err(SVT_HIP_ERR_INVALID, "upsample sz %d pitch %d", sz, nb_pitch);
+    hipStream_t s = (hipStream_t)stream;
+    if (is_16bit)
+        hipLaunchKernelGGL((upsample_edge_kernel<uint16_t>), dim3((uint32_t)nblocks), dim3(64), 0, s, (uint16_t*)d_edges, nb_pitch, NB_ORIGIN, sz, bd, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL((upsample_edge_kernel<uint8_t>), dim3((uint32_t)nblocks), dim3(64), 0, s, (uint8_t*)d_edges, nb_pitch, NB_ORIGIN, sz, 8, (uint32_t)nblocks);
+    return launch_status("upsample_intra_edge");
+}
+
+// ===========================================================================
+// (A) drop-in entry points: host pointers, one block, synchronous
+// ---- open-loop intra search ----
+static size_t ois_nb_pitch(uint32_t bsize) { return (size_t)NB_ORIGIN + 4 * bsize + 16; }     // multiple of 16
+static size_t ois_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t svt_hip_ois_work_bytes(uint32_t bsize, int ncand, size_t nblocks) {
+    if ((bsize != 8 && bsize != 16 && bsize != 32 && bsize != 64) || ncand <= 0 || ncand > 61) return 0;
+    return 2 * ois_align(nblocks * ois_nb_pitch(bsize)) + ois_align(nblocks) + (size_t)ncand * ois_align(nblocks * (size_t)bsize * bsize);
+}
+
+// dr_intra_derivative (AV1 spec 7.11.2.4; reference EbIntraPrediction.c:299), non-zero entries
+static int ois_dr_derivative(int angle) {
+    static const uint16_t at[][2] = {{3, 1023}, {6, 547}, {9, 372}, {14, 273}, {17, 215}, {20, 178}, {23, 151}, {26, 132},
+                                     {29, 116}, {32, 102}, {36, 90}, {39, 80}, {42, 71}, {45, 64}, {48, 57}, {51, 51},
+                                     {54, 45}, {58, 40}, {61, 35}, {64, 31}, {67, 27}, {70, 23}, {73, 19}, {76, 15},
+                                     {81, 11}, {84, 7}, {87, 3}};
+    for (const auto& e : at)
+        if (e[0] == angle) return e[1];
+    return 0;
+}
+
+extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, uint32_t width, uint32_t height,
+                                        const uint32_t* d_xy, uint32_t bsize, const uint8_t* modes, const int8_t* angle_deltas,
+                                        int ncand, uint32_t* d_distortion, int8_t* d_best_index, void* d_work,
+                                        size_t work_bytes, size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_pic || !d_xy || !d_distortion || !d_best_index || !d_work || !modes || !angle_deltas) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (bsize != 8 && bsize != 16 && bsize != 32 && bsize != 64) return set_err(SVT_HIP_ERR_INVALID, "block size %u", bsize);
+    if (ncand <= 0 || ncand > 61) return set_err(SVT_HIP_ERR_INVALID, "%d candidates (1..61, MAX_OIS_CANDIDATES)", ncand);
+    if (width == 0 || height == 0 || width > 0xffffu || height > 0xffffu || stride < width) return set_err(SVT_HIP_ERR_INVALID, "picture %ux%u stride %u", width, height, stride);
+    if (work_bytes < svt_hip_ois_work_bytes(bsize, ncand, nblocks)) return set_err(SVT_HIP_ERR_INVALID, "work buffer: %zu B, need %zu", work_bytes, svt_hip_ois_work_bytes(bsize, ncand, nblocks));
+    if (nblocks > 0x7fffffffu / 256) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+    static const int mode_angle[13] = {0, 90, 180, 45, 135, 113, 157, 203, 67, 0, 0, 0, 0};      // mode_to_angle_map, EbCodingUnit.h:129
+    for (int c = 0; c < ncand; c++) {
+        if (modes[c] > 12) return set_err(SVT_HIP_ERR_INVALID, "candidate %d: prediction mode %u", c, modes[c]);
+        if (modes[c] >= 1 && modes[c] <= 8) {
+            const int a = mode_angle[modes[c]] + 3 * angle_deltas[c];
+            if (a <= 0 || a >= 270) return set_err(SVT_HIP_ERR_INVALID, "candidate %d: angle %d", c, a);
+            if (a != 90 && a != 180) {
+                const int d1 = a < 90 ? a : (a < 180 ? 180 - a : 270 - a), d2 = a < 180 && a > 90 ? a - 90 : d1;
+                if (!ois_dr_derivative(d1) || !ois_dr_derivative(d2)) return set_err(SVT_HIP_ERR_INVALID, "candidate %d: angle %d has no derivative", c, a);
+            }
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t pitch = ois_nb_pitch(bsize);
+    char* w = (char*)d_work;
+    uint8_t* d_above = (uint8_t*)w;
+    uint8_t* d_left = d_above + ois_align(nblocks * pitch);
+    uint8_t* d_dc = d_left + ois_align(nblocks * pitch);
+    uint8_t* d_pred = d_dc + ois_align(nblocks);
+    if (hipMemsetAsync(d_above, 0, 2 * ois_align(nblocks * pitch), st) != hipSuccess) return set_err(SVT_HIP_ERR_RUNTIME, "hipMemsetAsync");
+    {
+        const uint32_t slots = 256 / (2 * bsize);
+        hipLaunchKernelGGL(ois_gather_kernel, dim3((uint32_t)((nblocks + slots - 1) / slots)), dim3(256), 0, st, d_pic, stride, width,
+                           height, d_xy, bsize, d_above, d_left, (uint32_t)pitch, d_dc, (uint32_t)nblocks);
+        if (int rc = launch_status("ois_gather")) return rc;
+    }
+    // every candidate's prediction into its own dense batch, then ONE SAD launch over (block, candidate).  The
+    // directional candidates of one zone (up to 19) share one launch (DirMulti): 9 prediction launches for the
+    // reference's 45-candidate list instead of 44.
+    const size_t cand_pitch = ois_align(nblocks * (size_t)bsize * bsize);
+    unsigned long long const_mask = 0;
+    DirMulti zone[3];
+    // 8x8 / 16x16 (a block's lanes share a wave): the directional kernels compare each angle's prediction with the source
+    // block themselves (DirMulti SAD mode) - no prediction scratch round trip for 38 of the 45 candidates
+    const bool fold = bsize <= 16 && !g_tune_ois_no_fold;
+    unsigned long long fold_mask = 0;
+    for (auto& z : zone) {
+        z.n = 0; z.batch_pitch = cand_pitch;
+        z.sad_pic = d_pic; z.sad_stride = stride; z.sad_xy = d_xy; z.sad_dist = fold ? d_distortion : nullptr; z.sad_ncand = (uint32_t)ncand;
+    }
+    for (int c = 0; c < ncand; c++) {
+        const int m = modes[c];
+        if (m == 0) { const_mask |= 1ull << c; continue; }     // DC_PRED under the availability rule: constant prediction
+        int mode = -1;
+        if (m >= 1 && m <= 8) {                                               // dr_predictor, EbIntraPrediction.c:3352-3383
+            const int a = mode_angle[m] + 3 * angle_deltas[c];
+            if (a == 90) mode = SVT_INTRA_V;
+            else if (a == 180) mode = SVT_INTRA_H;
+            else {
+                const int zi = a < 90 ? 0 : (a < 180 ? 1 : 2);
+                DirMulti& z = zone[zi];
+                if (z.n == 20) {                                              // flush a full group (longer candidate lists)
+                    if (int rc = intra_pred_impl(d_pred, (int32_t)bsize, (size_t)bsize * bsize, nullptr, d_above, d_left, (int32_t)pitch,
+                                                 SVT_INTRA_Z1 + zi, (int)bsize, (int)bsize, 0, 0, 1, 1, 0, 8, nblocks, stream, &z))
+                        return rc;
+                    z.n = 0;
+                }
+                z.dx[z.n] = (int16_t)(zi == 0 ? ois_dr_derivative(a) : (zi == 1 ? ois_dr_derivative(180 - a) : 1));
+                z.dy[z.n] = (int16_t)(zi == 0 ? 1 : (zi == 1 ? ois_dr_derivative(a - 90) : ois_dr_derivative(270 - a)));
+                z.slot[z.n] = (uint8_t)c;
+                z.n++;
+                if (fold) fold_mask |= 1ull << c;
+                continue;
+            }
+        } else {
+            mode = m == 9 ? SVT_INTRA_SMOOTH : m == 10 ? SVT_INTRA_SMOOTH_V : m == 11 ? SVT_INTRA_SMOOTH_H : SVT_INTRA_PAETH;
+        }
+        if (int rc = svt_hip_intra_pred_batch(d_pred + (size_t)c * cand_pitch, (int32_t)bsize, (size_t)bsize * bsize, nullptr, d_above,
+                                              d_left, (int32_t)pitch, mode, (int)bsize, (int)bsize, 0, 0, 1, 1, 0, 8, nblocks, stream))
+            return rc;
+    }
+    for (int zi = 0; zi < 3; zi++)
+        if (zone[zi].n)
+            if (int rc = intra_pred_impl(d_pred, (int32_t)bsize, (size_t)bsize * bsize, nullptr, d_above, d_left, (int32_t)pitch,
+                                         SVT_INTRA_Z1 + zi, (int)bsize, (int)bsize, 0, 0, 1, 1, 0, 8, nblocks, stream, &zone[zi]))
+                return rc;
+    {
+        const uint32_t lpb = bsize * bsize / (bsize < 16 ? 8 : 16);
+        const uint32_t sad_slots = 256 / lpb;
+        const uint32_t sad_grid = (uint32_t)((nblocks + sad_slots - 1) / sad_slots);
+        const size_t shmem = ((size_t)sad_slots + (lpb > 64 ? 4 : 0)) * (size_t)ncand * sizeof(uint32_t);
+        hipLaunchKernelGGL(ois_sad_kernel, dim3(sad_grid), dim3(256), shmem, st, d_pic, stride, d_xy, bsize, d_pred, cand_pitch,
+                           d_dc, const_mask, fold_mask, d_distortion, d_best_index, (uint32_t)ncand, (uint32_t)nblocks);
+    }
+    return launch_status("ois_sad");
+}
+
+// one intra block: stage [lo, hi) of above / left around the origin, predict, copy the block back
+static void dropin_intra(int mode, int bw, int bh, void* dst, ptrdiff_t stride, const void* above, const void* left,
+                         int a_lo, int a_hi, int l_lo, int l_hi, int ua, int ul, int dx, int dy, int is16, int bd,
+                         const char* fn) {
+    const size_t es = is16 ? 2 : 1;
+    const int pitch = NB_ORIGIN + 2 * (bw + bh) + 16;
+    const size_t nb_b = align256((size_t)pitch * es), px_b = (size_t)bw * bh * es;
+    DROPIN_TRY(t_ctx.ensure(2 * nb_b + px_b), fn);
+    char* d_a = t_ctx.dbuf;
+    char* d_l = t_ctx.dbuf + nb_b;
+    char* d_px = t_ctx.dbuf + 2 * nb_b;
+    HIP_DIE(hipMemsetAsync(d_a, 0, 2 * nb_b, t_ctx.stream), fn);
+    if (a_hi > a_lo)
+        HIP_DIE(hipMemcpyAsync(d_a + (size_t)(NB_ORIGIN + a_lo) * es, (const char*)above + (ptrdiff_t)a_lo * (ptrdiff_t)es,
+                               (size_t)(a_hi - a_lo) * es, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    if (l_hi > l_lo)
+        HIP_DIE(hipMemcpyAsync(d_l + (size_t)(NB_ORIGIN + l_lo) * es, (const char*)left + (ptrdiff_t)l_lo * (ptrdiff_t)es,
+                               (size_t)(l_hi - l_lo) * es, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_intra_pred_batch(d_px, bw, (size_t)bw * bh, nullptr, d_a, d_l, pitch, mode, bw, bh, ua, ul, dx, dy,
+                                        is16, bd, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpy2DAsync(dst, (size_t)stride * es, d_px, (size_t)bw * es, (size_t)bw * es, bh, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+extern "C" void svt_hip_intra_predictor(int mode, int bw, int bh, uint8_t* dst, ptrdiff_t stride, const uint8_t* above,
+                                        const uint8_t* left) {
+    dropin_intra(mode, bw, bh, dst, stride, above, left, -1, bw, 0, bh, 0, 0, 1, 1, 0, 8, "svt_hip_intra_predictor");
+}
+extern "C" void svt_hip_highbd_intra_predictor(int mode, int bw, int bh, uint16_t* dst, ptrdiff_t stride,
+                                               const uint16_t* above, const uint16_t* left, int32_t bd) {
+    dropin_intra(mode, bw, bh, dst, stride, above, left, -1, bw, 0, bh, 0, 0, 1, 1, 1, bd, "svt_hip_highbd_intra_predictor");
+}
+#define DR_RANGES_Z1 0, (((bw + bh - 1) << upsample_above) + 2), 0, 0
+#define DR_RANGES_Z3 0, 0, 0, (((bw + bh - 1) << upsample_left) + 2)
+#define DR_RANGES_Z2 -(1 << upsample_above), (((bw - 1) << upsample_above) + 2), -(1 << upsample_left), (((bh - 1) << upsample_left) + 2)
+extern "C" void svt_hip_av1_dr_prediction_z1(uint8_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t* above,
+                                             const uint8_t* left, int32_t upsample_above, int32_t dx, int32_t dy) {
+    dropin_intra(SVT_INTRA_Z1, bw, bh, dst, stride, above, left, DR_RANGES_Z1, upsample_above, 0, dx, dy, 0, 8, "svt_hip_av1_dr_prediction_z1");
+}
+extern "C" void svt_hip_av1_dr_prediction_z2(uint8_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t* above,
+                                             const uint8_t* left, int32_t upsample_above, int32_t upsample_left,
+                                             int32_t dx, int32_t dy) {
+    dropin_intra(SVT_INTRA_Z2, bw, bh, dst, stride, above, left, DR_RANGES_Z2, upsample_above, upsample_left, dx, dy, 0, 8, "svt_hip_av1_dr_prediction_z2");
+}
+extern "C" void svt_hip_av1_dr_prediction_z3(uint8_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t* above,
+                                             const uint8_t* left, int32_t upsample_left, int32_t dx, int32_t dy) {
+    dropin_intra(SVT_INTRA_Z3, bw, bh, dst, stride, above, left, DR_RANGES_Z3, 0, upsample_left, dx, dy, 0, 8, "svt_hip_av1_dr_prediction_z3");
+}
+extern "C" void svt_hip_av1_highbd_dr_prediction_z1(uint16_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh,
+                                                    const uint16_t* above, const uint16_t* left, int32_t upsample_above,
+                                                    int32_t dx, int32_t dy, int32_t bd) {
+    dropin_intra(SVT_INTRA_Z1, bw, bh, dst, stride, above, left, DR_RANGES_Z1, upsample_above, 0, dx, dy, 1, bd, "svt_hip_av1_highbd_dr_prediction_z1");
+}
+extern "C" void svt_hip_av1_highbd_dr_prediction_z2(uint16_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh,
+                                                    const uint16_t* above, const uint16_t* left, int32_t upsample_above,
+                                                    int32_t upsample_left, int32_t dx, int32_t dy, int32_t bd) {
+    dropin_intra(SVT_INTRA_Z2, bw, bh, dst, stride, above, left, DR_RANGES_Z2, upsample_above, upsample_left, dx, dy, 1, bd, "svt_hip_av1_highbd_dr_prediction_z2");
+}
+extern "C" void svt_hip_av1_highbd_dr_prediction_z3(uint16_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh,
+                                                    const uint16_t* above, const uint16_t* left, int32_t upsample_left,
+                                                    int32_t dx, int32_t dy, int32_t bd) {
+    dropin_intra(SVT_INTRA_Z3, bw, bh, dst, stride, above, left, DR_RANGES_Z3, 0, upsample_left, dx, dy, 1, bd, "svt_hip_av1_highbd_dr_prediction_z3");
+}
+

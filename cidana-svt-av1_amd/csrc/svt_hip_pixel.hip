@@ -1,0 +1,415 @@
+// svt_hip_pixel.hip — entry points of the pixel / search family of libsvt_hip_dsp.so (include/svt_hip_dsp.h): SAD, SSE,
+// residual, SAD search, ME multi-size search, coefficient-domain distortion and their drop-ins.
+#include "host_common.h"
+#include "kernel_me.h"
+#include "kernel_pixel.h"
+
+using namespace svtdev;
+using namespace svthost;
+
+static int sad_sse_common(bool sse, const uint8_t* a, uint32_t as, size_t ap, const uint8_t* b, uint32_t bs,
+                          size_t bp, uint32_t w, uint32_t h, void* out, size_t n, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (n == 0) return SVT_HIP_OK;
+    if (!a || !b || !out) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (w == 0 || h == 0 || w > 128 || h > 128) return set_err(SVT_HIP_ERR_INVALID, "block %ux%u", w, h);
+    if (n == 0) return SVT_HIP_OK;
+    const uint32_t grid = (uint32_t)((n + 15) / 16);
+    if (sse)
+        hipLaunchKernelGGL((sad_sse_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, as, ap, b, bs, bp, w, h, out, (uint32_t)n);
+    else
+        hipLaunchKernelGGL((sad_sse_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, as, ap, b, bs, bp, w, h, out, (uint32_t)n);
+    return launch_status(sse ? "sse" : "sad");
+}
+extern "C" int svt_hip_sad_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                 const uint8_t* d_ref, uint32_t ref_stride, size_t ref_block_pitch, uint32_t width,
+                                 uint32_t height, uint32_t* d_out, size_t nblocks, void* stream) {
+    return sad_sse_common(false, d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, width, height, d_out, nblocks, stream);
+}
+extern "C" int svt_hip_sse_batch(const uint8_t* d_a, uint32_t a_stride, size_t a_block_pitch, const uint8_t* d_b,
+                                 uint32_t b_stride, size_t b_block_pitch, uint32_t width, uint32_t height,
+                                 uint64_t* d_out, size_t nblocks, void* stream) {
+    return sad_sse_common(true, d_a, a_stride, a_block_pitch, d_b, b_stride, b_block_pitch, width, height, d_out, nblocks, stream);
+}
+extern "C" int svt_hip_residual_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                      const uint8_t* d_pred, uint32_t pred_stride, size_t pred_block_pitch,
+                                      int16_t* d_res, uint32_t res_stride, size_t res_block_pitch, uint32_t width,
+                                      uint32_t height, size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_src || !d_pred || !d_res) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (width == 0 || height == 0) return set_err(SVT_HIP_ERR_INVALID, "empty block");
+    if (nblocks == 0) return SVT_HIP_OK;
+    const uint32_t rcs = (width & 15) == 0 ? 16u : ((width & 7) == 0 ? 8u : ((width & 3) == 0 ? 4u : 1u));
+    const size_t total = (size_t)(width / rcs) * height * nblocks;
+    const size_t grid = (total + 255) / 256;
+    if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+    const uint32_t cpr = width / rcs;
+    const size_t per = (size_t)cpr * height;
+    const bool pow2 = (cpr & (cpr - 1)) == 0 && (per & (per - 1)) == 0;
+#define RESL(CS, P2) hipLaunchKernelGGL((residual_kernel<CS, P2>), dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_src, src_stride, \
+                       src_block_pitch, d_pred, pred_stride, pred_block_pitch, d_res, res_stride, res_block_pitch,   \
+                       width, height, (uint32_t)nblocks)
+#define RESC(CS) if (pow2) RESL(CS, true); else RESL(CS, false)
+    if (rcs == 16) { RESC(16); } else if (rcs == 8) { RESC(8); } else if (rcs == 4) { RESC(4); } else { RESC(1); }
+#undef RESC
+#undef RESL
+    return launch_status("residual");
+}
+
+static int sad_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch, const uint32_t* d_src_offs,
+                           const uint8_t* d_ref, uint32_t ref_stride, uint32_t ref_stride_raw,
+                           size_t ref_block_pitch, const uint32_t* d_ref_offs, uint32_t width, uint32_t height,
+                           int16_t search_area_width, int16_t search_area_height,
+                           uint64_t* d_best_sad, int16_t* d_x, int16_t* d_y, size_t nblocks,
+                           void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_src || !d_ref || !d_best_sad || !d_x || !d_y) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (width == 0 || height == 0 || width > 64 || height > 64) return set_err(SVT_HIP_ERR_INVALID, "block %ux%u", width, height);
+    if (search_area_width <= 0 || search_area_height <= 0) return set_err(SVT_HIP_ERR_INVALID, "empty search area");
+    if (nblocks == 0) return SVT_HIP_OK;
+    const uint32_t win_w = width + search_area_width - 1;
+    const bool plain = ref_stride == ref_stride_raw;
+    const uint32_t nrows = plain ? (uint32_t)(search_area_height + height - 1) : (uint32_t)search_area_height * height;
+    const bool q16_for_16x16 = !g_tune_no_q16 && width == 16 && search_area_width % 16 == 0;      // see the q16 routing below
+    if (plain && !g_tune_no_qsad && !g_tune_no_q2 && ((width == 16 && height == 16 && !q16_for_16x16) || (width == 8 && height == 8))) {
+        // small blocks: source block in registers, 4 x 2 candidates per lane
+        const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+        const uint32_t src_bytes = (width * height + 15) & ~15u;
+        const uint32_t groups = (uint32_t)((search_area_width + 3) / 4) * (uint32_t)((search_area_height + 1) / 2);
+        uint32_t lpb = 1;
+        while (lpb < groups && lpb < 64) lpb <<= 1;
+        // window + one spare row + 16 spare bytes per lane, padded to 8 (mod 32) bytes (LDS bank spread, see the kernel)
+        uint32_t ref_bytes = wpitch * (nrows + 1) + 16 * lpb;
+        ref_bytes = ((ref_bytes + 31) & ~31u) + 8;
+        const uint32_t per_blk = src_bytes + ref_bytes;
+        if (per_blk <= 64 * 1024) {
+            uint32_t threads = 256;
+            while (threads > lpb && (size_t)(threads / lpb) * per_blk > 64 * 1024) threads >>= 1;
+            const uint32_t slots = threads / lpb;
+            const uint32_t grid = (uint32_t)((nblocks + slots - 1) / slots);
+#define SSQ2(CW, CH, SU)                                                                                                \
+    hipLaunchKernelGGL((sad_search_q2_kernel<CW, CH, SU>), dim3(grid), dim3(threads), (size_t)slots * per_blk, (hipStream_t)stream, \
+                       d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, (int)search_area_width,         \
+                       (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, ref_bytes, lpb, cpr_magic,           \
+                       d_src_offs, d_ref_offs, (uint32_t)nblocks)
+            // exact j / cpr for j < 2^16 chunks (cpr <= 8): floor(2^32 / cpr) + 1
+            const uint32_t cpr_magic = (uint32_t)(0x100000000ull / ((win_w + 15) >> 4)) + 1u;
+            // staging depth: all of a lane's chunks in ONE batch of loads when that takes at most 8 per lane (one memory
+            // latency per block instead of two: the kernel is latency-bound at 3 waves per SIMD)
+            const uint32_t nchunk = ((win_w + 15) >> 4) * nrows;
+            const bool deep = !g_tune_q2_su4 && nchunk > 4 * lpb;
+            if (width == 16) { if (deep) SSQ2(16, 16, 8); else SSQ2(16, 16, 4); }
+            else { if (deep) SSQ2(8, 8, 8); else SSQ2(8, 8, 4); }
+#undef SSQ2
+            return launch_status("sad_search_q2");
+        }
+    }
+    // 16-wide blocks: 16x32 / 16x64 always (measured 2.1-2.3x over sad_search_q_kernel); 16x16 when no candidate
+    // of a lane is masked (search width % 16 == 0: 10 % over q2, equal otherwise)
+    if (plain && !g_tune_no_qsad && !g_tune_no_q16 && height % (256 / (width ? width : 1)) == 0 &&
+        (width == 32 || width == 64 || (width == 16 && (height != 16 || search_area_width % 16 == 0)))) {
+        // wide blocks: 16 candidates per lane on b128 LDS reads (sad_search_q16_kernel)
+        uint32_t wpitch = (((uint32_t)search_area_width + 15) & ~15u) + width;
+        if (((wpitch >> 4) & 1) == 0) wpitch += 16;            // odd multiple of 16 B: bank spread over search rows
+        const uint32_t ref_bytes = wpitch * nrows;
+        const uint32_t per_blk = width * height + ref_bytes;
+        if (per_blk <= 64 * 1024) {
+            const uint32_t tasks = (uint32_t)((search_area_width + 15) / 16) * (uint32_t)search_area_height;
+            uint32_t tsh = 0;
+            while ((1u << tsh) < tasks && tsh < 6) tsh++;
+            const uint32_t row_groups = height / (256 / width);
+            uint32_t lpb = 1u << tsh;
+            while (lpb < 64 && (lpb >> tsh) * 2 <= row_groups) lpb <<= 1;
+            uint32_t threads = 256;
+            while (threads > lpb && (size_t)(threads / lpb) * per_blk > 64 * 1024) threads >>= 1;
+            const uint32_t slots = threads / lpb;
+            const uint32_t grid = (uint32_t)((nblocks + slots - 1) / slots);
+            const uint32_t cpr_magic = (uint32_t)(0x100000000ull / ((win_w + 15) >> 4)) + 1u;
+#define SSQ16(CW)                                                                                                       \
+    hipLaunchKernelGGL((sad_search_q16_kernel<CW>), dim3(grid), dim3(threads), (size_t)slots * per_blk, (hipStream_t)stream, \
+                       d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, height, (int)search_area_width,  \
+                       (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, wpitch, ref_bytes, lpb, tsh,         \
+                       cpr_magic, d_src_offs, d_ref_offs, (uint32_t)nblocks)
+            if (width == 16) SSQ16(16); else if (width == 32) SSQ16(32); else SSQ16(64);
+#undef SSQ16
+            return launch_status("sad_search_q16");
+        }
+    }
+    if ((width & 3) == 0 && !g_tune_no_qsad) {
+        // quad-SAD kernel: 4 candidates per lane
+        const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+        const uint32_t src_bytes = (width * height + 15) & ~15u;
+        const uint32_t ref_bytes = (wpitch * nrows + 16 + 15) & ~15u;
+        const uint32_t per_blk = src_bytes + ref_bytes;
+        if (per_blk > 64 * 1024) return set_err(SVT_HIP_ERR_INVALID, "search window needs %u B of LDS per block (> 64 KiB)", per_blk);
+        const uint32_t groups = (uint32_t)((search_area_width + 3) / 4) * (uint32_t)search_area_height;
+        uint32_t lpb = 1;
+        while (lpb < groups && lpb < 64) lpb <<= 1;
+        uint32_t threads = 256;
+        while (threads > lpb && (size_t)(threads / lpb) * per_blk > 64 * 1024) threads >>= 1;
+        const uint32_t slots = threads / lpb;
+        const uint32_t grid = (uint32_t)((nblocks + slots - 1) / slots);
+#define SSQ(CW, CH)                                                                                                     \
+    hipLaunchKernelGGL((sad_search_q_kernel<CW, CH>), dim3(grid), dim3(threads), (size_t)slots * per_blk, (hipStream_t)stream, \
+                       d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_stride_raw, ref_block_pitch, width, height,  \
+                       (int)search_area_width, (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, src_bytes, \
+                       ref_bytes, lpb, d_src_offs, d_ref_offs, (uint32_t)nblocks)
+        if (width == 16 && height == 16) SSQ(16, 16);
+        else if (width == 8 && height == 8) SSQ(8, 8);
+        else if (width == 32 && height == 32) SSQ(32, 32);
+        else if (width == 64 && height == 64) SSQ(64, 64);
+        else SSQ(0, 0);
+#undef SSQ
+        return launch_status("sad_search_q");
+    }
+    const uint32_t wpitch = (win_w + 3 + 8) & ~3u;
+    const uint32_t spitch = (width + 3) & ~3u;
+    const uint32_t src_bytes = (spitch * height + 15) & ~15u;
+    const uint32_t ref_bytes = (wpitch * nrows + 16 + 15) & ~15u;
+    const uint32_t per_wave = src_bytes + ref_bytes;
+    if (per_wave > 64 * 1024) return set_err(SVT_HIP_ERR_INVALID, "search window needs %u B of LDS per block (> 64 KiB)", per_wave);
+    uint32_t waves = (64 * 1024) / per_wave;
+    if (waves > 4) waves = 4;
+    const uint32_t grid = (uint32_t)((nblocks + waves - 1) / waves);
+    hipLaunchKernelGGL(sad_search_kernel, dim3(grid), dim3(waves * 64), waves * per_wave, (hipStream_t)stream, d_src,
+                       src_stride, src_block_pitch, d_ref, ref_stride, ref_stride_raw, ref_block_pitch, width, height,
+                       (int)search_area_width, (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y,
+                       src_bytes, ref_bytes, d_src_offs, d_ref_offs, (uint32_t)nblocks);
+    return launch_status("sad_search");
+}
+
+extern "C" int svt_hip_sad_search_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                        const uint8_t* d_ref, uint32_t ref_stride, uint32_t ref_stride_raw,
+                                        size_t ref_block_pitch, uint32_t width, uint32_t height,
+                                        int16_t search_area_width, int16_t search_area_height,
+                                        uint64_t* d_best_sad, int16_t* d_x, int16_t* d_y, size_t nblocks,
+                                        void* stream) {
+    return sad_search_impl(d_src, src_stride, src_block_pitch, nullptr, d_ref, ref_stride, ref_stride_raw, ref_block_pitch,
+                           nullptr, width, height, search_area_width, search_area_height, d_best_sad, d_x, d_y, nblocks, stream);
+}
+extern "C" int svt_hip_sad_search_planes_batch(const uint8_t* d_src_plane, uint32_t src_stride, const uint32_t* d_src_offsets,
+                                               const uint8_t* d_ref_plane, uint32_t ref_stride, uint32_t ref_stride_raw,
+                                               const uint32_t* d_ref_offsets, uint32_t width, uint32_t height,
+                                               int16_t search_area_width, int16_t search_area_height,
+                                               uint64_t* d_best_sad, int16_t* d_x, int16_t* d_y, size_t nblocks,
+                                               void* stream) {
+    if (nblocks && (!d_src_offsets || !d_ref_offsets)) { if (int rc = require_init()) return rc; return set_err(SVT_HIP_ERR_INVALID, "NULL offset table"); }
+    return sad_search_impl(d_src_plane, src_stride, 0, d_src_offsets, d_ref_plane, ref_stride, ref_stride_raw, 0, d_ref_offsets,
+                           width, height, search_area_width, search_area_height, d_best_sad, d_x, d_y, nblocks, stream);
+}
+
+static int me_sb_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch, const uint32_t* d_src_offs,
+                             const uint8_t* d_ref, uint32_t ref_stride, size_t ref_block_pitch, const uint32_t* d_ref_offs,
+                             int search_w, int search_h, const int16_t* d_origins, int x_origin,
+                             int y_origin, uint32_t* d_best_sad, uint32_t* d_best_mv, size_t nblocks,
+                             void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_src || !d_ref || !d_best_sad || !d_best_mv) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (search_w <= 0 || search_h <= 0 || search_w * search_h > 4096)
+        return set_err(SVT_HIP_ERR_INVALID, "search area %dx%d (1..4096 points)", search_w, search_h);
+    const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
+    const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+    const size_t lds = 32 * 64 + (size_t)wpitch * win_h;
+    if (lds > 60 * 1024) return set_err(SVT_HIP_ERR_INVALID, "search window needs %zu B of LDS (> 60 KiB)", lds);
+    if (!g_tune_no_me16) {      // 16 points per lane; widths that are not a multiple of 16 mask the tail of each row
+        if ((search_w & 15) == 0)
+            hipLaunchKernelGGL(me_sb_search16_kernel<false>, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
+                               src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
+                               x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offs, d_ref_offs, (uint32_t)nblocks);
+        else
+            hipLaunchKernelGGL(me_sb_search16_kernel<true>, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
+                               src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
+                               x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offs, d_ref_offs, (uint32_t)nblocks);
+        return launch_status("me_sb_search16");
+    }
+    hipLaunchKernelGGL(me_sb_search_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
+                       src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
+                       x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offs, d_ref_offs, (uint32_t)nblocks);
+    return launch_status("me_sb_search");
+}
+
+extern "C" int svt_hip_me_sb_search_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                          const uint8_t* d_ref, uint32_t ref_stride, size_t ref_block_pitch,
+                                          int search_w, int search_h, const int16_t* d_origins, int x_origin,
+                                          int y_origin, uint32_t* d_best_sad, uint32_t* d_best_mv, size_t nblocks,
+                                          void* stream) {
+    return me_sb_search_impl(d_src, src_stride, src_block_pitch, nullptr, d_ref, ref_stride, ref_block_pitch, nullptr, search_w,
+                             search_h, d_origins, x_origin, y_origin, d_best_sad, d_best_mv, nblocks, stream);
+}
+extern "C" int svt_hip_me_sb_search_planes_batch(const uint8_t* d_src_plane, uint32_t src_stride, const uint32_t* d_src_offsets,
+                                                 const uint8_t* d_ref_plane, uint32_t ref_stride, const uint32_t* d_ref_offsets,
+                                                 int search_w, int search_h, const int16_t* d_origins, int x_origin,
+                                                 int y_origin, uint32_t* d_best_sad, uint32_t* d_best_mv, size_t nblocks,
+                                                 void* stream) {
+    if (nblocks && (!d_src_offsets || !d_ref_offsets)) { if (int rc = require_init()) return rc; return set_err(SVT_HIP_ERR_INVALID, "NULL offset table"); }
+    return me_sb_search_impl(d_src_plane, src_stride, 0, d_src_offsets, d_ref_plane, ref_stride, 0, d_ref_offsets, search_w,
+                             search_h, d_origins, x_origin, y_origin, d_best_sad, d_best_mv, nblocks, stream);
+}
+
+// K6 in the reference's result layout, both result flavours, square or all 209 PUs (include/svt_hip_dsp.h)
+extern "C" int svt_hip_me_fullpel_search_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                               const uint32_t* d_src_offsets, const uint8_t* d_ref, uint32_t ref_stride,
+                                               size_t ref_block_pitch, const uint32_t* d_ref_offsets, int search_w,
+                                               int search_h, const int16_t* d_origins, int x_origin, int y_origin,
+                                               int flavour, int nsq, uint32_t* d_best_sad, uint32_t* d_best_mv,
+                                               uint32_t pu_pitch, size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_src || !d_ref || !d_best_sad || !d_best_mv) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (flavour != SVT_HIP_FLAVOUR_C && flavour != SVT_HIP_FLAVOUR_AVX2) return set_err(SVT_HIP_ERR_INVALID, "flavour %d", flavour);
+    const uint32_t npus = nsq ? SVT_HIP_ME_PUS_ALL : SVT_HIP_ME_PUS;
+    if (pu_pitch < npus) return set_err(SVT_HIP_ERR_INVALID, "pu_pitch %u < %u PUs", pu_pitch, npus);
+    if (search_w <= 0 || search_h <= 0 || search_w * search_h > 4096)
+        return set_err(SVT_HIP_ERR_INVALID, "search area %dx%d (1..4096 points)", search_w, search_h);
+    if (!nsq && !g_tune_me_exact) {
+        // square PUs: the 16-points-per-lane kernel, any width; the AVX2 flavour only re-labels the 32x32 keys
+        const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
+        const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+        const size_t lds = 32 * 64 + (size_t)wpitch * win_h;
+        if (lds <= 60 * 1024) {
+            const int w8q = flavour == SVT_HIP_FLAVOUR_AVX2 ? (search_w & ~7) : 0;
+            if ((search_w & 15) == 0)
+                hipLaunchKernelGGL(me_sb_search16_kernel<false>, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
+                                   src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
+                                   x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offsets, d_ref_offsets, (uint32_t)nblocks,
+                                   w8q, 1, pu_pitch);
+            else
+                hipLaunchKernelGGL(me_sb_search16_kernel<true>, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
+                                   src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
+                                   x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offsets, d_ref_offsets, (uint32_t)nblocks,
+                                   w8q, 1, pu_pitch);
+            return launch_status("me_sb_search16 (reference layout)");
+        }
+    }
+    hipLaunchKernelGGL(me_fullpel_exact_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), 0, (hipStream_t)stream, d_src, src_stride,
+                       src_block_pitch, d_src_offsets, d_ref, ref_stride, ref_block_pitch, d_ref_offsets, search_w, search_h,
+                       d_origins, x_origin, y_origin, flavour, nsq ? 1 : 0, d_best_sad, d_best_mv, pu_pitch, (uint32_t)nblocks);
+    return launch_status("me_fullpel_exact");
+}
+
+extern "C" int svt_hip_full_distortion32_batch(const int32_t* d_coeff, uint32_t coeff_stride, size_t coeff_block_pitch,
+                                               const int32_t* d_recon, uint32_t recon_stride, size_t recon_block_pitch,
+                                               uint32_t width, uint32_t height, int cbf_zero, uint64_t* d_out,
+                                               size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_coeff || !d_out || (!cbf_zero && !d_recon)) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (width == 0 || height == 0 || width > 128 || height > 128) return set_err(SVT_HIP_ERR_INVALID, "area %ux%u", width, height);
+    hipLaunchKernelGGL(full_distortion32_kernel, dim3((uint32_t)((nblocks + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                       d_coeff, coeff_stride, coeff_block_pitch, d_recon, recon_stride, recon_block_pitch, width, height,
+                       cbf_zero, (unsigned long long*)d_out, (uint32_t)nblocks);
+    return launch_status("full_distortion32");
+}
+
+// copies a w x h u8 block with `stride` into dense device memory
+static void h2d_block(void* d, const uint8_t* h, uint32_t stride, uint32_t w, uint32_t ht, const char* fn) {
+    HIP_DIE(hipMemcpy2DAsync(d, w, h, stride, w, ht, hipMemcpyHostToDevice, t_ctx.stream), fn);
+}
+
+extern "C" uint32_t svt_hip_nxm_sad_kernel(const uint8_t* src, uint32_t src_stride, const uint8_t* ref,
+                                           uint32_t ref_stride, uint32_t height, uint32_t width) {
+    const char* fn = "svt_hip_nxm_sad_kernel";
+    const size_t bb = align256((size_t)width * height);
+    DROPIN_TRY(t_ctx.ensure(2 * bb + 256), fn);
+    uint8_t* d_a = (uint8_t*)t_ctx.dbuf;
+    uint8_t* d_b = d_a + bb;
+    uint32_t* d_o = (uint32_t*)(d_a + 2 * bb);
+    h2d_block(d_a, src, src_stride, width, height, fn);
+    h2d_block(d_b, ref, ref_stride, width, height, fn);
+    DROPIN_TRY(svt_hip_sad_batch(d_a, width, 0, d_b, width, 0, width, height, d_o, 1, t_ctx.stream), fn);
+    uint32_t out = 0;
+    HIP_DIE(hipMemcpyAsync(&out, d_o, 4, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+    return out;
+}
+extern "C" uint64_t svt_hip_spatial_full_distortion_kernel(uint8_t* input, uint32_t input_stride, uint8_t* recon,
+                                                           uint32_t recon_stride, uint32_t area_width,
+                                                           uint32_t area_height) {
+    const char* fn = "svt_hip_spatial_full_distortion_kernel";
+    const size_t bb = align256((size_t)area_width * area_height);
+    DROPIN_TRY(t_ctx.ensure(2 * bb + 256), fn);
+    uint8_t* d_a = (uint8_t*)t_ctx.dbuf;
+    uint8_t* d_b = d_a + bb;
+    uint64_t* d_o = (uint64_t*)(d_a + 2 * bb);
+    h2d_block(d_a, input, input_stride, area_width, area_height, fn);
+    h2d_block(d_b, recon, recon_stride, area_width, area_height, fn);
+    DROPIN_TRY(svt_hip_sse_batch(d_a, area_width, 0, d_b, area_width, 0, area_width, area_height, d_o, 1, t_ctx.stream), fn);
+    uint64_t out = 0;
+    HIP_DIE(hipMemcpyAsync(&out, d_o, 8, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+    return out;
+}
+extern "C" void svt_hip_residual_kernel(uint8_t* input, uint32_t input_stride, uint8_t* pred, uint32_t pred_stride,
+                                        int16_t* residual, uint32_t residual_stride, uint32_t area_width,
+                                        uint32_t area_height) {
+    const char* fn = "svt_hip_residual_kernel";
+    const size_t bb = align256((size_t)area_width * area_height);
+    DROPIN_TRY(t_ctx.ensure(4 * bb), fn);
+    uint8_t* d_a = (uint8_t*)t_ctx.dbuf;
+    uint8_t* d_b = d_a + bb;
+    int16_t* d_r = (int16_t*)(d_a + 2 * bb);
+    h2d_block(d_a, input, input_stride, area_width, area_height, fn);
+    h2d_block(d_b, pred, pred_stride, area_width, area_height, fn);
+    DROPIN_TRY(svt_hip_residual_batch(d_a, area_width, 0, d_b, area_width, 0, d_r, area_width, 0, area_width, area_height, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpy2DAsync(residual, (size_t)residual_stride * 2, d_r, (size_t)area_width * 2, (size_t)area_width * 2,
+                             area_height, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+extern "C" void svt_hip_sad_loop_kernel(uint8_t* src, uint32_t src_stride, uint8_t* ref, uint32_t ref_stride,
+                                        uint32_t height, uint32_t width, uint64_t* best_sad, int16_t* x_search_center,
+                                        int16_t* y_search_center, uint32_t src_stride_raw, int16_t search_area_width,
+                                        int16_t search_area_height) {
+    const char* fn = "svt_hip_sad_loop_kernel";
+    // stage the touched source rows and the touched reference span as-is (strides kept)
+    const size_t src_span = (size_t)(height - 1) * src_stride + width;
+    const size_t ref_span = (size_t)(search_area_height - 1) * src_stride_raw + (size_t)(height - 1) * ref_stride +
+                            width + search_area_width - 1;
+    const size_t sb = align256(src_span), rb = align256(ref_span);
+    DROPIN_TRY(t_ctx.ensure(sb + rb + 256), fn);
+    uint8_t* d_s = (uint8_t*)t_ctx.dbuf;
+    uint8_t* d_r = d_s + sb;
+    uint64_t* d_best = (uint64_t*)(d_r + rb);
+    int16_t* d_xy = (int16_t*)(d_best + 1);
+    int16_t xy[2] = {*x_search_center, *y_search_center};
+    HIP_DIE(hipMemcpyAsync(d_s, src, src_span, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(d_r, ref, ref_span, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(d_xy, xy, 4, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_sad_search_batch(d_s, src_stride, 0, d_r, ref_stride, src_stride_raw, 0, width, height,
+                                        search_area_width, search_area_height, d_best, d_xy, d_xy + 1, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(best_sad, d_best, 8, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(xy, d_xy, 4, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+    *x_search_center = xy[0];
+    *y_search_center = xy[1];
+}
+
+static void dropin_dist32(int cbf_zero, int32_t* coeff, uint32_t cs, int32_t* recon, uint32_t rs, uint64_t out[2],
+                          uint32_t w, uint32_t h, const char* fn) {
+    const size_t bb = align256((size_t)w * h * 4);
+    DROPIN_TRY(t_ctx.ensure(2 * bb + 256), fn);
+    int32_t* d_c = (int32_t*)t_ctx.dbuf;
+    int32_t* d_r = (int32_t*)(t_ctx.dbuf + bb);
+    uint64_t* d_o = (uint64_t*)(t_ctx.dbuf + 2 * bb);
+    HIP_DIE(hipMemcpy2DAsync(d_c, (size_t)w * 4, coeff, (size_t)cs * 4, (size_t)w * 4, h, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    if (!cbf_zero)
+        HIP_DIE(hipMemcpy2DAsync(d_r, (size_t)w * 4, recon, (size_t)rs * 4, (size_t)w * 4, h, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_full_distortion32_batch(d_c, w, 0, d_r, w, 0, w, h, cbf_zero, d_o, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(out, d_o, 16, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+extern "C" void svt_hip_full_distortion_kernel32_bits(int32_t* coeff, uint32_t coeff_stride, int32_t* recon_coeff,
+                                                      uint32_t recon_coeff_stride, uint64_t distortion_result[2],
+                                                      uint32_t area_width, uint32_t area_height) {
+    dropin_dist32(0, coeff, coeff_stride, recon_coeff, recon_coeff_stride, distortion_result, area_width, area_height,
+                  "svt_hip_full_distortion_kernel32_bits");
+}
+extern "C" void svt_hip_full_distortion_kernel_cbf_zero32_bits(int32_t* coeff, uint32_t coeff_stride, int32_t* recon_coeff,
+                                                               uint32_t recon_coeff_stride, uint64_t distortion_result[2],
+                                                               uint32_t area_width, uint32_t area_height) {
+    dropin_dist32(1, coeff, coeff_stride, recon_coeff, recon_coeff_stride, distortion_result, area_width, area_height,
+                  "svt_hip_full_distortion_kernel_cbf_zero32_bits");
+}
+
