@@ -102,6 +102,16 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_ois_search_batch.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_int,
                                            c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]
     L.svt_hip_txb_init_levels_batch.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_uint32, c_uint32, c_size_t, c_void_p]
+    L.svt_hip_sad_planes_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_uint32, c_void_p,
+                                           c_size_t, c_void_p]
+    L.svt_hip_sad_x4d_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_uint32,
+                                        c_void_p, c_size_t, c_void_p]
+    L.svt_hip_sad_avg_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t,
+                                        c_uint32, c_uint32, c_void_p, c_size_t, c_void_p]
+    L.svt_hip_residual16_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t, c_void_p, c_uint32, c_size_t,
+                                           c_uint32, c_uint32, c_size_t, c_void_p]
+    L.svt_hip_picture_full_distortion32_batch.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_uint32, c_uint32, c_void_p, c_int,
+                                                          c_void_p, c_size_t, c_void_p]
     L.svt_hip_me_fullpel_search_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_void_p, c_uint32, c_size_t, c_void_p,
                                                   c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_uint32,
                                                   c_size_t, c_void_p]

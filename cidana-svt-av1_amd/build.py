@@ -13,9 +13,10 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libsvt_hip_dsp.so")
-SOURCES = ["csrc/svt_hip_core.hip", "csrc/svt_hip_txfm.hip", "csrc/svt_hip_pixel.hip", "csrc/svt_hip_intra.hip"]
+SOURCES = ["csrc/svt_hip_core.hip", "csrc/svt_hip_txfm.hip", "csrc/svt_hip_pixel.hip", "csrc/svt_hip_intra.hip", "csrc/host_tables.cpp"]
 OBJ_DIR = os.path.join(PKG, "build_obj")            # git-ignored; objects do not travel, the linked .so does
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fwrapv", "-Wall", "-Wno-unused-function"]
+HOST_FLAGS = ["-x", "c++", "-O2", "-fPIC", "-std=c++17", "-Wall"]        # host-only units: no device pass
 
 
 def _stale(target, deps):
@@ -46,11 +47,11 @@ def build_product(force=False, verbose=True):
     jobs, objs = [], []
     for src in SOURCES:
         sp = os.path.join(PKG, src)
-        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
         objs.append(obj)
         deps = _deps_of(obj)
         if force or deps is None or _stale(obj, deps + [sp, os.path.abspath(__file__)]):
-            cmd = [hipcc] + HIPCC_FLAGS + ["-MD", "-c", sp, "-o", obj]
+            cmd = [hipcc] + (HIPCC_FLAGS if src.endswith(".hip") else HOST_FLAGS) + ["-MD", "-c", sp, "-o", obj]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             jobs.append((src, subprocess.Popen(cmd, cwd=PKG)))

@@ -10,34 +10,52 @@ namespace svtdev {
 // C_DEFAULT/EbPictureOperators_C.c:40).  Blocks dense or at offsets; one
 // LPB-lane group per block, lane = (row, 4-pixel group) walking the block.
 // ---------------------------------------------------------------------------
-template <bool SSE>
+// MODE 0: SAD (fast_loop_nx_m_sad_kernel / aom_sadMxN_c), 1: SSE (spatial_full_distortion_kernel), 2: SAD against the
+// rounded average of two references (combined_averaging_sad, C_DEFAULT/EbComputeSAD_C.c:13-40: avg = (r1 + r2 + 1) >> 1).
+// Addressing: block i of `a` is at a + (a_offs ? a_offs[i >> a_shift] : (i >> a_shift) * a_block_pitch) - a_shift = 2 shares
+// one source block between the four references of aom_sadMxNx4d - and block i of `b` at b + (b_offs ? b_offs[i] : i * pitch).
+template <int MODE>
 __global__ __launch_bounds__(256) void sad_sse_kernel(
-    const uint8_t* __restrict__ a, uint32_t a_stride, size_t a_block_pitch,
-    const uint8_t* __restrict__ b, uint32_t b_stride, size_t b_block_pitch,
+    const uint8_t* __restrict__ a, uint32_t a_stride, size_t a_block_pitch, const uint32_t* __restrict__ a_offs, int a_shift,
+    const uint8_t* __restrict__ b, uint32_t b_stride, size_t b_block_pitch, const uint32_t* __restrict__ b_offs,
+    const uint8_t* __restrict__ c2, uint32_t c_stride, size_t c_block_pitch,
     uint32_t width, uint32_t height, void* __restrict__ out, uint32_t nblocks) {
     // 16 lanes per block, 4 blocks per wave; a lane walks (row, chunk) items with chunks of
     // cs = 16 / 8 / 4 / 1 bytes fetched by one unaligned load each.  SAD: v_sad_u8 per dword;
     // SSE: sum (x-y)^2 = x.x + y.y - 2 x.y with three v_dot4_u32_u8 per dword (exact in u32).
+    constexpr bool SSE = MODE == 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 4, l = lane & 15;
     const uint32_t blk = (blockIdx.x * 4 + wave) * 4 + sub;
     const bool valid = blk < nblocks;
     unsigned long long acc = 0;
     if (valid) {
-        const uint8_t* pa = a + (size_t)blk * a_block_pitch;
-        const uint8_t* pb = b + (size_t)blk * b_block_pitch;
+        const uint32_t ai = blk >> a_shift;
+        const uint8_t* pa = a + (a_offs ? (size_t)a_offs[ai] : (size_t)ai * a_block_pitch);
+        const uint8_t* pb = b + (b_offs ? (size_t)b_offs[blk] : (size_t)blk * b_block_pitch);
+        const uint8_t* pc = MODE == 2 ? c2 + (size_t)blk * c_block_pitch : nullptr;
         const uint32_t cs = (width & 15) == 0 ? 16u : ((width & 7) == 0 ? 8u : ((width & 3) == 0 ? 4u : 1u));
         const uint32_t cpr = width / cs, items = cpr * height;
         uint32_t y = l / cpr, c = l - y * cpr;                 // advance (y, c) by 16 items without dividing again
         const uint32_t dy16 = 16 / cpr, dc16 = 16 - dy16 * cpr;
         for (uint32_t i = l; i < items; i += 16) {
-            uint32_t va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0};
+            uint32_t va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0}, vc[4] = {0, 0, 0, 0};
             const uint8_t* qa = pa + (size_t)y * a_stride + c * cs;
             const uint8_t* qb = pb + (size_t)y * b_stride + c * cs;
             if (cs == 16) { __builtin_memcpy(va, qa, 16); __builtin_memcpy(vb, qb, 16); }
             else if (cs == 8) { __builtin_memcpy(va, qa, 8); __builtin_memcpy(vb, qb, 8); }
             else if (cs == 4) { __builtin_memcpy(va, qa, 4); __builtin_memcpy(vb, qb, 4); }
             else { va[0] = qa[0]; vb[0] = qb[0]; }
+            if (MODE == 2) {
+                const uint8_t* qc = pc + (size_t)y * c_stride + c * cs;
+                if (cs == 16) __builtin_memcpy(vc, qc, 16);
+                else if (cs == 8) __builtin_memcpy(vc, qc, 8);
+                else if (cs == 4) __builtin_memcpy(vc, qc, 4);
+                else vc[0] = qc[0];
+#pragma unroll
+                for (int k = 0; k < 4; k++)      // per-byte (x + y + 1) >> 1 = (x | y) - ((x ^ y) >> 1)
+                    vb[k] = (vb[k] | vc[k]) - (((vb[k] ^ vc[k]) >> 1) & 0x7f7f7f7fu);
+            }
             unsigned t = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -67,10 +85,11 @@ __global__ __launch_bounds__(256) void sad_sse_kernel(
 // job (tools/probe/store_probe.hip: grid-stride loops cost 15-40 % of the store bandwidth).
 // POW2: items per row and per block are powers of two (every AV1 block size), so the item -> (block,
 // row, chunk) split is shifts and masks; otherwise 64-bit divisions.
-template <int CS, bool POW2>
+// PixT uint16_t: residual_kernel16bit (EbPictureOperators.c:134-164), CS counts samples.
+template <int CS, bool POW2, typename PixT = uint8_t>
 __global__ __launch_bounds__(256) void residual_kernel(
-    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
-    const uint8_t* __restrict__ pred, uint32_t pred_stride, size_t pred_block_pitch,
+    const PixT* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
+    const PixT* __restrict__ pred, uint32_t pred_stride, size_t pred_block_pitch,
     int16_t* __restrict__ res, uint32_t res_stride, size_t res_block_pitch, uint32_t width,
     uint32_t height, uint32_t nblocks) {
     const uint32_t cpr = width / CS;
@@ -88,11 +107,11 @@ __global__ __launch_bounds__(256) void residual_kernel(
         const uint32_t j = (uint32_t)(i - blk * per);
         y = j / cpr; c = j - y * cpr;
     }
-    const uint8_t* ps_ = src + blk * src_block_pitch + (size_t)y * src_stride + c * CS;
-    const uint8_t* pp = pred + blk * pred_block_pitch + (size_t)y * pred_stride + c * CS;
+    const PixT* ps_ = src + blk * src_block_pitch + (size_t)y * src_stride + c * CS;
+    const PixT* pp = pred + blk * pred_block_pitch + (size_t)y * pred_stride + c * CS;
     int16_t* pr = res + blk * res_block_pitch + (size_t)y * res_stride + c * CS;
-    uint8_t vs[CS], vp[CS];
-    __builtin_memcpy(vs, ps_, CS); __builtin_memcpy(vp, pp, CS);
+    PixT vs[CS], vp[CS];
+    __builtin_memcpy(vs, ps_, CS * sizeof(PixT)); __builtin_memcpy(vp, pp, CS * sizeof(PixT));
     int16_t o[CS];
 #pragma unroll
     for (int k = 0; k < CS; k++) o[k] = (int16_t)((int)vs[k] - (int)vp[k]);
@@ -714,34 +733,56 @@ __global__ __launch_bounds__(256) void sad_search_q16_kernel(
 
 // full_distortion_kernel32_bits / _cbf_zero32_bits (EbPictureOperators.c:283-346):
 // out[blk][0] = sum (c - r)^2 (or sum c^2 when cbf_zero), out[blk][1] = sum c^2.
-// 16 lanes per block, 4 blocks per wave.
+// 16 lanes per block, 4 blocks per wave.  nz != NULL: per-block choice as picture_full_distortion32_bits makes it
+// (:377-395: count_non_zero_coeffs == 0 -> the cbf_zero kernel).  AVX2: the residual term as the reference's AVX2 kernel
+// accumulates it (EbPictureOperators_Intrinsic_AVX2.c:1955-2011): four 64-bit lanes by column mod 4, the square taken from
+// the low 32 bits of the difference, low and high halves of a lane summed separately with 32-bit adds (no carry).
+template <bool AVX2>
 __global__ __launch_bounds__(256) void full_distortion32_kernel(
     const int32_t* __restrict__ coeff, uint32_t coeff_stride, size_t coeff_block_pitch,
     const int32_t* __restrict__ recon, uint32_t recon_stride, size_t recon_block_pitch, uint32_t width,
-    uint32_t height, int cbf_zero, unsigned long long* __restrict__ out, uint32_t nblocks) {
+    uint32_t height, int cbf_zero, const uint32_t* __restrict__ nz, unsigned long long* __restrict__ out,
+    uint32_t nblocks) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 4, l = lane & 15;
     const uint32_t blk = (blockIdx.x * 4 + wave) * 4 + sub;
     const bool valid = blk < nblocks;
     unsigned long long resid = 0, pred = 0;
+    unsigned lo = 0, hi = 0;
+    const bool zero = cbf_zero || (nz && valid && nz[blk] == 0);
     if (valid) {
         const int32_t* pc = coeff + (size_t)blk * coeff_block_pitch;
-        const int32_t* pr = cbf_zero ? nullptr : recon + (size_t)blk * recon_block_pitch;
+        const int32_t* pr = zero ? nullptr : recon + (size_t)blk * recon_block_pitch;
         const uint32_t total = width * height;
         for (uint32_t i = l; i < total; i += 16) {
             const uint32_t y = i / width, x = i - y * width;
             const long long c = pc[(size_t)y * coeff_stride + x];
             pred += (unsigned long long)(c * c);
-            if (!cbf_zero) {
+            if (!zero) {
                 const long long d = c - (long long)pr[(size_t)y * recon_stride + x];
-                resid += (unsigned long long)(d * d);
+                if (AVX2) {
+                    const long long dl = (int)(unsigned)(unsigned long long)d;
+                    const unsigned long long sq = (unsigned long long)(dl * dl);
+                    lo += (unsigned)sq; hi += (unsigned)(sq >> 32);       // width % 4 == 0: all of a lane's x share x & 3 = l & 3
+                } else {
+                    resid += (unsigned long long)(d * d);
+                }
             }
         }
     }
-    resid = group_sum64<16>(resid);
+    if (AVX2) {
+        // lanes l, l ^ 4, l ^ 8, l ^ 12 hold the same column class: wrapping 32-bit sums, then 64-bit over the 4 classes
+        lo += (unsigned)__shfl_xor((int)lo, 4, 64); hi += (unsigned)__shfl_xor((int)hi, 4, 64);
+        lo += (unsigned)__shfl_xor((int)lo, 8, 64); hi += (unsigned)__shfl_xor((int)hi, 8, 64);
+        resid = ((unsigned long long)hi << 32) | lo;
+        resid += __shfl_xor(resid, 1, 64);
+        resid += __shfl_xor(resid, 2, 64);
+    } else {
+        resid = group_sum64<16>(resid);
+    }
     pred = group_sum64<16>(pred);
     if (valid && l == 0) {
-        out[(size_t)blk * 2 + 0] = cbf_zero ? pred : resid;
+        out[(size_t)blk * 2 + 0] = zero ? pred : resid;
         out[(size_t)blk * 2 + 1] = pred;
     }
 }

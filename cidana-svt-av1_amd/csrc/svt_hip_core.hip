@@ -189,3 +189,66 @@ extern "C" int svt_hip_rtcd_override(const svt_hip_rtcd_table* t) {
     return SVT_HIP_OK;
 }
 
+
+// ---- slot registry: reference RTCD global name -> drop-in of the same signature --------------------------------------
+namespace {
+struct Slot { const char* name; void* fn; };
+#define SLOT_FWD(A, B, W, H) {"av1_fwd_txfm2d_" #W "x" #H, (void*)svt_hip_av1_fwd_txfm2d_##W##x##H},
+#define SLOT_INV(A, B, W, H) {"av1_inv_txfm2d_add_" #W "x" #H, (void*)svt_hip_av1_inv_txfm2d_add_##W##x##H},
+#define SLOT_PRED(mode, MODE, W, H)                                                           \
+    {"aom_" #mode "_predictor_" #W "x" #H, (void*)svt_hip_aom_##mode##_predictor_##W##x##H}, \
+    {"aom_highbd_" #mode "_predictor_" #W "x" #H, (void*)svt_hip_aom_highbd_##mode##_predictor_##W##x##H},
+#define SLOT_SAD(W, H) {"aom_sad" #W "x" #H, (void*)svt_hip_aom_sad##W##x##H}, {"aom_sad" #W "x" #H "x4d", (void*)svt_hip_aom_sad##W##x##H##x4d},
+const Slot kSlots[] = {
+    SVT_HIP_BLOCK_SIZES_2(SLOT_FWD, 0, 0)
+    SVT_HIP_BLOCK_SIZES_2(SLOT_INV, 0, 0)
+    {"av1_inv_txfm_add", (void*)svt_hip_av1_inv_txfm_add},
+    {"aom_quantize_b", (void*)svt_hip_aom_quantize_b},
+    {"aom_quantize_b_32x32", (void*)svt_hip_aom_quantize_b_32x32},
+    {"aom_quantize_b_64x64", (void*)svt_hip_aom_quantize_b_64x64},
+    {"aom_highbd_quantize_b", (void*)svt_hip_aom_highbd_quantize_b},
+    {"aom_highbd_quantize_b_32x32", (void*)svt_hip_aom_highbd_quantize_b_32x32},
+    {"aom_highbd_quantize_b_64x64", (void*)svt_hip_aom_highbd_quantize_b_64x64},
+    {"ResidualKernel", (void*)svt_hip_residual_kernel},
+    SVT_HIP_INTRA_MODES(SVT_HIP_BLOCK_SIZES_2, SLOT_PRED)
+    {"eb_smooth_v_predictor", (void*)svt_hip_eb_smooth_v_predictor},
+    {"eb_smooth_h_predictor", (void*)svt_hip_eb_smooth_h_predictor},
+    {"av1_dr_prediction_z1", (void*)svt_hip_av1_dr_prediction_z1},
+    {"av1_dr_prediction_z2", (void*)svt_hip_av1_dr_prediction_z2},
+    {"av1_dr_prediction_z3", (void*)svt_hip_av1_dr_prediction_z3},
+    {"av1_highbd_dr_prediction_z1", (void*)svt_hip_av1_highbd_dr_prediction_z1},
+    {"av1_highbd_dr_prediction_z2", (void*)svt_hip_av1_highbd_dr_prediction_z2},
+    {"av1_highbd_dr_prediction_z3", (void*)svt_hip_av1_highbd_dr_prediction_z3},
+    {"av1_filter_intra_edge", (void*)svt_hip_av1_filter_intra_edge},
+    {"av1_filter_intra_edge_high", (void*)svt_hip_av1_filter_intra_edge_high},
+    {"av1_upsample_intra_edge", (void*)svt_hip_av1_upsample_intra_edge},
+    {"av1_upsample_intra_edge_high", (void*)svt_hip_av1_upsample_intra_edge_high},
+    {"subtract_average", (void*)svt_hip_subtract_average},
+    {"cfl_predict_lbd", (void*)svt_hip_cfl_predict_lbd},
+    {"cfl_predict_hbd", (void*)svt_hip_cfl_predict_hbd},
+    {"av1_txb_init_levels", (void*)svt_hip_av1_txb_init_levels},
+    SVT_HIP_SAD_SIZES(SLOT_SAD)
+};
+#undef SLOT_FWD
+#undef SLOT_INV
+#undef SLOT_PRED
+#undef SLOT_SAD
+constexpr int kNumSlots = (int)(sizeof(kSlots) / sizeof(kSlots[0]));
+}  // namespace
+
+extern "C" int svt_hip_rtcd_slot_count(void) { return kNumSlots; }
+extern "C" const char* svt_hip_rtcd_slot_name(int index) { return index >= 0 && index < kNumSlots ? kSlots[index].name : nullptr; }
+extern "C" void* svt_hip_rtcd_slot_function(const char* name) {
+    if (!name) return nullptr;
+    for (int i = 0; i < kNumSlots; i++)
+        if (!strcmp(kSlots[i].name, name)) return kSlots[i].fn;
+    return nullptr;
+}
+extern "C" int svt_hip_rtcd_override_slot(const char* name, void** slot) {
+    if (!name || !slot) return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    void* fn = svt_hip_rtcd_slot_function(name);
+    if (!fn) return set_err(SVT_HIP_ERR_INVALID, "no drop-in for slot '%s'", name);
+    if (int rc = require_init()) return rc;      // a slot is only handed out when the device is usable: there is no CPU fallback
+    *slot = fn;
+    return SVT_HIP_OK;
+}

@@ -424,3 +424,104 @@ extern "C" void svt_hip_av1_highbd_dr_prediction_z3(uint16_t* dst, ptrdiff_t str
     dropin_intra(SVT_INTRA_Z3, bw, bh, dst, stride, above, left, DR_RANGES_Z3, 0, upsample_left, dx, dy, 1, bd, "svt_hip_av1_highbd_dr_prediction_z3");
 }
 
+
+// ---- per-size RTCD slot entry points (intra_pred_fn / intra_high_pred_fn, EbIntraPrediction.h:36-41): what
+// init_intra_predictors_internal stores in pred[][] / dc_pred[][][] (EbIntraPrediction.c:2842-3350) ----
+#define DEF_PRED(mode, MODE, W, H)                                                                                          \
+    extern "C" void svt_hip_aom_##mode##_predictor_##W##x##H(uint8_t* dst, ptrdiff_t stride, const uint8_t* above,        \
+                                                             const uint8_t* left) {                                       \
+        dropin_intra(MODE, W, H, dst, stride, above, left, -1, W, 0, H, 0, 0, 1, 1, 0, 8, "svt_hip_aom_" #mode "_predictor_" #W "x" #H); \
+    }                                                                                                                     \
+    extern "C" void svt_hip_aom_highbd_##mode##_predictor_##W##x##H(uint16_t* dst, ptrdiff_t stride, const uint16_t* above, \
+                                                                    const uint16_t* left, int bd) {                       \
+        dropin_intra(MODE, W, H, dst, stride, above, left, -1, W, 0, H, 0, 0, 1, 1, 1, bd, "svt_hip_aom_highbd_" #mode "_predictor_" #W "x" #H); \
+    }
+SVT_HIP_INTRA_MODES(SVT_HIP_BLOCK_SIZES_2, DEF_PRED)
+#undef DEF_PRED
+extern "C" void svt_hip_eb_smooth_v_predictor(uint8_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t* above,
+                                              const uint8_t* left) {
+    dropin_intra(SVT_INTRA_SMOOTH_V, bw, bh, dst, stride, above, left, -1, bw, 0, bh, 0, 0, 1, 1, 0, 8, "svt_hip_eb_smooth_v_predictor");
+}
+extern "C" void svt_hip_eb_smooth_h_predictor(uint8_t* dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t* above,
+                                              const uint8_t* left) {
+    dropin_intra(SVT_INTRA_SMOOTH_H, bw, bh, dst, stride, above, left, -1, bw, 0, bh, 0, 0, 1, 1, 0, 8, "svt_hip_eb_smooth_h_predictor");
+}
+
+// ---- av1_filter_intra_edge{,_high}, av1_upsample_intra_edge{,_high} (aom_dsp_rtcd.h:152-156, 431-437) ----
+static void dropin_edge(int upsample, void* p, int sz, int strength_or_bd, int is16, const char* fn) {
+    const size_t es = is16 ? 2 : 1;
+    const int pitch = NB_ORIGIN + 2 * sz + 16;
+    DROPIN_TRY(t_ctx.ensure((size_t)pitch * es), fn);
+    char* d = t_ctx.dbuf;
+    // filter: p[0 .. sz-1] in and out; upsample: p[-1 .. sz-1] in, p[-2 .. 2*sz-2] out (EbIntraPrediction.c:3597-3660)
+    const int in_lo = upsample ? -1 : 0, in_n = upsample ? sz + 1 : sz, out_lo = upsample ? -2 : 0, out_n = upsample ? 2 * sz + 1 : sz;
+    HIP_DIE(hipMemcpyAsync(d + (size_t)(NB_ORIGIN + in_lo) * es, (const char*)p + (ptrdiff_t)in_lo * (ptrdiff_t)es, (size_t)in_n * es,
+                           hipMemcpyHostToDevice, t_ctx.stream), fn);
+    if (upsample) DROPIN_TRY(svt_hip_upsample_intra_edge_batch(d, pitch, sz, is16, strength_or_bd, 1, t_ctx.stream), fn);
+    else DROPIN_TRY(svt_hip_filter_intra_edge_batch(d, pitch, sz, strength_or_bd, is16, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync((char*)p + (ptrdiff_t)out_lo * (ptrdiff_t)es, d + (size_t)(NB_ORIGIN + out_lo) * es, (size_t)out_n * es,
+                           hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+extern "C" void svt_hip_av1_filter_intra_edge(uint8_t* p, int32_t sz, int32_t strength) {
+    if (strength) dropin_edge(0, p, sz, strength, 0, "svt_hip_av1_filter_intra_edge");
+}
+extern "C" void svt_hip_av1_filter_intra_edge_high(uint16_t* p, int32_t sz, int32_t strength) {
+    if (strength) dropin_edge(0, p, sz, strength, 1, "svt_hip_av1_filter_intra_edge_high");
+}
+extern "C" void svt_hip_av1_upsample_intra_edge(uint8_t* p, int32_t sz) { dropin_edge(1, p, sz, 8, 0, "svt_hip_av1_upsample_intra_edge"); }
+extern "C" void svt_hip_av1_upsample_intra_edge_high(uint16_t* p, int32_t sz, int32_t bd) {
+    dropin_edge(1, p, sz, bd, 1, "svt_hip_av1_upsample_intra_edge_high");
+}
+
+// ---- subtract_average, cfl_predict_lbd / _hbd, av1_txb_init_levels (aom_dsp_rtcd.h:140-148, 2376) ----
+extern "C" void svt_hip_subtract_average(int16_t* pred_buf_q3, int32_t width, int32_t height, int32_t round_offset,
+                                         int32_t num_pel_log2) {
+    const char* fn = "svt_hip_subtract_average";
+    const size_t bytes = (size_t)32 * height * 2;                     // CFL_BUF_LINE = 32 int16 per row
+    DROPIN_TRY(t_ctx.ensure(bytes), fn);
+    HIP_DIE(hipMemcpyAsync(t_ctx.dbuf, pred_buf_q3, bytes, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_subtract_average_batch((int16_t*)t_ctx.dbuf, 32, (size_t)32 * height, (uint32_t)width, (uint32_t)height, round_offset, num_pel_log2, 1,
+                                              t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(pred_buf_q3, t_ctx.dbuf, bytes, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+static void dropin_cfl_predict(const int16_t* q3, const void* pred, int32_t pred_stride, void* dst, int32_t dst_stride,
+                               int32_t alpha_q3, int32_t bit_depth, int32_t width, int32_t height, int is16, const char* fn) {
+    const size_t es = is16 ? 2 : 1;
+    const size_t qb = align256((size_t)32 * height * 2), pb = align256((size_t)width * height * es);
+    DROPIN_TRY(t_ctx.ensure(qb + 2 * pb + 256), fn);
+    char* d_q = t_ctx.dbuf;
+    char* d_p = d_q + qb;
+    char* d_d = d_p + pb;
+    int32_t* d_alpha = (int32_t*)(d_d + pb);
+    HIP_DIE(hipMemcpyAsync(d_q, q3, (size_t)32 * height * 2, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpy2DAsync(d_p, (size_t)width * es, pred, (size_t)pred_stride * es, (size_t)width * es, height, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(d_alpha, &alpha_q3, 4, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_cfl_predict_batch((const int16_t*)d_q, 32, (size_t)32 * height, d_p, (uint32_t)width, d_d, (uint32_t)width, nullptr, d_alpha, bit_depth,
+                                         (uint32_t)width, (uint32_t)height, is16, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpy2DAsync(dst, (size_t)dst_stride * es, d_d, (size_t)width * es, (size_t)width * es, height, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+extern "C" void svt_hip_cfl_predict_lbd(const int16_t* pred_buf_q3, uint8_t* pred, int32_t pred_stride, uint8_t* dst,
+                                        int32_t dst_stride, int32_t alpha_q3, int32_t bit_depth, int32_t width, int32_t height) {
+    dropin_cfl_predict(pred_buf_q3, pred, pred_stride, dst, dst_stride, alpha_q3, bit_depth, width, height, 0, "svt_hip_cfl_predict_lbd");
+}
+extern "C" void svt_hip_cfl_predict_hbd(const int16_t* pred_buf_q3, uint16_t* pred, int32_t pred_stride, uint16_t* dst,
+                                        int32_t dst_stride, int32_t alpha_q3, int32_t bit_depth, int32_t width, int32_t height) {
+    dropin_cfl_predict(pred_buf_q3, pred, pred_stride, dst, dst_stride, alpha_q3, bit_depth, width, height, 1, "svt_hip_cfl_predict_hbd");
+}
+extern "C" void svt_hip_av1_txb_init_levels(const svt_tran_low_t* const coeff, const int32_t width, const int32_t height,
+                                            uint8_t* const levels) {
+    const char* fn = "svt_hip_av1_txb_init_levels";
+    // `levels` points TX_PAD_TOP rows into the padded buffer (EbRateDistortionCost.c:125-150): whole buffer = (w+4)*(h+6)+16
+    const int stride = width + 4;
+    const size_t cb = align256((size_t)width * height * 4), lb = (size_t)stride * (height + 6) + 16;
+    const size_t lpitch = (lb + 3) & ~(size_t)3;
+    DROPIN_TRY(t_ctx.ensure(cb + lpitch), fn);
+    HIP_DIE(hipMemcpyAsync(t_ctx.dbuf, coeff, (size_t)width * height * 4, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_txb_init_levels_batch((const int32_t*)t_ctx.dbuf, (size_t)width * height, (uint8_t*)t_ctx.dbuf + cb, lpitch, (uint32_t)width, (uint32_t)height, 1,
+                                             t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(levels - 2 * stride, t_ctx.dbuf + cb, lb, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}

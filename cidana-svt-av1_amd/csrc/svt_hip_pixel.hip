@@ -7,54 +7,95 @@
 using namespace svtdev;
 using namespace svthost;
 
-static int sad_sse_common(bool sse, const uint8_t* a, uint32_t as, size_t ap, const uint8_t* b, uint32_t bs,
-                          size_t bp, uint32_t w, uint32_t h, void* out, size_t n, void* stream) {
+// mode 0 SAD, 1 SSE, 2 averaging SAD (kernel_pixel.h); a_shift = 2: four references per source block (x4d)
+static int sad_sse_common(int mode, const uint8_t* a, uint32_t as, size_t ap, const uint32_t* a_offs, int a_shift,
+                          const uint8_t* b, uint32_t bs, size_t bp, const uint32_t* b_offs, const uint8_t* c, uint32_t cst,
+                          size_t cp, uint32_t w, uint32_t h, void* out, size_t n, void* stream) {
     if (int rc = require_init()) return rc;
     if (n == 0) return SVT_HIP_OK;
-    if (!a || !b || !out) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (!a || !b || !out || (mode == 2 && !c)) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
     if (w == 0 || h == 0 || w > 128 || h > 128) return set_err(SVT_HIP_ERR_INVALID, "block %ux%u", w, h);
-    if (n == 0) return SVT_HIP_OK;
     const uint32_t grid = (uint32_t)((n + 15) / 16);
-    if (sse)
-        hipLaunchKernelGGL((sad_sse_kernel<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, as, ap, b, bs, bp, w, h, out, (uint32_t)n);
-    else
-        hipLaunchKernelGGL((sad_sse_kernel<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, as, ap, b, bs, bp, w, h, out, (uint32_t)n);
-    return launch_status(sse ? "sse" : "sad");
+#define SADL(M) hipLaunchKernelGGL((sad_sse_kernel<M>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a, as, ap, a_offs, a_shift, b, bs, bp, \
+                                   b_offs, c, cst, cp, w, h, out, (uint32_t)n)
+    if (mode == 1) SADL(1); else if (mode == 2) SADL(2); else SADL(0);
+#undef SADL
+    return launch_status(mode == 1 ? "sse" : (mode == 2 ? "sad_avg" : "sad"));
 }
 extern "C" int svt_hip_sad_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
                                  const uint8_t* d_ref, uint32_t ref_stride, size_t ref_block_pitch, uint32_t width,
                                  uint32_t height, uint32_t* d_out, size_t nblocks, void* stream) {
-    return sad_sse_common(false, d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, width, height, d_out, nblocks, stream);
+    return sad_sse_common(0, d_src, src_stride, src_block_pitch, nullptr, 0, d_ref, ref_stride, ref_block_pitch, nullptr, nullptr, 0, 0,
+                          width, height, d_out, nblocks, stream);
 }
 extern "C" int svt_hip_sse_batch(const uint8_t* d_a, uint32_t a_stride, size_t a_block_pitch, const uint8_t* d_b,
                                  uint32_t b_stride, size_t b_block_pitch, uint32_t width, uint32_t height,
                                  uint64_t* d_out, size_t nblocks, void* stream) {
-    return sad_sse_common(true, d_a, a_stride, a_block_pitch, d_b, b_stride, b_block_pitch, width, height, d_out, nblocks, stream);
+    return sad_sse_common(1, d_a, a_stride, a_block_pitch, nullptr, 0, d_b, b_stride, b_block_pitch, nullptr, nullptr, 0, 0, width, height,
+                          d_out, nblocks, stream);
 }
-extern "C" int svt_hip_residual_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
-                                      const uint8_t* d_pred, uint32_t pred_stride, size_t pred_block_pitch,
-                                      int16_t* d_res, uint32_t res_stride, size_t res_block_pitch, uint32_t width,
-                                      uint32_t height, size_t nblocks, void* stream) {
+extern "C" int svt_hip_sad_planes_batch(const uint8_t* d_src_plane, uint32_t src_stride, const uint32_t* d_src_offsets,
+                                        const uint8_t* d_ref_plane, uint32_t ref_stride, const uint32_t* d_ref_offsets,
+                                        uint32_t width, uint32_t height, uint32_t* d_out, size_t nblocks, void* stream) {
+    if (nblocks && (!d_src_offsets || !d_ref_offsets)) { if (int rc = require_init()) return rc; return set_err(SVT_HIP_ERR_INVALID, "NULL offset table"); }
+    return sad_sse_common(0, d_src_plane, src_stride, 0, d_src_offsets, 0, d_ref_plane, ref_stride, 0, d_ref_offsets, nullptr, 0, 0, width,
+                          height, d_out, nblocks, stream);
+}
+extern "C" int svt_hip_sad_x4d_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                     const uint32_t* d_src_offsets, const uint8_t* d_ref_plane, uint32_t ref_stride,
+                                     const uint32_t* d_ref_offsets, uint32_t width, uint32_t height, uint32_t* d_out,
+                                     size_t nblocks, void* stream) {
+    if (nblocks && !d_ref_offsets) { if (int rc = require_init()) return rc; return set_err(SVT_HIP_ERR_INVALID, "NULL offset table"); }
+    if (nblocks > 0x3fffffffu) { if (int rc = require_init()) return rc; return set_err(SVT_HIP_ERR_INVALID, "too many blocks"); }
+    return sad_sse_common(0, d_src, src_stride, src_block_pitch, d_src_offsets, 2, d_ref_plane, ref_stride, 0, d_ref_offsets, nullptr, 0, 0,
+                          width, height, d_out, nblocks * 4, stream);
+}
+extern "C" int svt_hip_sad_avg_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch, const uint8_t* d_ref1,
+                                     uint32_t ref1_stride, size_t ref1_block_pitch, const uint8_t* d_ref2,
+                                     uint32_t ref2_stride, size_t ref2_block_pitch, uint32_t width, uint32_t height,
+                                     uint32_t* d_out, size_t nblocks, void* stream) {
+    return sad_sse_common(2, d_src, src_stride, src_block_pitch, nullptr, 0, d_ref1, ref1_stride, ref1_block_pitch, nullptr, d_ref2,
+                          ref2_stride, ref2_block_pitch, width, height, d_out, nblocks, stream);
+}
+template <typename PixT>
+static int residual_impl(const PixT* d_src, uint32_t src_stride, size_t src_block_pitch, const PixT* d_pred, uint32_t pred_stride,
+                         size_t pred_block_pitch, int16_t* d_res, uint32_t res_stride, size_t res_block_pitch, uint32_t width,
+                         uint32_t height, size_t nblocks, void* stream) {
     if (int rc = require_init()) return rc;
     if (nblocks == 0) return SVT_HIP_OK;
     if (!d_src || !d_pred || !d_res) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
     if (width == 0 || height == 0) return set_err(SVT_HIP_ERR_INVALID, "empty block");
-    if (nblocks == 0) return SVT_HIP_OK;
-    const uint32_t rcs = (width & 15) == 0 ? 16u : ((width & 7) == 0 ? 8u : ((width & 3) == 0 ? 4u : 1u));
+    // samples per lane: 16 bytes of input where the width allows it
+    constexpr uint32_t MAXCS = 16 / sizeof(PixT);
+    const uint32_t rcs = (width % MAXCS) == 0 ? MAXCS : ((width & 7) == 0 ? 8u : ((width & 3) == 0 ? 4u : 1u));
     const size_t total = (size_t)(width / rcs) * height * nblocks;
     const size_t grid = (total + 255) / 256;
     if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
     const uint32_t cpr = width / rcs;
     const size_t per = (size_t)cpr * height;
     const bool pow2 = (cpr & (cpr - 1)) == 0 && (per & (per - 1)) == 0;
-#define RESL(CS, P2) hipLaunchKernelGGL((residual_kernel<CS, P2>), dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_src, src_stride, \
+#define RESL(CS, P2) hipLaunchKernelGGL((residual_kernel<CS, P2, PixT>), dim3((uint32_t)grid), dim3(256), 0, (hipStream_t)stream, d_src, src_stride, \
                        src_block_pitch, d_pred, pred_stride, pred_block_pitch, d_res, res_stride, res_block_pitch,   \
                        width, height, (uint32_t)nblocks)
 #define RESC(CS) if (pow2) RESL(CS, true); else RESL(CS, false)
-    if (rcs == 16) { RESC(16); } else if (rcs == 8) { RESC(8); } else if (rcs == 4) { RESC(4); } else { RESC(1); }
+    if (rcs == 16) { if constexpr (MAXCS == 16) { RESC(16); } } else if (rcs == 8) { RESC(8); } else if (rcs == 4) { RESC(4); } else { RESC(1); }
 #undef RESC
 #undef RESL
     return launch_status("residual");
+}
+extern "C" int svt_hip_residual_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                      const uint8_t* d_pred, uint32_t pred_stride, size_t pred_block_pitch,
+                                      int16_t* d_res, uint32_t res_stride, size_t res_block_pitch, uint32_t width,
+                                      uint32_t height, size_t nblocks, void* stream) {
+    return residual_impl<uint8_t>(d_src, src_stride, src_block_pitch, d_pred, pred_stride, pred_block_pitch, d_res, res_stride,
+                                  res_block_pitch, width, height, nblocks, stream);
+}
+extern "C" int svt_hip_residual16_batch(const uint16_t* d_src, uint32_t src_stride, size_t src_block_pitch,
+                                        const uint16_t* d_pred, uint32_t pred_stride, size_t pred_block_pitch,
+                                        int16_t* d_res, uint32_t res_stride, size_t res_block_pitch, uint32_t width,
+                                        uint32_t height, size_t nblocks, void* stream) {
+    return residual_impl<uint16_t>(d_src, src_stride, src_block_pitch, d_pred, pred_stride, pred_block_pitch, d_res, res_stride,
+                                   res_block_pitch, width, height, nblocks, stream);
 }
 
 static int sad_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch, const uint32_t* d_src_offs,
@@ -290,18 +331,41 @@ extern "C" int svt_hip_me_fullpel_search_batch(const uint8_t* d_src, uint32_t sr
     return launch_status("me_fullpel_exact");
 }
 
-extern "C" int svt_hip_full_distortion32_batch(const int32_t* d_coeff, uint32_t coeff_stride, size_t coeff_block_pitch,
-                                               const int32_t* d_recon, uint32_t recon_stride, size_t recon_block_pitch,
-                                               uint32_t width, uint32_t height, int cbf_zero, uint64_t* d_out,
-                                               size_t nblocks, void* stream) {
+static int full_distortion32_impl(const int32_t* d_coeff, uint32_t coeff_stride, size_t coeff_block_pitch, const int32_t* d_recon,
+                                  uint32_t recon_stride, size_t recon_block_pitch, uint32_t width, uint32_t height,
+                                  int cbf_zero, const uint32_t* d_nz, int flavour, uint64_t* d_out, size_t nblocks, void* stream) {
     if (int rc = require_init()) return rc;
     if (nblocks == 0) return SVT_HIP_OK;
     if (!d_coeff || !d_out || (!cbf_zero && !d_recon)) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
     if (width == 0 || height == 0 || width > 128 || height > 128) return set_err(SVT_HIP_ERR_INVALID, "area %ux%u", width, height);
-    hipLaunchKernelGGL(full_distortion32_kernel, dim3((uint32_t)((nblocks + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
-                       d_coeff, coeff_stride, coeff_block_pitch, d_recon, recon_stride, recon_block_pitch, width, height,
-                       cbf_zero, (unsigned long long*)d_out, (uint32_t)nblocks);
+    if (flavour != SVT_HIP_FLAVOUR_C && flavour != SVT_HIP_FLAVOUR_AVX2) return set_err(SVT_HIP_ERR_INVALID, "flavour %d", flavour);
+    if (flavour == SVT_HIP_FLAVOUR_AVX2 && (width & 3)) return set_err(SVT_HIP_ERR_INVALID, "the AVX2 kernel is defined for widths that are a multiple of 4");
+    const dim3 grid((uint32_t)((nblocks + 15) / 16));
+    if (flavour == SVT_HIP_FLAVOUR_AVX2)
+        hipLaunchKernelGGL(full_distortion32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, d_coeff, coeff_stride, coeff_block_pitch,
+                           d_recon, recon_stride, recon_block_pitch, width, height, cbf_zero, d_nz, (unsigned long long*)d_out, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL(full_distortion32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, d_coeff, coeff_stride, coeff_block_pitch,
+                           d_recon, recon_stride, recon_block_pitch, width, height, cbf_zero, d_nz, (unsigned long long*)d_out, (uint32_t)nblocks);
     return launch_status("full_distortion32");
+}
+extern "C" int svt_hip_full_distortion32_batch(const int32_t* d_coeff, uint32_t coeff_stride, size_t coeff_block_pitch,
+                                               const int32_t* d_recon, uint32_t recon_stride, size_t recon_block_pitch,
+                                               uint32_t width, uint32_t height, int cbf_zero, uint64_t* d_out,
+                                               size_t nblocks, void* stream) {
+    return full_distortion32_impl(d_coeff, coeff_stride, coeff_block_pitch, d_recon, recon_stride, recon_block_pitch, width, height,
+                                  cbf_zero, nullptr, SVT_HIP_FLAVOUR_C, d_out, nblocks, stream);
+}
+extern "C" int svt_hip_picture_full_distortion32_batch(const int32_t* d_coeff, size_t coeff_block_pitch, const int32_t* d_recon,
+                                                       size_t recon_block_pitch, uint32_t bwidth, uint32_t bheight,
+                                                       const uint32_t* d_count_non_zero_coeffs, int flavour, uint64_t* d_out,
+                                                       size_t nblocks, void* stream) {
+    // picture_full_distortion32_bits (EbPictureOperators.c:349-457): a 64-sample dimension covers 32 coefficients, the row
+    // stride of both buffers is the (clamped) width, count_non_zero_coeffs == 0 selects the cbf_zero kernel per block
+    const uint32_t w = bwidth < 64 ? bwidth : 32, h = bheight < 64 ? bheight : 32;
+    if (nblocks && !d_recon) { if (int rc = require_init()) return rc; return set_err(SVT_HIP_ERR_INVALID, "NULL buffer"); }
+    return full_distortion32_impl(d_coeff, w, coeff_block_pitch, d_recon, w, recon_block_pitch, w, h, 0, d_count_non_zero_coeffs, flavour,
+                                  d_out, nblocks, stream);
 }
 
 // copies a w x h u8 block with `stride` into dense device memory
@@ -413,3 +477,69 @@ extern "C" void svt_hip_full_distortion_kernel_cbf_zero32_bits(int32_t* coeff, u
                   "svt_hip_full_distortion_kernel_cbf_zero32_bits");
 }
 
+
+// combined_averaging_sad (EB_SADAVGKERNELNxM_TYPE, EbComputeSAD.h:49-57; NxMSadAveragingKernel_funcPtrArray)
+extern "C" uint32_t svt_hip_combined_averaging_sad(uint8_t* src, uint32_t src_stride, uint8_t* ref1, uint32_t ref1_stride,
+                                                   uint8_t* ref2, uint32_t ref2_stride, uint32_t height, uint32_t width) {
+    const char* fn = "svt_hip_combined_averaging_sad";
+    const size_t bb = align256((size_t)width * height);
+    DROPIN_TRY(t_ctx.ensure(3 * bb + 256), fn);
+    uint8_t* d_a = (uint8_t*)t_ctx.dbuf;
+    uint8_t* d_b = d_a + bb;
+    uint8_t* d_c = d_a + 2 * bb;
+    uint32_t* d_o = (uint32_t*)(d_a + 3 * bb);
+    h2d_block(d_a, src, src_stride, width, height, fn);
+    h2d_block(d_b, ref1, ref1_stride, width, height, fn);
+    h2d_block(d_c, ref2, ref2_stride, width, height, fn);
+    DROPIN_TRY(svt_hip_sad_avg_batch(d_a, width, 0, d_b, width, 0, d_c, width, 0, width, height, d_o, 1, t_ctx.stream), fn);
+    uint32_t out = 0;
+    HIP_DIE(hipMemcpyAsync(&out, d_o, 4, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+    return out;
+}
+
+// aom_sadMxN / aom_sadMxNx4d (aom_dsp_rtcd.h:1328-1500; C: C_DEFAULT/EbComputeSAD_C.c:140-233)
+static void dropin_sad_x4d(int w, int h, const uint8_t* src, int src_stride, const uint8_t* const ref[4], int ref_stride,
+                           uint32_t* sad_array, const char* fn) {
+    const size_t bb = align256((size_t)w * h);
+    DROPIN_TRY(t_ctx.ensure(5 * bb + 256), fn);
+    uint8_t* d = (uint8_t*)t_ctx.dbuf;
+    uint32_t* d_o = (uint32_t*)(d + 5 * bb);
+    h2d_block(d, src, (uint32_t)src_stride, w, h, fn);
+    for (int i = 0; i < 4; i++) h2d_block(d + (size_t)(1 + i) * bb, ref[i], (uint32_t)ref_stride, w, h, fn);
+    // four dense reference blocks bb bytes apart against one source block (a_shift = 2 through the x4d entry point)
+    const uint32_t offs[4] = {0, (uint32_t)bb, (uint32_t)(2 * bb), (uint32_t)(3 * bb)};
+    uint32_t* d_offs = d_o + 4;
+    HIP_DIE(hipMemcpyAsync(d_offs, offs, sizeof(offs), hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_sad_x4d_batch(d, w, 0, nullptr, d + bb, w, d_offs, w, h, d_o, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpyAsync(sad_array, d_o, 16, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}
+#define DEF_SAD(W, H)                                                                                                          \
+    extern "C" unsigned int svt_hip_aom_sad##W##x##H(const uint8_t* src_ptr, int src_stride, const uint8_t* ref_ptr, int ref_stride) { \
+        return svt_hip_nxm_sad_kernel(src_ptr, (uint32_t)src_stride, ref_ptr, (uint32_t)ref_stride, H, W);                     \
+    }                                                                                                                          \
+    extern "C" void svt_hip_aom_sad##W##x##H##x4d(const uint8_t* src_ptr, int src_stride, const uint8_t* const ref_ptr[],     \
+                                                  int ref_stride, uint32_t* sad_array) {                                      \
+        dropin_sad_x4d(W, H, src_ptr, src_stride, ref_ptr, ref_stride, sad_array, "svt_hip_aom_sad" #W "x" #H "x4d");          \
+    }
+SVT_HIP_SAD_SIZES(DEF_SAD)
+#undef DEF_SAD
+
+// residual_kernel16bit (EbPictureOperators.c:134-164)
+extern "C" void svt_hip_residual_kernel16bit(uint16_t* input, uint32_t input_stride, uint16_t* pred, uint32_t pred_stride,
+                                             int16_t* residual, uint32_t residual_stride, uint32_t area_width,
+                                             uint32_t area_height) {
+    const char* fn = "svt_hip_residual_kernel16bit";
+    const size_t bb = align256((size_t)area_width * area_height * 2);
+    DROPIN_TRY(t_ctx.ensure(3 * bb), fn);
+    uint16_t* d_a = (uint16_t*)t_ctx.dbuf;
+    uint16_t* d_b = (uint16_t*)(t_ctx.dbuf + bb);
+    int16_t* d_r = (int16_t*)(t_ctx.dbuf + 2 * bb);
+    const size_t rowb = (size_t)area_width * 2;
+    HIP_DIE(hipMemcpy2DAsync(d_a, rowb, input, (size_t)input_stride * 2, rowb, area_height, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpy2DAsync(d_b, rowb, pred, (size_t)pred_stride * 2, rowb, area_height, hipMemcpyHostToDevice, t_ctx.stream), fn);
+    DROPIN_TRY(svt_hip_residual16_batch(d_a, area_width, 0, d_b, area_width, 0, d_r, area_width, 0, area_width, area_height, 1, t_ctx.stream), fn);
+    HIP_DIE(hipMemcpy2DAsync(residual, (size_t)residual_stride * 2, d_r, rowb, rowb, area_height, hipMemcpyDeviceToHost, t_ctx.stream), fn);
+    HIP_DIE(hipStreamSynchronize(t_ctx.stream), fn);
+}

@@ -94,6 +94,20 @@ int svt_hip_memcpy_h2d(void *dptr, const void *hptr, size_t bytes, void *stream)
 int svt_hip_memcpy_d2h(void *hptr, const void *dptr, size_t bytes, void *stream);
 int svt_hip_stream_sync(void *stream);
 
+/* ---- host-side tables for callers outside the encoder (csrc/host_tables.cpp; no device involved) ------------------
+ * y-plane quantiser rows of av1_build_quantizer(bit_depth, 0, 0, 0, 0, 0) (EbModeDecisionConfigurationProcess.c:429-520):
+ * five int16 [256][8] tables indexed [qindex][0 = DC, 1..7 = AC], the rows the quantiser entry points take. */
+int svt_hip_build_quantizer(int bit_depth, int16_t (*zbin)[8], int16_t (*round)[8], int16_t (*quant)[8],
+                            int16_t (*quant_shift)[8], int16_t (*dequant)[8]);
+/* av1_scan_orders[tx_size][tx_type] (EbTransforms.h:3349-3870): scan / iscan over the kept min(W,32) x min(H,32)
+ * coefficients (either pointer may be NULL); returns their number (<= 1024) or SVT_HIP_ERR_INVALID. */
+int svt_hip_get_scan(int tx_size, int tx_type, int16_t *scan, int16_t *iscan);
+/* the candidate list open_loop_intra_search_sb enumerates for one block size (EbMotionEstimation.c:8747-8846): modes in AV1
+ * PredictionMode numbering, angle deltas -2..2; arrays of SVT_HIP_OIS_MAX_CANDIDATES; returns the count. */
+#define SVT_HIP_OIS_MAX_CANDIDATES 61
+int svt_hip_ois_candidates(uint32_t bsize, int temporal_layer_index, int intra_pred_mode, int is_used_as_reference,
+                           int is_16bit, uint8_t *modes, int8_t *angle_deltas);
+
 /* ============================================================================
  * (B) batched API — device pointers, `stream` is a hipStream_t (NULL = default)
  * Every call only enqueues work; it returns before the GPU finishes.
@@ -231,6 +245,29 @@ int svt_hip_residual_batch(const uint8_t *d_src, uint32_t src_stride, size_t src
                            int16_t *d_res, uint32_t res_stride, size_t res_block_pitch,
                            uint32_t width, uint32_t height, size_t nblocks, void *stream);
 
+/* residual_kernel16bit (EbPictureOperators.c:134-164): the same on 16-bit samples (Av1EncodeLoop16bit, EbCodingLoop.c:1085) */
+int svt_hip_residual16_batch(const uint16_t *d_src, uint32_t src_stride, size_t src_block_pitch,
+                             const uint16_t *d_pred, uint32_t pred_stride, size_t pred_block_pitch,
+                             int16_t *d_res, uint32_t res_stride, size_t res_block_pitch,
+                             uint32_t width, uint32_t height, size_t nblocks, void *stream);
+/* K4 on picture planes (block b at plane + d_*_offsets[b], byte offsets) */
+int svt_hip_sad_planes_batch(const uint8_t *d_src_plane, uint32_t src_stride, const uint32_t *d_src_offsets,
+                             const uint8_t *d_ref_plane, uint32_t ref_stride, const uint32_t *d_ref_offsets,
+                             uint32_t width, uint32_t height, uint32_t *d_out, size_t nblocks, void *stream);
+/* aom_sadMxNx4d (aom_dsp_rtcd.h:1328-1500; C: C_DEFAULT/EbComputeSAD_C.c:151-160): per source block, SADs against FOUR
+ * reference positions, d_ref_plane + d_ref_offsets[4*b + i]; d_out uint32 [nblocks][4].  Source blocks dense
+ * (d_src_offsets == NULL: b * src_block_pitch) or at d_src + d_src_offsets[b]. */
+int svt_hip_sad_x4d_batch(const uint8_t *d_src, uint32_t src_stride, size_t src_block_pitch,
+                          const uint32_t *d_src_offsets, const uint8_t *d_ref_plane, uint32_t ref_stride,
+                          const uint32_t *d_ref_offsets, uint32_t width, uint32_t height, uint32_t *d_out,
+                          size_t nblocks, void *stream);
+/* combined_averaging_sad (NxMSadAveragingKernel_funcPtrArray, EbComputeSAD.h:162-197; C: C_DEFAULT/EbComputeSAD_C.c:13-40;
+ * called by BiPredictionSearch, EbMotionEstimation.c:6639): SAD(src, (ref1 + ref2 + 1) >> 1) */
+int svt_hip_sad_avg_batch(const uint8_t *d_src, uint32_t src_stride, size_t src_block_pitch, const uint8_t *d_ref1,
+                          uint32_t ref1_stride, size_t ref1_block_pitch, const uint8_t *d_ref2,
+                          uint32_t ref2_stride, size_t ref2_block_pitch, uint32_t width, uint32_t height,
+                          uint32_t *d_out, size_t nblocks, void *stream);
+
 /* K5 SAD search (NxMSadLoopKernel_funcPtrArray, EbComputeSAD.h:199; C:
  * sad_loop_kernel, EbComputeSAD_C.c:72-120).  Per block b: source block at
  * d_src + b*src_block_pitch, reference window origin at d_ref + b*ref_block_pitch.
@@ -320,6 +357,17 @@ int svt_hip_full_distortion32_batch(const int32_t *d_coeff, uint32_t coeff_strid
                                     uint32_t recon_stride, size_t recon_block_pitch,
                                     uint32_t width, uint32_t height, int cbf_zero,
                                     uint64_t *d_out, size_t nblocks, void *stream);
+
+/* picture_full_distortion32_bits (EbPictureOperators.c:349-457), luma leg, for nblocks transform blocks: a 64-sample
+ * dimension covers 32 coefficients, both buffers are dense with the (clamped) width as row stride and lie *_block_pitch
+ * int32 apart, d_count_non_zero_coeffs[b] == 0 selects the cbf_zero kernel for block b (NULL: never).  flavour
+ * SVT_HIP_FLAVOUR_AVX2 reproduces full_distortion_kernel32_bits_avx2's residual sum, which adds the low and high halves
+ * of its 64-bit lanes separately (_mm256_add_epi32, EbPictureOperators_Intrinsic_AVX2.c:1989): it differs from the C
+ * kernel once a lane's low halves sum past 2^32 (tests/golden/pins.npz holds both). */
+int svt_hip_picture_full_distortion32_batch(const int32_t *d_coeff, size_t coeff_block_pitch, const int32_t *d_recon,
+                                            size_t recon_block_pitch, uint32_t bwidth, uint32_t bheight,
+                                            const uint32_t *d_count_non_zero_coeffs, int flavour, uint64_t *d_out,
+                                            size_t nblocks, void *stream);
 
 /* Open-loop intra search: open_loop_intra_search_sb, EbMotionEstimation.c:8694-8850,
  * for all blocks of ONE size of a picture (or of many pictures' worth of blocks) in one call.
@@ -511,6 +559,81 @@ void svt_hip_av1_highbd_dr_prediction_z2(uint16_t *dst, ptrdiff_t stride, int32_
 void svt_hip_av1_highbd_dr_prediction_z3(uint16_t *dst, ptrdiff_t stride, int32_t bw, int32_t bh,
                                          const uint16_t *above, const uint16_t *left, int32_t upsample_left,
                                          int32_t dx, int32_t dy, int32_t bd);
+
+/* ---- per-size RTCD slot entry points ------------------------------------------------------------------------------
+ * X-macro lists of the reference's slot families (a host can use them too). */
+#define SVT_HIP_BLOCK_SIZES_2(X, A, B) \
+    X(A, B, 4, 4) X(A, B, 8, 8) X(A, B, 16, 16) X(A, B, 32, 32) X(A, B, 64, 64) X(A, B, 4, 8) X(A, B, 8, 4) X(A, B, 8, 16) \
+    X(A, B, 16, 8) X(A, B, 16, 32) X(A, B, 32, 16) X(A, B, 32, 64) X(A, B, 64, 32) X(A, B, 4, 16) X(A, B, 16, 4) \
+    X(A, B, 8, 32) X(A, B, 32, 8) X(A, B, 16, 64) X(A, B, 64, 16)
+/* SIZES(X, mode, MODE) applied to every non-directional mode: aom_<mode>_predictor_WxH <-> SVT_INTRA_* */
+#define SVT_HIP_INTRA_MODES(SIZES, X) \
+    SIZES(X, dc, SVT_INTRA_DC) SIZES(X, dc_top, SVT_INTRA_DC_TOP) SIZES(X, dc_left, SVT_INTRA_DC_LEFT) \
+    SIZES(X, dc_128, SVT_INTRA_DC_128) SIZES(X, v, SVT_INTRA_V) SIZES(X, h, SVT_INTRA_H) SIZES(X, smooth, SVT_INTRA_SMOOTH) \
+    SIZES(X, smooth_v, SVT_INTRA_SMOOTH_V) SIZES(X, smooth_h, SVT_INTRA_SMOOTH_H) SIZES(X, paeth, SVT_INTRA_PAETH)
+/* the 22 sizes of aom_sadMxN / aom_sadMxNx4d (aom_dsp_rtcd.h:1328-1500) */
+#define SVT_HIP_SAD_SIZES(X) \
+    X(128, 128) X(128, 64) X(64, 128) X(64, 64) X(64, 32) X(32, 64) X(32, 32) X(32, 16) X(16, 32) X(16, 16) X(16, 8) \
+    X(8, 16) X(8, 8) X(8, 4) X(4, 8) X(4, 4) X(4, 16) X(16, 4) X(8, 32) X(32, 8) X(16, 64) X(64, 16)
+
+/* aom_<mode>_predictor_WxH / aom_highbd_<mode>_predictor_WxH: exactly intra_pred_fn / intra_high_pred_fn
+ * (EbIntraPrediction.h:36-41), one per mode and size, storable in the reference's slots and its pred[][] / dc_pred[][][]
+ * tables (EbIntraPrediction.c:2842-3350).  10 modes x 19 sizes x {8-bit, high bit depth}. */
+#define SVT_HIP_DECL_PRED(mode, MODE, W, H)                                                                             \
+    void svt_hip_aom_##mode##_predictor_##W##x##H(uint8_t *dst, ptrdiff_t stride, const uint8_t *above, const uint8_t *left); \
+    void svt_hip_aom_highbd_##mode##_predictor_##W##x##H(uint16_t *dst, ptrdiff_t stride, const uint16_t *above,          \
+                                                         const uint16_t *left, int bd);
+SVT_HIP_INTRA_MODES(SVT_HIP_BLOCK_SIZES_2, SVT_HIP_DECL_PRED)
+#undef SVT_HIP_DECL_PRED
+/* eb_smooth_v_predictor / eb_smooth_h_predictor (aom_dsp_rtcd.h:259-264) */
+void svt_hip_eb_smooth_v_predictor(uint8_t *dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t *above,
+                                   const uint8_t *left);
+void svt_hip_eb_smooth_h_predictor(uint8_t *dst, ptrdiff_t stride, int32_t bw, int32_t bh, const uint8_t *above,
+                                   const uint8_t *left);
+/* aom_sadMxN, aom_sadMxNx4d (aom_dsp_rtcd.h:1328-1500) */
+#define SVT_HIP_DECL_SAD(W, H)                                                                                          \
+    unsigned int svt_hip_aom_sad##W##x##H(const uint8_t *src_ptr, int src_stride, const uint8_t *ref_ptr, int ref_stride); \
+    void svt_hip_aom_sad##W##x##H##x4d(const uint8_t *src_ptr, int src_stride, const uint8_t *const ref_ptr[],            \
+                                       int ref_stride, uint32_t *sad_array);
+SVT_HIP_SAD_SIZES(SVT_HIP_DECL_SAD)
+#undef SVT_HIP_DECL_SAD
+/* EB_SADAVGKERNELNxM_TYPE (EbComputeSAD.h:49-57): a row of NxMSadAveragingKernel_funcPtrArray */
+uint32_t svt_hip_combined_averaging_sad(uint8_t *src, uint32_t src_stride, uint8_t *ref1, uint32_t ref1_stride,
+                                        uint8_t *ref2, uint32_t ref2_stride, uint32_t height, uint32_t width);
+/* residual_kernel16bit (EbPictureOperators.c:134) */
+void svt_hip_residual_kernel16bit(uint16_t *input, uint32_t input_stride, uint16_t *pred, uint32_t pred_stride,
+                                  int16_t *residual, uint32_t residual_stride, uint32_t area_width,
+                                  uint32_t area_height);
+/* av1_filter_intra_edge{,_high}, av1_upsample_intra_edge{,_high} (aom_dsp_rtcd.h:152-156, 431-437) */
+void svt_hip_av1_filter_intra_edge(uint8_t *p, int32_t sz, int32_t strength);
+void svt_hip_av1_filter_intra_edge_high(uint16_t *p, int32_t sz, int32_t strength);
+void svt_hip_av1_upsample_intra_edge(uint8_t *p, int32_t sz);
+void svt_hip_av1_upsample_intra_edge_high(uint16_t *p, int32_t sz, int32_t bd);
+/* subtract_average, cfl_predict_lbd / _hbd (aom_dsp_rtcd.h:140-148), av1_txb_init_levels (:2376) */
+void svt_hip_subtract_average(int16_t *pred_buf_q3, int32_t width, int32_t height, int32_t round_offset,
+                              int32_t num_pel_log2);
+void svt_hip_cfl_predict_lbd(const int16_t *pred_buf_q3, uint8_t *pred, int32_t pred_stride, uint8_t *dst,
+                             int32_t dst_stride, int32_t alpha_q3, int32_t bit_depth, int32_t width, int32_t height);
+void svt_hip_cfl_predict_hbd(const int16_t *pred_buf_q3, uint16_t *pred, int32_t pred_stride, uint16_t *dst,
+                             int32_t dst_stride, int32_t alpha_q3, int32_t bit_depth, int32_t width, int32_t height);
+void svt_hip_av1_txb_init_levels(const svt_tran_low_t *const coeff, const int32_t width, const int32_t height,
+                                 uint8_t *const levels);
+
+/* ---- dispatch registration ---------------------------------------------------------------------------------------
+ * The library keeps a registry {reference slot name -> drop-in of the same signature} for every RTCD global of
+ * aom_dsp_rtcd.h it implements (svt_hip_rtcd_slot_count() entries: the 19 av1_fwd_txfm2d_WxH, the 19
+ * av1_inv_txfm2d_add_WxH, av1_inv_txfm_add, the six quantisers, ResidualKernel, 380 intra predictor slots,
+ * eb_smooth_v/h_predictor, av1_dr_prediction_z1-3 and their highbd twins, the edge filters / upsamplers, subtract_average,
+ * cfl_predict_lbd/hbd, av1_txb_init_levels, 22 aom_sadMxN and 22 aom_sadMxNx4d).  After the stock
+ * setup_rtcd_internal(asm_type) (EbEncHandle.c:917) and BEFORE init_intra_predictors_internal() the host calls, per slot,
+ *     svt_hip_rtcd_override_slot("aom_dc_predictor_16x16", (void **)&aom_dc_predictor_16x16);
+ * (INTEGRATION.md has the macro that does it for every slot).  Unknown names return SVT_HIP_ERR_INVALID and leave the
+ * slot alone.  The *_funcPtrArray[asm_type] tables are static per translation unit in the reference, so their ASM_HIP rows
+ * are added at compile time (integration/asm_hip.patch). */
+int svt_hip_rtcd_slot_count(void);
+const char *svt_hip_rtcd_slot_name(int index);        /* NULL when out of range */
+void *svt_hip_rtcd_slot_function(const char *name);   /* the drop-in registered under a reference slot name, or NULL */
+int svt_hip_rtcd_override_slot(const char *name, void **slot);
 
 /* Pointer table the host fills after the stock setup_rtcd_internal(asm_type)
  * (EbEncHandle.c:917) and BEFORE init_intra_predictors_internal(): each member is

@@ -39,6 +39,18 @@ uint64_t svt_oracle_sse(const uint8_t *a, uint32_t a_stride, const uint8_t *b, u
     return acc;
 }
 
+/* combined_averaging_sad, C_DEFAULT/EbComputeSAD_C.c:13-40: SAD against the rounded average of two references */
+uint32_t svt_oracle_sad_avg(const uint8_t *src, uint32_t src_stride, const uint8_t *ref1, uint32_t ref1_stride,
+                            const uint8_t *ref2, uint32_t ref2_stride, uint32_t height, uint32_t width) {
+    uint32_t sad = 0;
+    for (uint32_t y = 0; y < height; y++, src += src_stride, ref1 += ref1_stride, ref2 += ref2_stride)
+        for (uint32_t x = 0; x < width; x++) {
+            const int avg = (ref1[x] + ref2[x] + 1) >> 1;
+            sad += (uint32_t)abs((int)src[x] - avg);
+        }
+    return sad;
+}
+
 /* full_distortion_kernel32_bits, EbPictureOperators.c:283-315 */
 void svt_oracle_full_distortion32(const int32_t *coeff, uint32_t coeff_stride, const int32_t *recon,
                                   uint32_t recon_stride, uint64_t out[2], uint32_t width, uint32_t height) {

@@ -49,6 +49,7 @@ def oracle():
         L = ctypes.CDLL(path)
         L.svt_oracle_sad.restype = ctypes.c_uint32
         L.svt_oracle_sse.restype = ctypes.c_uint64
+        L.svt_oracle_sad_avg.restype = ctypes.c_uint32
         L.svt_oracle_fwd_txfm2d_pack64.restype = ctypes.c_uint64
         _cache["oracle"] = L
     return _cache["oracle"]

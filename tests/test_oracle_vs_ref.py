@@ -331,3 +331,35 @@ def test_full_distortion32_vs_reference_c_and_avx2():
             for nm in ("full_distortion_kernel_cbf_zero32_bits", "full_distortion_kernel_cbf_zero32_bits_avx2"):
                 getattr(R, nm)(ptr(a), U(w + 16), ptr(b), U(w + 24), ptr(r), U(w), U(h))
                 assert r[0] == o[1] and r[1] == o[1], (w, h, mag, nm)
+
+
+def test_sad_variants_vs_reference():
+    """a9: combined_averaging_sad (C), aom_sadMxN_c / aom_sadMxNx4d_c for the 22 RTCD sizes, and the AVX2 twins where the
+    reference has them - all plain SADs (x4d = four of them), pinned here so that the drop-ins have a checker"""
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(21)
+    R.combined_averaging_sad.restype = ctypes.c_uint32
+    U = ctypes.c_uint32
+    for (w, h) in ((4, 4), (8, 8), (16, 16), (24, 24), (32, 32), (48, 48), (64, 64), (8, 32), (64, 16)):
+        s = rng.integers(0, 256, (h, w + 5), dtype=np.uint8); r1 = rng.integers(0, 256, (h, w + 9), dtype=np.uint8)
+        r2 = rng.integers(0, 256, (h, w + 1), dtype=np.uint8)
+        if w == 8:
+            r1[:] = 255; r2[:] = 254; s[:] = 0
+        got = R.combined_averaging_sad(ptr(s), U(w + 5), ptr(r1), U(w + 9), ptr(r2), U(w + 1), U(h), U(w))
+        assert got == O.svt_oracle_sad_avg(ptr(s), U(w + 5), ptr(r1), U(w + 9), ptr(r2), U(w + 1), U(h), U(w)), (w, h)
+    sizes = [(128, 128), (128, 64), (64, 128), (64, 64), (64, 32), (32, 64), (32, 32), (32, 16), (16, 32), (16, 16), (16, 8), (8, 16),
+             (8, 8), (8, 4), (4, 8), (4, 4), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
+    for (w, h) in sizes:
+        s = rng.integers(0, 256, (h, w + 3), dtype=np.uint8)
+        refs = [rng.integers(0, 256, (h, w + 7), dtype=np.uint8) for _ in range(4)]
+        exp = [O.svt_oracle_sad(ptr(s), U(w + 3), ptr(r), U(w + 7), U(h), U(w)) for r in refs]
+        f = getattr(R, f"aom_sad{w}x{h}_c"); f.restype = ctypes.c_uint32
+        assert [f(ptr(s), c_int(w + 3), ptr(r), c_int(w + 7)) for r in refs] == exp, (w, h)
+        arr = (ctypes.c_void_p * 4)(*[r.ctypes.data for r in refs])
+        out = np.zeros(4, np.uint32)
+        getattr(R, f"aom_sad{w}x{h}x4d_c")(ptr(s), c_int(w + 3), arr, c_int(w + 7), ptr(out))
+        assert list(out) == exp, (w, h)
+        fa = getattr(R, f"aom_sad{w}x{h}_avx2", None)
+        if fa is not None and w >= 32:
+            fa.restype = ctypes.c_uint32
+            assert fa(ptr(s), c_int(w + 3), ptr(refs[0]), c_int(w + 7)) == exp[0], (w, h, "avx2")
