@@ -102,6 +102,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_ois_search_batch.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_int,
                                            c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]
     L.svt_hip_txb_init_levels_batch.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_uint32, c_uint32, c_size_t, c_void_p]
+    L.svt_hip_encode_recon_frame.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     L.svt_hip_sad_planes_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_uint32, c_void_p,
                                            c_size_t, c_void_p]
     L.svt_hip_sad_x4d_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_uint32,
@@ -501,6 +502,30 @@ class SvtHipDsp:
                                                          x_origin, y_origin, self._p(best_sad), self._p(best_mv), n,
                                                          self._stream()), "svt_hip_me_sb_search_batch")
         return best_sad, best_mv
+
+    # -- frame-level encode pass: all (plane, size) groups of a frame in one call --------------------
+    class FrameGroup(ctypes.Structure):
+        _fields_ = [("d_src", c_void_p), ("src_stride", c_uint32), ("d_pred", c_void_p), ("pred_stride", c_uint32),
+                    ("d_recon", c_void_p), ("recon_stride", c_uint32), ("d_xy", c_void_p), ("d_offsets", c_void_p),
+                    ("nblocks", c_uint32), ("tx_size", ctypes.c_int32), ("tx_type", ctypes.c_int32), ("d_iscan", c_void_p),
+                    ("d_qcoeff", c_void_p), ("d_eob", c_void_p), ("d_coeff", c_void_p), ("d_dqcoeff", c_void_p)]
+
+    def make_frame_groups(self, groups):
+        """groups: list of dicts with tensors src, pred, recon (planes), xy, iscan, qcoeff, eob and optional offsets, coeff,
+        dqcoeff, plus src_stride / pred_stride / recon_stride, tx_size, tx_type.  -> ctypes array (keep the tensors alive!)"""
+        arr = (self.FrameGroup * len(groups))()
+        for i, g in enumerate(groups):
+            P = lambda k: self._p(g[k]) if g.get(k) is not None else None
+            arr[i] = self.FrameGroup(P("src"), g["src_stride"], P("pred"), g["pred_stride"], P("recon"), g["recon_stride"], P("xy"),
+                                     P("offsets"), g["xy"].numel(), g["tx_size"], g["tx_type"], P("iscan"), P("qcoeff"), P("eob"),
+                                     P("coeff"), P("dqcoeff"))
+        return arr
+
+    def encode_recon_frame(self, group_array, qrow, is_16bit=False, bd=8):
+        tabs = [_np16(qrow[k]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
+        self._check(self.lib.svt_hip_encode_recon_frame(group_array, len(group_array), 1 if is_16bit else 0, bd, tabs[0].ctypes.data,
+                                                        tabs[1].ctypes.data, tabs[2].ctypes.data, tabs[3].ctypes.data, tabs[4].ctypes.data,
+                                                        self._stream()), "svt_hip_encode_recon_frame")
 
     ME_PUS_ALL = 209
     FLAVOUR_C, FLAVOUR_AVX2 = 0, 1

@@ -719,4 +719,122 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// enc4_kernel<PixT, BD, KEEP> — the encode-pass chain for TX_4X4, all 16 transform types: ONE LANE PER BLOCK, the whole
+// block in registers (16 residuals, two passes of four 4-point transforms each way), no LDS.  Adjacent lanes take adjacent
+// blocks, so on planes a row of 64 blocks is fetched as 64 adjacent 4-sample loads per block row.  Replaces the two-stage
+// path (forward + quantise kernel, device copy, inverse kernel) the 4x4 blocks took in round 1: 2 x 16 B in, 64 B qcoeff +
+// 16 B reconstruction out per block instead of two launches and the coeff / dqcoeff round trip through HBM.
+// Reference chain: Av1EncodeLoop (EbCodingLoop.c:617-753) with av1_fwd_txfm2d_4x4 (shift {2, 0, 0}, cos_bit 13 / 13,
+// EbTransforms.h:120-156), aom_highbd_quantize_b (log_scale 0) and av1_inv_txfm2d_add_4x4 (shift {0, -4}).
+// qfast: the quantiser table has power-of-two quant_shift (host-checked): one-product form; else the exact 64-bit form.
+// ---------------------------------------------------------------------------
+template <typename PixT, int BD, bool KEEP>
+__global__ __launch_bounds__(256) void enc4_kernel(
+    const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
+    int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
+    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp, int qfast,
+    int tx_type, uint32_t nblocks, const uint32_t* __restrict__ xy, uint32_t src_stride, uint32_t pred_stride,
+    uint32_t recon_stride) {
+    const uint32_t blk = blockIdx.x * 256u + threadIdx.x;
+    if (blk >= nblocks) return;
+    constexpr int in_bits = BD + 8, row_bits = BD == 8 ? 16 : (BD == 10 ? 18 : 20);      // av1_gen_inv_stage_range (:5404-5456)
+    constexpr int cin_bits = BD + 6 > 16 ? BD + 6 : 16, col_bits = BD == 12 ? 18 : 16, maxpix = (1 << BD) - 1;
+    const int vk = kVKind[tx_type], hk = kHKind[tx_type];
+    const bool ud = vk == K1D_FLIPADST, lr = hk == K1D_FLIPADST;
+    size_t so, po, ro;
+    uint32_t ss = 4, ps = 4, rs = 4;
+    if (xy) {
+        const uint32_t o = xy[blk];
+        const size_t x = o & 0xffffu, y = o >> 16;
+        ss = src_stride; ps = pred_stride; rs = recon_stride;
+        so = y * ss + x; po = y * ps + x; ro = y * rs + x;
+    } else {
+        so = po = ro = (size_t)blk * 16;
+    }
+    PixT sv[4][4], pv[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        __builtin_memcpy(sv[r], src + so + (size_t)r * ss, 4 * sizeof(PixT));
+        __builtin_memcpy(pv[r], pred + po + (size_t)r * ps, 4 * sizeof(PixT));
+    }
+    int d[4][4];
+    unsigned sad_acc = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            d[r][c] = (int)sv[r][c] - (int)pv[r][c];
+            sad_acc += (unsigned)(d[r][c] < 0 ? -d[r][c] : d[r][c]);
+        }
+    if (sad) sad[blk] = sad_acc;
+    // ---- forward: columns (up-shift 2, ud flip on the way in, lr flip on the way out), then rows ----
+    int t[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int x[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) x[r] = (ud ? d[3 - r][c] : d[r][c]) * 4;
+        fwd1d<4, 13>(vk, x);
+#pragma unroll
+        for (int r = 0; r < 4; r++) t[r][c] = x[r];
+    }
+    int co[16];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int y[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) y[c] = lr ? t[r][3 - c] : t[r][c];      // column c of the pass-1 output went to 3 - c
+        fwd1d<4, 13>(hk, y);
+#pragma unroll
+        for (int c = 0; c < 4; c++) co[r * 4 + c] = y[c];
+    }
+    // ---- quantise / dequantise / eob ----
+    int q[16], dq[16];
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (qfast) quant_one<2>(co[i], i == 0 ? 0 : 1, qp, q[i], dq[i]);
+        else quant_one<0>(co[i], i == 0 ? 0 : 1, qp, q[i], dq[i]);
+        e = max(e, q[i] ? (int)iscan[i] + 1 : 0);
+    }
+    eob[blk] = (uint16_t)e;
+    {
+        int4* qo = reinterpret_cast<int4*>(qcoeff + (size_t)blk * 16);
+#pragma unroll
+        for (int r = 0; r < 4; r++) __builtin_memcpy(qo + r, &q[4 * r], 16);
+        if (KEEP) {
+            int4* c4 = reinterpret_cast<int4*>(coeff + (size_t)blk * 16);
+            int4* d4 = reinterpret_cast<int4*>(dqcoeff + (size_t)blk * 16);
+#pragma unroll
+            for (int r = 0; r < 4; r++) { __builtin_memcpy(c4 + r, &co[4 * r], 16); __builtin_memcpy(d4 + r, &dq[4 * r], 16); }
+        }
+    }
+    // ---- inverse: rows (clamp bd + 8, shift 0), columns (clamp, shift 4), flips, add, clip ----
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int x[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) x[c] = svtgen::svt_clamp(dq[r * 4 + c], -(1 << (in_bits - 1)), (1 << (in_bits - 1)) - 1);
+        inv1d<4>(hk, x, -(1 << (row_bits - 1)), (1 << (row_bits - 1)) - 1);
+#pragma unroll
+        for (int c = 0; c < 4; c++) t[r][c] = x[c];
+    }
+    PixT ov[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int y[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) y[r] = svtgen::svt_clamp(lr ? t[r][3 - c] : t[r][c], -(1 << (cin_bits - 1)), (1 << (cin_bits - 1)) - 1);
+        inv1d<4>(vk, y, -(1 << (col_bits - 1)), (1 << (col_bits - 1)) - 1);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int res = round_shift_c<4>(ud ? y[3 - r] : y[r]);
+            ov[r][c] = (PixT)min(max((int)pv[r][c] + res, 0), maxpix);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) __builtin_memcpy(recon + ro + (size_t)r * rs, ov[r], 4 * sizeof(PixT));
+}
+
 }  // namespace svtdev

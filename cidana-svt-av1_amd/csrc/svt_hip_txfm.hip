@@ -358,6 +358,20 @@ static int encode_recon_impl(const void* d_src_v, uint32_t src_stride, const voi
             return launch_status("encode_recon_32x32");
         }
     }
+    if (tx_size == SVT_TX_4X4 && ((d_coeff != nullptr) == (d_dqcoeff != nullptr)) && !g_tune_no_enc_staged) {
+        // one lane per block, everything in registers (enc4_kernel); any quantiser table
+        const QParams qp = make_qparams(zbin, round, quant, quant_shift, dequant, 0);
+        bool fast = qp.fast_ok;
+        for (int i = 0; i < 2; i++) fast = fast && qp.quant_shift[i] >= 0 && qp.dequant[i] >= 0 && qp.round[i] >= 0;
+        const dim3 grid((uint32_t)((nblocks + 255) / 256));
+#define ENC4(T, B, KEEP) hipLaunchKernelGGL((enc4_kernel<T, B, KEEP>), grid, dim3(256), 0, s, (const T*)d_src_v, (const T*)d_pred_v, (T*)d_recon_v, \
+                                           d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, fast ? 1 : 0, tx_type, (uint32_t)nblocks, d_xy,         \
+                                           src_stride, pred_stride, recon_stride)
+        if (is_16bit) { if (d_coeff) ENC4(uint16_t, 10, true); else ENC4(uint16_t, 10, false); }
+        else { if (d_coeff) ENC4(uint8_t, 8, true); else ENC4(uint8_t, 8, false); }
+#undef ENC4
+        return launch_status("encode_recon_4x4");
+    }
     {   // every other size: the staged fused kernel (dense 8-bit batches, power-of-two quant_shift tables)
         const int pels = kTxW[tx_size] * kTxH[tx_size];
         const QParams qp = make_qparams(zbin, round, quant, quant_shift, dequant, pels > 1024 ? 2 : (pels > 256 ? 1 : 0));
@@ -463,6 +477,91 @@ extern "C" int svt_hip_fwd_quant_planes_batch(const void* d_src, uint32_t src_st
 #define CALL(W, H) launch_fq<W, H>(d_src, src_stride, d_pred, pred_stride, d_xy, nblocks, is_16bit, tx_type, qp, d_iscan, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_energy, s)
     TX_SWITCH(tx_size, CALL)
 #undef CALL
+}
+
+// ---- frame-level fan-out: independent groups on internal streams, forked from and joined into the caller's stream ----
+namespace {
+constexpr int kFanStreams = 8;
+struct FanOut {
+    hipStream_t s[kFanStreams] = {};
+    hipEvent_t fork = nullptr, join[kFanStreams] = {};
+    bool ready = false;
+    int ensure() {
+        if (ready) return SVT_HIP_OK;
+        HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        for (int i = 0; i < kFanStreams; i++) {
+            HIP_TRY(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&join[i], hipEventDisableTiming));
+        }
+        ready = true;
+        return SVT_HIP_OK;
+    }
+    ~FanOut() {
+        if (!ready) return;
+        for (int i = 0; i < kFanStreams; i++) { (void)hipStreamDestroy(s[i]); (void)hipEventDestroy(join[i]); }
+        (void)hipEventDestroy(fork);
+    }
+};
+thread_local FanOut t_fan;
+}  // namespace
+
+extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int ngroups, int is_16bit, int bd,
+                                          const int16_t* zbin, const int16_t* round, const int16_t* quant,
+                                          const int16_t* quant_shift, const int16_t* dequant, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (ngroups == 0) return SVT_HIP_OK;
+    if (!groups || ngroups < 0) return set_err(SVT_HIP_ERR_INVALID, "NULL group list");
+    for (int g = 0; g < ngroups; g++) {            // validate everything before anything is enqueued
+        const svt_hip_frame_group& G = groups[g];
+        if (G.nblocks == 0) continue;
+        if (!G.d_src || !G.d_pred || !G.d_recon || !G.d_xy || !G.d_iscan || !G.d_qcoeff || !G.d_eob)
+            return set_err(SVT_HIP_ERR_INVALID, "group %d: NULL member", g);
+        if (!txfm_allowed(G.tx_size, G.tx_type)) return set_err(SVT_HIP_ERR_INVALID, "group %d: tx_size %d / tx_type %d", g, G.tx_size, G.tx_type);
+        if ((G.d_coeff != nullptr) != (G.d_dqcoeff != nullptr)) return set_err(SVT_HIP_ERR_INVALID, "group %d: d_coeff and d_dqcoeff go together", g);
+        if (G.tx_size == SVT_TX_4X4 && g_tune_no_enc_staged && (!G.d_coeff || !G.d_offsets || G.d_recon != G.d_pred || G.recon_stride != G.pred_stride))
+            return set_err(SVT_HIP_ERR_INVALID, "group %d: with no_enc_staged set, 4x4 groups take the two-stage path and need d_coeff, d_dqcoeff, d_offsets and in-place reconstruction", g);
+    }
+    if (int rc = t_fan.ensure()) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int nstreams = ngroups < kFanStreams ? ngroups : kFanStreams;
+    HIP_TRY(hipEventRecord(t_fan.fork, s));
+    for (int i = 0; i < nstreams; i++) HIP_TRY(hipStreamWaitEvent(t_fan.s[i], t_fan.fork, 0));
+    int rc = SVT_HIP_OK;
+    // largest groups first, round-robin: the long kernels start early and the small ones fill in beside them
+    int order[256];
+    const int ng = ngroups < 256 ? ngroups : 256;
+    if (ngroups > 256) return set_err(SVT_HIP_ERR_INVALID, "more than 256 groups in one call");
+    for (int i = 0; i < ng; i++) order[i] = i;
+    for (int i = 1; i < ng; i++) {                 // insertion sort by work (pixels), descending
+        const int v = order[i];
+        const size_t wv = (size_t)groups[v].nblocks * kTxW[groups[v].tx_size] * kTxH[groups[v].tx_size];
+        int j = i - 1;
+        while (j >= 0 && (size_t)groups[order[j]].nblocks * kTxW[groups[order[j]].tx_size] * kTxH[groups[order[j]].tx_size] < wv) { order[j + 1] = order[j]; j--; }
+        order[j + 1] = v;
+    }
+    for (int k = 0; k < ng && rc == SVT_HIP_OK; k++) {
+        const svt_hip_frame_group& G = groups[order[k]];
+        if (G.nblocks == 0) continue;
+        hipStream_t gs = t_fan.s[k % nstreams];
+        if (G.tx_size == SVT_TX_4X4 && g_tune_no_enc_staged) {
+            rc = svt_hip_fwd_quant_planes_batch(G.d_src, G.src_stride, G.d_pred, G.pred_stride, G.d_xy, G.nblocks, is_16bit, bd, G.tx_size, G.tx_type,
+                                                zbin, round, quant, quant_shift, dequant, G.d_iscan, G.d_coeff, G.d_qcoeff, G.d_dqcoeff, G.d_eob,
+                                                nullptr, nullptr, gs);
+            if (rc == SVT_HIP_OK)
+                rc = svt_hip_inv_txfm2d_add_batch(G.d_dqcoeff, G.d_recon, is_16bit, (int32_t)G.recon_stride, 0, G.d_offsets, G.nblocks, G.tx_size,
+                                                  G.tx_type, bd, gs);
+        } else {
+            rc = encode_recon_impl(G.d_src, G.src_stride, G.d_pred, G.pred_stride, G.d_recon, G.recon_stride, G.d_xy, is_16bit, bd, G.nblocks,
+                                   G.tx_size, G.tx_type, zbin, round, quant, quant_shift, dequant, G.d_iscan, G.d_coeff, G.d_qcoeff, G.d_dqcoeff,
+                                   G.d_eob, nullptr, gs);
+        }
+    }
+    // always join, also after an error: the caller's stream (or capture) must not be left with dangling branches
+    for (int i = 0; i < nstreams; i++) {
+        if (hipEventRecord(t_fan.join[i], t_fan.s[i]) != hipSuccess || hipStreamWaitEvent(s, t_fan.join[i], 0) != hipSuccess)
+            if (rc == SVT_HIP_OK) rc = set_err(SVT_HIP_ERR_RUNTIME, "stream join failed");
+    }
+    return rc;
 }
 
 extern "C" int svt_hip_fwd_quant_batch(const int16_t* d_residual, size_t nblocks, int tx_size, int tx_type, int bd,

@@ -1,0 +1,88 @@
+"""Host-side tiling of pictures into the (plane, transform size) groups the frame-level entry point takes
+(svt_hip_encode_recon_frame) - BASELINE.json configs[3] (one 1080p yuv420p frame, every CU size) and configs[4] (3840x2160
+10-bit, 240 frames, one GOP of 30 frames per rank) - and the fixed-size digest of a pass that ranks all-reduce.
+
+A "pass" over a yuv420p picture at luma size S tiles the luma plane with SxS blocks and both chroma planes with
+S/2 x S/2 blocks (S/2 >= 4), DCT_DCT, as SURVEY 8(d) specifies for C4 / C5; partial blocks at the right / bottom edge
+are left untouched.  Everything here is plain index arithmetic; the device work is the C ABI's."""
+from __future__ import annotations
+
+import numpy as np
+
+TX_OF_SIDE = {64: 4, 32: 3, 16: 2, 8: 1, 4: 0}          # square TxSize by side
+LUMA_SIZES = (64, 32, 16, 8, 4)
+
+
+def tile_origins(pw: int, ph: int, side: int):
+    """(xy, offsets): block origins x | y << 16 and element offsets y * pw + x of the full side x side tiles of a plane"""
+    xs = np.arange(0, pw - side + 1, side, dtype=np.uint32)
+    ys = np.arange(0, ph - side + 1, side, dtype=np.uint32)
+    xy = ((ys[:, None] << 16) | xs[None, :]).reshape(-1)
+    offs = (ys[:, None] * np.uint32(pw) + xs[None, :]).reshape(-1)
+    return xy.astype(np.uint32), offs.astype(np.uint32)
+
+
+class FramePass:
+    """Device-side state of every group of one or more passes over one picture: origin tables, scan tables, output
+    buffers, and the ctypes group array for svt_hip_encode_recon_frame.  Keeps every tensor alive."""
+
+    def __init__(self, dsp, pkg, planes_src, planes_pred, luma_sizes=LUMA_SIZES, is_16bit=False, keep_coeff=False):
+        import torch
+        self.dsp, self.torch = dsp, torch
+        self.groups = []
+        dev = next(iter(planes_src.values())).device
+        for S in luma_sizes:
+            for name, src in planes_src.items():
+                side = S if name == "Y" else S // 2
+                if side < 4:
+                    continue
+                ts = TX_OF_SIDE[side]
+                ph, pw = src.shape
+                xy, offs = tile_origins(pw, ph, side)
+                n = xy.size
+                if n == 0:
+                    continue
+                _, iscan = pkg.tables.scan_tables(ts, 0)
+                nc = min(side, 32) ** 2
+                pred = planes_pred[name]
+                recon = pred.clone()              # samples outside the full tiles keep the prediction, as in-place reconstruction would
+                g = {"name": name, "luma_size": S, "tx_size": ts, "tx_type": 0, "src": src, "src_stride": pw, "pred": pred, "pred_stride": pw,
+                     "recon": recon, "recon_stride": pw, "xy": torch.from_numpy(xy.view(np.int32)).to(dev),
+                     "offsets": torch.from_numpy(offs.view(np.int32)).to(dev) if ts == 0 else None,
+                     "iscan": torch.from_numpy(iscan).to(dev), "qcoeff": torch.empty((n, nc), dtype=torch.int32, device=dev),
+                     "eob": torch.zeros(n, dtype=torch.int16, device=dev), "pixels": n * side * side}
+                if keep_coeff:
+                    g["coeff"] = torch.empty((n, nc), dtype=torch.int32, device=dev)
+                    g["dqcoeff"] = torch.empty((n, nc), dtype=torch.int32, device=dev)
+                self.groups.append(g)
+        self.array = dsp.make_frame_groups(self.groups)
+        self.is_16bit = is_16bit
+        self.pixels = sum(g["pixels"] for g in self.groups)
+        self.blocks = sum(g["xy"].numel() for g in self.groups)
+
+    def run(self, qrow):
+        """every group in one call (concurrent on the library's internal streams)"""
+        self.dsp.encode_recon_frame(self.array, qrow, is_16bit=self.is_16bit, bd=10 if self.is_16bit else 8)
+
+    def run_sequential(self, qrow):
+        """the same groups, one entry-point call after the other on the caller's stream (what round 1 measured; the wrappers
+        allocate their outputs from torch's caching allocator)"""
+        d = self.dsp
+        bd = 10 if self.is_16bit else 8
+        for g in self.groups:
+            d.encode_recon_planes(g["src"], g["src_stride"], g["pred"], g["pred_stride"], g["recon"], g["recon_stride"], g["xy"],
+                                  g["tx_size"], 0, qrow, g["iscan"], bd=bd)
+
+    def digest(self):
+        """int64 [blocks, sum eob, sum |qcoeff| weighted checksum, sum recon samples] of the pass, computed on the device"""
+        t = self.torch
+        d = t.zeros(4, dtype=t.int64, device=self.groups[0]["eob"].device)
+        for g in self.groups:
+            d[0] += g["xy"].numel()
+            d[1] += (g["eob"].to(t.int64) & 0xffff).sum()
+            q = g["qcoeff"].to(t.int64)
+            w = (t.arange(q.shape[1], device=q.device, dtype=t.int64) % 8191) + 1
+            d[2] += (q * w).sum() % ((1 << 61) - 1)
+            d[3] += (g["recon"].to(t.int64) & 0xffff).sum()
+        d[2] %= (1 << 61) - 1
+        return d

@@ -179,9 +179,9 @@ int svt_hip_fwd_quant_sad_batch(const uint8_t *d_src, const uint8_t *d_pred, siz
  * d_src / d_pred.  TX_32X32 with DCT_DCT or IDTX runs ONE fused kernel in which coefficients and
  * residual never leave the CU (7 174 B of HBM traffic per block instead of 20 486); every other size
  * except 4x4 runs the generic fused kernel of the same structure.  d_coeff and d_dqcoeff are optional in
- * the fused kernels (both NULL = not written).  4x4 blocks, quantiser tables whose quant_shift is not a
- * power of two and buffers that are not 16-B aligned run svt_hip_fwd_quant_sad_batch + a device copy +
- * svt_hip_inv_txfm2d_add_batch and need both buffers. */
+ * the fused kernels (both NULL = not written).  TX_4X4 runs one lane per block with the whole block in registers (any
+ * quantiser table).  For the other sizes, quantiser tables whose quant_shift is not a power of two and buffers that are
+ * not 16-B aligned run svt_hip_fwd_quant_sad_batch + a device copy + svt_hip_inv_txfm2d_add_batch and need both buffers. */
 int svt_hip_encode_recon_batch(const uint8_t *d_src, const uint8_t *d_pred, size_t nblocks, int tx_size,
                                int tx_type, const int16_t *zbin, const int16_t *round,
                                const int16_t *quant, const int16_t *quant_shift, const int16_t *dequant,
@@ -193,7 +193,7 @@ int svt_hip_encode_recon_batch(const uint8_t *d_src, const uint8_t *d_pred, size
  * d_xy[b] >> 16) of the source, prediction and reconstruction planes (row strides in samples); the
  * reconstruction may be written in place into the prediction plane (d_recon == d_pred with equal
  * strides), as the reference does after pic_copy_kernel (EbCodingLoop.c:741-753).  is_16bit / bd: uint8
- * samples (bd 8) or uint16 samples (bd 10; d_sad must be NULL).  Fused kernels only: 4x4 blocks and
+ * samples (bd 8) or uint16 samples (bd 10; d_sad must be NULL).  Fused kernels only: for sizes other than 4x4,
  * non-standard quantiser tables return SVT_HIP_ERR_INVALID (use svt_hip_fwd_quant_planes_batch +
  * svt_hip_inv_txfm2d_add_batch there). */
 int svt_hip_encode_recon_planes_batch(const void *d_src, uint32_t src_stride, const void *d_pred,
@@ -204,6 +204,29 @@ int svt_hip_encode_recon_planes_batch(const void *d_src, uint32_t src_stride, co
                                       const int16_t *quant_shift, const int16_t *dequant,
                                       const int16_t *d_iscan, int32_t *d_coeff, int32_t *d_qcoeff,
                                       int32_t *d_dqcoeff, uint16_t *d_eob, uint32_t *d_sad, void *stream);
+
+/* The encode-pass chain for a whole FRAME (or many frames) in ONE call: every (plane, transform size) group of blocks the
+ * frame is cut into - BASELINE.json configs[3] / [4], the per-SB loop of AV1EncodePass (EbCodingLoop.c:2249) turned inside
+ * out.  A group is what svt_hip_encode_recon_planes_batch takes; the groups of a call are independent (disjoint blocks), so
+ * the library issues them CONCURRENTLY on internal streams forked from, and joined back into, `stream` (a lone 1080p frame
+ * gives each size's kernel less than one workgroup per CU: run one after the other the frame is launch-latency-bound).
+ * The call only enqueues work and can be captured into a HIP graph by the caller (the fork / join becomes graph branches).
+ * One quantiser row set per call (one qindex), as in the per-plane entry point. */
+typedef struct svt_hip_frame_group {
+    const void *d_src;  uint32_t src_stride;     /* planes: pointer to sample (0, 0), stride in samples */
+    const void *d_pred; uint32_t pred_stride;
+    void *d_recon;      uint32_t recon_stride;   /* may be d_pred with the same stride: reconstruct in place */
+    const uint32_t *d_xy;                        /* block origins x | y << 16 */
+    const uint32_t *d_offsets;                   /* unused (NULL) unless svt_hip_tune("no_enc_staged", 1): y * recon_stride + x */
+    uint32_t nblocks;
+    int32_t tx_size, tx_type;
+    const int16_t *d_iscan;                      /* DEVICE int16 [min(W,32) * min(H,32)] for this size / type */
+    int32_t *d_qcoeff;  uint16_t *d_eob;         /* dense per-group outputs */
+    int32_t *d_coeff, *d_dqcoeff;                /* optional, both or neither */
+} svt_hip_frame_group;
+int svt_hip_encode_recon_frame(const svt_hip_frame_group *groups, int ngroups, int is_16bit, int bd,
+                               const int16_t *zbin, const int16_t *round, const int16_t *quant,
+                               const int16_t *quant_shift, const int16_t *dequant, void *stream);
 
 /* BASELINE.json configs[1]: FwdTxfm2d + quantize on a batch of int16 residual blocks
  * (dense W*H per block) — av1_estimate_transform + av1_quantize_inv_quantize

@@ -61,11 +61,9 @@ def test_fused_encode_recon_32x32_idtx(dsp):
 @pytest.mark.parametrize("tx_size,tx_type", [(0, 0), (1, 5), (1, 0), (2, 1), (2, 6), (4, 0), (5, 3), (6, 0), (7, 8), (9, 0), (10, 9),
                                              (11, 0), (12, 0), (13, 1), (14, 0), (15, 0), (16, 10), (17, 0), (18, 0)])
 def test_encode_recon_other_sizes(dsp, tx_size, tx_type, keep):
-    """enc_staged_kernel (every size but 4x4 and 32x32) and, for 4x4, the composed two-kernel path."""
+    """enc_staged_kernel (every size but 4x4 and 32x32) and, for 4x4, the one-lane-per-block enc4_kernel."""
     if not svtlibs.txfm_allowed(tx_size, tx_type):
         pytest.skip("type not defined for this size")
-    if tx_size == 0 and not keep:
-        pytest.skip("4x4 runs the composed path, which needs the coefficient buffers")
     rng = np.random.default_rng(7 + tx_size)
     for kind, n in (("smooth", 11), ("extreme", 7), ("random", 70)):       # 70: more than one wave of small blocks
         src, pred = make_pixels(rng, n, TX_H[tx_size], TX_W[tx_size], kind)
@@ -77,8 +75,12 @@ def test_encode_recon_argument_errors(dsp, pkg):
     qrow = {k: v[100].copy() for k, v in qt.items()}
     _, iscan = svtlibs.scan_tables(0, 0)
     src = torch.zeros((3, 4, 4), dtype=torch.uint8, device="cuda:0")
-    with pytest.raises(RuntimeError):                           # composed path (4x4) needs coeff / dqcoeff buffers
-        dsp.encode_recon(src, src.clone(), 0, 0, qrow, dev(iscan), keep_coeff=False)
+    dsp.lib.svt_hip_tune(b"no_enc_staged", 1)
+    try:
+        with pytest.raises(RuntimeError):                       # the composed two-kernel path needs coeff / dqcoeff buffers
+            dsp.encode_recon(src, src.clone(), 0, 0, qrow, dev(iscan), keep_coeff=False)
+    finally:
+        dsp.lib.svt_hip_tune(b"no_enc_staged", 0)
     out = dsp.encode_recon(src[:0], src[:0].clone(), 0, 0, qrow, dev(iscan))     # empty batch is a no-op
     assert out["recon"].shape[0] == 0
 
@@ -200,3 +202,28 @@ def test_fused_chain_equals_two_kernel_path_at_scale(dsp, tx_size, n):
     torch.cuda.synchronize()
     assert torch.equal(a["recon"], rec2) and torch.equal(a["qcoeff"], q) and torch.equal(a["coeff"], co)
     assert torch.equal(a["dqcoeff"], dq) and torch.equal(a["eob"], eob) and torch.equal(a["sad"], sad)
+
+
+@pytest.mark.parametrize("tx_type", range(16))
+def test_encode_recon_4x4_every_type_fused_equals_two_stage(dsp, tx_type):
+    """enc4_kernel (one lane per block, registers only) against the oracle AND against the two-kernel path it replaces,
+    all 16 transform types incl. the flips, extreme residuals, several quantisers incl. a non-power-of-two quant_shift"""
+    rng = np.random.default_rng(100 + tx_type)
+    for kind, n in (("smooth", 130), ("extreme", 66), ("random", 515)):
+        src, pred = make_pixels(rng, n, 4, 4, kind)
+        for q in (0, 60, 255):
+            check(dsp, src, pred, 0, tx_type, q, True)
+            check(dsp, src, pred, 0, tx_type, q, False)
+    src, pred = make_pixels(rng, 300, 4, 4, "random")
+    qt = svtlibs.quant_tables(8)
+    qrow = {k: v[90].copy() for k, v in qt.items()}
+    qrow["quant_shift"][:] = 12345                     # not a power of two: the exact 64-bit quantiser form
+    _, iscan = svtlibs.scan_tables(0, tx_type)
+    a = dsp.encode_recon(dev(src), dev(pred), 0, tx_type, qrow, dev(iscan), keep_coeff=True)
+    dsp.lib.svt_hip_tune(b"no_enc_staged", 1)
+    try:
+        b = dsp.encode_recon(dev(src), dev(pred), 0, tx_type, qrow, dev(iscan), keep_coeff=True)
+    finally:
+        dsp.lib.svt_hip_tune(b"no_enc_staged", 0)
+    for k in ("coeff", "qcoeff", "dqcoeff", "eob", "recon", "sad"):
+        assert torch.equal(a[k], b[k]), k
