@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=1 << 20, help="32x32 blocks per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a ONE-GPU box: every rank uses cuda:0 and the process group is gloo (RCCL cannot put two ranks "
+                         "on one device); walks exactly the multi-rank code path of the driver's 8-GPU run")
     args = ap.parse_args()
 
     import torch
@@ -190,12 +193,15 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dsp = pkg.SvtHipDsp(local_rank)               # raises if the HIP library/device is unusable
@@ -242,7 +248,7 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)    # one kernel per step, back to back
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -269,6 +275,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
+            **({"rehearsal_all_ranks_on_one_gpu": True} if args.rehearse else {}),
             "vs_baseline": None,
             "dtype": "i32",
             "data": "synthetic",
