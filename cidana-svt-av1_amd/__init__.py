@@ -113,6 +113,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
                                            c_uint32, c_uint32, c_size_t, c_void_p]
     L.svt_hip_picture_full_distortion32_batch.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_uint32, c_uint32, c_void_p, c_int,
                                                           c_void_p, c_size_t, c_void_p]
+    L.svt_hip_hme_level_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_size_t, c_void_p]
+    L.svt_hip_hme_level_params.argtypes = [c_int, c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32,
+                                           c_uint32, c_uint32, c_uint32, c_void_p]
     L.svt_hip_me_fullpel_search_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_void_p, c_uint32, c_size_t, c_void_p,
                                                   c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_uint32,
                                                   c_size_t, c_void_p]
@@ -526,6 +530,34 @@ class SvtHipDsp:
         self._check(self.lib.svt_hip_encode_recon_frame(group_array, len(group_array), 1 if is_16bit else 0, bd, tabs[0].ctypes.data,
                                                         tabs[1].ctypes.data, tabs[2].ctypes.data, tabs[3].ctypes.data, tabs[4].ctypes.data,
                                                         self._stream()), "svt_hip_encode_recon_frame")
+
+    # -- hierarchical ME: one level for all SBs, clipping on the device ----------------------------
+    class HmeParams(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_int32) for n in ("search_area_width", "search_area_height", "x_origin_offset", "y_origin_offset",
+                                                  "pad_width", "pad_height", "ref_width", "ref_height", "round_down", "mv_shift")]
+
+    def hme_level_params(self, level, hme_w, hme_h, region_w, region_h, total_w, total_h, mult_x, mult_y, ref_origin_x, ref_origin_y,
+                         ref_width, ref_height):
+        p = self.HmeParams()
+        w, h = _np16(hme_w).view("uint16"), _np16(hme_h).view("uint16")
+        self._check(self.lib.svt_hip_hme_level_params(level, w.ctypes.data, h.ctypes.data, region_w, region_h, total_w, total_h, mult_x,
+                                                      mult_y, ref_origin_x, ref_origin_y, ref_width, ref_height, ctypes.byref(p)),
+                    "svt_hip_hme_level_params")
+        return p
+
+    def hme_level(self, src_pic, src_stride, ref_pic00, ref_stride, sb_origin, sb_size, centers, center_shift, params):
+        """src_pic: uint8 tensor whose data_ptr() is sample (0, 0) of the level's source picture; ref_pic00: likewise for the
+        padded reference (a view into the padded buffer).  sb_origin int16 [n, 2], sb_size int16 [n, 2] (uint16 values),
+        centers int16 [n, 2] or None.  -> (best_sad int64 [n], mv int16 [n, 2])"""
+        t = self.torch
+        n = sb_origin.shape[0]
+        best = t.zeros(n, dtype=t.int64, device=sb_origin.device)
+        mv = t.zeros((n, 2), dtype=t.int16, device=sb_origin.device)
+        self._check(self.lib.svt_hip_hme_level_batch(self._p(src_pic), src_stride, self._p(ref_pic00), ref_stride, self._p(sb_origin),
+                                                     self._p(sb_size), self._p(centers) if centers is not None else None, center_shift,
+                                                     ctypes.byref(params), self._p(best), self._p(mv), n, self._stream()),
+                    "svt_hip_hme_level_batch")
+        return best, mv
 
     ME_PUS_ALL = 209
     FLAVOUR_C, FLAVOUR_AVX2 = 0, 1

@@ -575,4 +575,115 @@ __global__ __launch_bounds__(ME_THREADS) void me_fullpel_exact_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// hme_level_kernel — one level of the hierarchical motion estimation for every SB of a picture (and every reference /
+// search region handed in as separate tasks): HmeLevel0 / HmeLevel1 / HmeLevel2 (EbMotionEstimation.c:5689-6150) INCLUDING the
+// per-SB search-area placement and clipping the reference does on the host (:5729-5798): origin = offset + search centre,
+// clipped against the padded reference picture in the reference's own statement order (its left / top "shrink" statements
+// test the already corrected origin and never fire: restated as written), width rounded down to a multiple of 16 / 8.
+// The search itself is sad_loop_kernel on EVERY OTHER ROW of the block (the 1/16 SB buffer holds every other row,
+// EbMotionEstimationProcess.c:548-556; levels 1 / 2 double both strides), first strict minimum in raster order.
+// One workgroup per task: the block's even rows and the clipped window live in LDS, the candidates are strided over the
+// 256 lanes (v_sad_u8 on dwords rebuilt with v_alignbyte), argmin key = sad << 32 | candidate.
+// Results as the reference leaves them: SAD x 2, (x + origin) << mv_shift.
+// ---------------------------------------------------------------------------
+struct HmeParams {          // == svt_hip_hme_params (include/svt_hip_dsp.h)
+    int32_t search_area_width, search_area_height, x_origin_offset, y_origin_offset, pad_width, pad_height, ref_width,
+        ref_height, round_down, mv_shift;
+};
+
+__global__ __launch_bounds__(ME_THREADS) void hme_level_kernel(
+    const uint8_t* __restrict__ src_pic, uint32_t src_stride, const uint8_t* __restrict__ ref_pic, uint32_t ref_stride,
+    const int16_t* __restrict__ sb_origin /* [n][2] */, const uint16_t* __restrict__ sb_size /* [n][2] */,
+    const int16_t* __restrict__ centers /* [n][2] or NULL */, int center_shift, HmeParams p,
+    unsigned long long* __restrict__ best_sad, int16_t* __restrict__ mv /* [n][2] */, uint32_t wpitch, uint32_t ntasks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* s_src = reinterpret_cast<uint32_t*>(smem);            // [32 rows][16 dwords]: the block's even rows, zero-padded
+    uint8_t* s_ref = smem + 32 * 64;
+    __shared__ unsigned long long s_red[4];
+    const uint32_t task = blockIdx.x;
+    if (task >= ntasks) return;
+    const int tid = threadIdx.x;
+    const int ox = sb_origin[2 * task], oy = sb_origin[2 * task + 1];
+    const int sbw = sb_size[2 * task], sbh = sb_size[2 * task + 1];
+    const int xc = centers ? (centers[2 * task] >> center_shift) : 0, yc = centers ? (centers[2 * task + 1] >> center_shift) : 0;
+    int saw = p.search_area_width, sah = p.search_area_height;
+    int xo = p.x_origin_offset + xc, yo = p.y_origin_offset + yc;
+    const int W = p.ref_width, H = p.ref_height;
+    xo = (ox + xo < -p.pad_width) ? -p.pad_width - ox : xo;
+    saw = (ox + xo < -p.pad_width) ? saw - (-p.pad_width - (ox + xo)) : saw;        // never true after the line above (as in the reference)
+    xo = (ox + xo > W - 1) ? xo - ((ox + xo) - (W - 1)) : xo;
+    if (ox + xo + saw > W) saw = max(1, saw - ((ox + xo + saw) - W));
+    if (saw >= p.round_down) saw &= ~(p.round_down - 1);
+    yo = (oy + yo < -p.pad_height) ? -p.pad_height - oy : yo;
+    sah = (oy + yo < -p.pad_height) ? sah - (-p.pad_height - (oy + yo)) : sah;
+    yo = (oy + yo > H - 1) ? yo - ((oy + yo) - (H - 1)) : yo;
+    if (oy + yo + sah > H) sah = max(1, sah - ((oy + yo + sah) - H));
+    const int hh = sbh >> 1;                                          // rows compared
+    const int win_w = sbw + saw - 1, win_h = sah + 2 * hh - 2;
+    const uint8_t* gs = src_pic + (ptrdiff_t)oy * (ptrdiff_t)src_stride + ox;
+    const uint8_t* gr = ref_pic + (ptrdiff_t)(oy + yo) * (ptrdiff_t)ref_stride + (ox + xo);
+    // ---- stage: even block rows (zero-padded to 64 B) and the window, dword by dword (bytes at a row's ragged end) ----
+    for (int i = tid; i < 32 * 16; i += ME_THREADS) {
+        const int r = i >> 4, q = i & 15;
+        uint32_t v = 0;
+        if (r < hh) {
+            const uint8_t* g = gs + (size_t)(2 * r) * src_stride + 4 * q;
+            if (4 * q + 4 <= sbw) __builtin_memcpy(&v, g, 4);
+            else for (int b = 0; 4 * q + b < sbw; b++) v |= (uint32_t)g[b] << (8 * b);
+        }
+        s_src[i] = v;
+    }
+    const int wq = (win_w + 3) >> 2;                                  // dwords per window row
+    for (int i = tid; i < win_h * wq; i += ME_THREADS) {
+        const int r = i / wq, q = i - r * wq;
+        const uint8_t* g = gr + (ptrdiff_t)r * (ptrdiff_t)ref_stride + 4 * q;
+        uint32_t v = 0;
+        if (4 * q + 4 <= win_w) __builtin_memcpy(&v, g, 4);
+        else for (int b = 0; 4 * q + b < win_w; b++) v |= (uint32_t)g[b] << (8 * b);
+        *reinterpret_cast<uint32_t*>(s_ref + (size_t)r * wpitch + 4 * q) = v;
+    }
+    __syncthreads();
+    // ---- candidates ----
+    unsigned long long best = ~0ull;
+    const int ncand = saw * sah;
+    const int bq = (sbw + 3) >> 2;                                    // dwords per block row
+    for (int cand = tid; cand < ncand; cand += ME_THREADS) {
+        const int ys = cand / saw, xs = cand - ys * saw;
+        const unsigned sh = (unsigned)(xs & 3);
+        unsigned acc = 0;
+        for (int r = 0; r < hh; r++) {
+            const uint32_t* rrow = reinterpret_cast<const uint32_t*>(s_ref + (size_t)(ys + 2 * r) * wpitch) + (xs >> 2);
+            const uint32_t* srow = s_src + r * 16;
+            uint32_t lo = rrow[0];
+            for (int q = 0; q < bq; q++) {
+                const uint32_t hi = rrow[q + 1];                      // wpitch leaves 8 spare bytes per row
+                uint32_t rv = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                const int rem = sbw - 4 * q;
+                if (rem < 4) rv &= (1u << (8 * rem)) - 1;             // ragged last dword: the source side is zero-padded
+                acc = __builtin_amdgcn_sad_u8(srow[q], rv, acc);
+                lo = hi;
+            }
+        }
+        const unsigned long long key = ((unsigned long long)acc << 32) | (unsigned)cand;
+        best = key < best ? key : best;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned long long o = __shfl_xor(best, m, 64);
+        best = o < best ? o : best;
+    }
+    if ((tid & 63) == 0) s_red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long b = s_red[0];
+        for (int i = 1; i < 4; i++) b = s_red[i] < b ? s_red[i] : b;
+        const int cand = (int)(unsigned)b;
+        const int ys = cand / saw, xs = cand - ys * saw;
+        best_sad[task] = (b >> 32) * 2ull;
+        mv[2 * task] = (int16_t)((xs + xo) << p.mv_shift);
+        mv[2 * task + 1] = (int16_t)((ys + yo) << p.mv_shift);
+    }
+}
+
 }  // namespace svtdev

@@ -343,6 +343,36 @@ int svt_hip_me_sb_search_planes_batch(const uint8_t *d_src_plane, uint32_t src_s
                                       uint32_t *d_best_sad, uint32_t *d_best_mv, size_t nblocks,
                                       void *stream);
 
+/* Hierarchical motion estimation, one LEVEL per call for all SBs (x references x search regions, as separate tasks) of a
+ * picture: HmeLevel0 / HmeLevel1 / HmeLevel2 (EbMotionEstimation.c:5689, 5883, 6016; called per SB at :7739-7830) INCLUDING
+ * the search-area placement and clipping the reference does per SB on the host (:5729-5798).  Per task t:
+ *   d_sb_origin[t] = (x, y) of the SB and d_sb_size[t] = (width, height), at the level's resolution (origin >> 2 / >> 1 / >> 0);
+ *   search centre  = d_centers[t] >> center_shift (NULL: (0, 0)): level 0 takes the caller's centre, level 1 the level-0
+ *                    result >> 1, level 2 the level-1 result (the reference's call sites), so the levels chain ON THE DEVICE;
+ *   d_src_pic / d_ref_pic point at sample (0, 0) of the level's source / padded reference picture (the reference buffer
+ *                    must be readable from -pad to size + pad, as the encoder's padded pictures are);
+ *   outputs        d_best_sad[t] (uint64: SAD on every other row x 2) and d_mv[t] = (x, y) scaled to full resolution -
+ *                    exactly hmeLevelNSad[][] and x/yHmeLevelNSearchCenter[][] of MotionEstimateLcu.
+ * params: svt_hip_hme_level_params() derives them from the encoder's context values. */
+typedef struct svt_hip_hme_params {
+    int32_t search_area_width, search_area_height;    /* before clipping: L0 ((w * mult / 100) + 15) & ~15, h * mult / 100; L1 / L2 (w + 7) & ~7, h */
+    int32_t x_origin_offset, y_origin_offset;         /* origin = offset + centre: L0 -(total * mult / 100 >> 1) + preceding regions; L1 / L2 -(area >> 1) */
+    int32_t pad_width, pad_height;                    /* reference origin - 1 (L0, L1), BLOCK_SIZE_64 - 1 (L2) */
+    int32_t ref_width, ref_height;                    /* reference picture size at this level */
+    int32_t round_down;                               /* 16 (L0) or 8: width rounded down after clipping unless smaller */
+    int32_t mv_shift;                                 /* 2, 1, 0 */
+} svt_hip_hme_params;
+int svt_hip_hme_level_params(int level, const uint16_t *hme_search_area_in_width_array,
+                             const uint16_t *hme_search_area_in_height_array, uint32_t region_in_width,
+                             uint32_t region_in_height, uint32_t level0_total_search_area_width,
+                             uint32_t level0_total_search_area_height, uint32_t search_area_multiplier_x,
+                             uint32_t search_area_multiplier_y, uint32_t ref_origin_x, uint32_t ref_origin_y,
+                             uint32_t ref_width, uint32_t ref_height, svt_hip_hme_params *params);
+int svt_hip_hme_level_batch(const uint8_t *d_src_pic, uint32_t src_stride, const uint8_t *d_ref_pic, uint32_t ref_stride,
+                            const int16_t *d_sb_origin, const uint16_t *d_sb_size, const int16_t *d_centers,
+                            int center_shift, const svt_hip_hme_params *params, uint64_t *d_best_sad, int16_t *d_mv,
+                            size_t ntasks, void *stream);
+
 /* K6 with the encoder's own result rows: d_best_sad / d_best_mv hold, per SB, pu_pitch uint32 whose first 85 (nsq = 0)
  * or 209 (nsq != 0) entries are MeContext_t.p_sb_best_sad[list][ref][..] / p_sb_best_mv[..] in EbMeTierZeroPu order
  * (EbMotionEstimationContext.h:47-270): 64x64, 32x32 x4, 16x16 x16, 8x8 x64 and, for the non-square search

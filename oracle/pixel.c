@@ -327,3 +327,74 @@ void svt_oracle_me_sb_search_full(const uint8_t *src, uint32_t src_stride, const
         }
     }
 }
+
+/* ---- hierarchical ME levels 0 / 1 / 2 (HmeLevel0 / HmeLevel1 / HmeLevel2, EbMotionEstimation.c:5689-6150) -----------
+ * One arithmetic serves the three levels; what differs is the parameter set (svt_oracle_hme_params_for_level):
+ *   search area before clipping  L0: width ((w[region] * mult / 100) + 15) & ~15, height h[region] * mult / 100
+ *                                L1 / L2: width (w + 7) & ~7, height h
+ *   origin = offset + centre     L0: -((total * mult / 100) >> 1) + sum of the preceding regions' widths; L1 / L2: -(area >> 1)
+ *   clipping against the reference picture with its padding (pad = origin - 1; level 2: BLOCK_SIZE_64 - 1), left / right,
+ *   top / bottom exactly in the reference's order (:5745-5798), then width rounded DOWN to a multiple of 16 (L0) / 8
+ *   unless it is smaller; search = sad_loop_kernel on EVERY OTHER ROW of the block (source and reference strides doubled,
+ *   candidate rows one reference row apart); results: SAD x 2, (x + origin) << mv_shift (x4, x2, x1). */
+typedef struct svt_oracle_hme_params {
+    int32_t search_area_width, search_area_height, x_origin_offset, y_origin_offset, pad_width, pad_height, ref_width,
+        ref_height, round_down, mv_shift;
+} svt_oracle_hme_params;
+
+void svt_oracle_hme_params_for_level(int level, const uint16_t *hme_w, const uint16_t *hme_h, uint32_t region_w,
+                                     uint32_t region_h, uint32_t total_w, uint32_t total_h, uint32_t mult_x,
+                                     uint32_t mult_y, uint32_t ref_origin_x, uint32_t ref_origin_y, uint32_t ref_width,
+                                     uint32_t ref_height, svt_oracle_hme_params *p) {
+    memset(p, 0, sizeof(*p));
+    p->ref_width = (int32_t)ref_width; p->ref_height = (int32_t)ref_height;
+    if (level == 0) {
+        p->search_area_width = (int16_t)((((hme_w[region_w] * mult_x) / 100) + 15) & ~0x0F);
+        p->search_area_height = (int16_t)((hme_h[region_h] * mult_y) / 100);
+        int xd = 0, yd = 0;
+        for (uint32_t i = 0; i < region_w; i++) xd += (int16_t)((hme_w[i] * mult_x) / 100);
+        for (uint32_t i = 0; i < region_h; i++) yd += (int16_t)((hme_h[i] * mult_y) / 100);
+        p->x_origin_offset = -(int16_t)(((total_w * mult_x) / 100) >> 1) + xd;
+        p->y_origin_offset = -(int16_t)(((total_h * mult_y) / 100) >> 1) + yd;
+        p->pad_width = (int32_t)ref_origin_x - 1; p->pad_height = (int32_t)ref_origin_y - 1;
+        p->round_down = 16; p->mv_shift = 2;
+    } else {
+        p->search_area_width = (int16_t)((hme_w[region_w] + 7) & ~0x07);
+        p->search_area_height = (int16_t)hme_h[region_h];
+        p->x_origin_offset = -(p->search_area_width >> 1);
+        p->y_origin_offset = -(p->search_area_height >> 1);
+        if (level == 1) { p->pad_width = (int32_t)ref_origin_x - 1; p->pad_height = (int32_t)ref_origin_y - 1; p->mv_shift = 1; }
+        else { p->pad_width = 63; p->pad_height = 63; p->mv_shift = 0; }
+        p->round_down = 8;
+    }
+}
+
+/* src_pic / ref_pic point at sample (0, 0) of the level's source / reference picture (the reference may be read from
+ * -pad .. size + search margins: the caller's buffer is padded as the encoder's pictures are). */
+void svt_oracle_hme_level(const uint8_t *src_pic, uint32_t src_stride, const uint8_t *ref_pic, uint32_t ref_stride,
+                          int origin_x, int origin_y, uint32_t sb_width, uint32_t sb_height, int x_center, int y_center,
+                          const svt_oracle_hme_params *p, uint64_t *best_sad, int16_t *x_out, int16_t *y_out) {
+    int saw = p->search_area_width, sah = p->search_area_height;
+    int xo = p->x_origin_offset + x_center, yo = p->y_origin_offset + y_center;
+    const int padw = p->pad_width, padh = p->pad_height, W = p->ref_width, H = p->ref_height;
+    /* the reference's statements, in its order (:5745-5798).  NB: the width / height statement of the left / top clip tests the
+     * ALREADY CORRECTED origin, so it never fires - the area keeps its size and slides; restated as written */
+    xo = (origin_x + xo < -padw) ? -padw - origin_x : xo;
+    saw = (origin_x + xo < -padw) ? saw - (-padw - (origin_x + xo)) : saw;
+    xo = (origin_x + xo > W - 1) ? xo - ((origin_x + xo) - (W - 1)) : xo;
+    if (origin_x + xo + saw > W) { const int v = saw - ((origin_x + xo + saw) - W); saw = v > 1 ? v : 1; }
+    if (saw >= p->round_down) saw &= ~(p->round_down - 1);
+    yo = (origin_y + yo < -padh) ? -padh - origin_y : yo;
+    sah = (origin_y + yo < -padh) ? sah - (-padh - (origin_y + yo)) : sah;
+    yo = (origin_y + yo > H - 1) ? yo - ((origin_y + yo) - (H - 1)) : yo;
+    if (origin_y + yo + sah > H) { const int v = sah - ((origin_y + yo + sah) - H); sah = v > 1 ? v : 1; }
+    const uint8_t *src = src_pic + (ptrdiff_t)origin_y * (ptrdiff_t)src_stride + origin_x;
+    const uint8_t *ref = ref_pic + (ptrdiff_t)(origin_y + yo) * (ptrdiff_t)ref_stride + (origin_x + xo);
+    int16_t bx = 0, by = 0;
+    uint64_t best;
+    svt_oracle_sad_loop(src, src_stride * 2, ref, ref_stride * 2, sb_height >> 1, sb_width, &best, &bx, &by, ref_stride, (int16_t)saw,
+                        (int16_t)sah);
+    *best_sad = best * 2;
+    *x_out = (int16_t)((bx + xo) << p->mv_shift);
+    *y_out = (int16_t)((by + yo) << p->mv_shift);
+}

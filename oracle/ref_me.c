@@ -63,3 +63,67 @@ int ref_me_fullpel(const uint8_t *src, uint32_t src_stride, const uint8_t *ref_o
     free(eight); free(c);
     return 0;
 }
+
+/* ---- hierarchical motion estimation levels 0 / 1 / 2: the reference's own HmeLevel0 / HmeLevel1 / HmeLevel2
+ * (EbMotionEstimation.c:5689, 5883, 6016) on one SB.  The context's intermediate SB buffers are filled exactly as
+ * MotionEstimationKernel does (EbMotionEstimationProcess.c:500-560): the 1/16 buffer holds every other row (stride 16),
+ * the 1/4 buffer and the full-resolution SB buffer hold every row (strides 32 / 64) and are read with doubled strides.
+ * src_pic points at sample (0, 0) of the level's SOURCE picture (origin_x / origin_y index it); ref_buffer is the level's
+ * padded REFERENCE buffer_y with its origin / size.  hme_w / hme_h: the context's per-region search-area arrays of the
+ * level (level 1: entry [region] too).  Outputs as the reference leaves them (SAD doubled, MV scaled to full resolution). */
+int ref_hme_level(int level, const uint8_t *src_pic, uint32_t src_stride, uint8_t *ref_buffer, uint32_t ref_stride,
+                  uint32_t ref_origin_x, uint32_t ref_origin_y, uint32_t ref_width, uint32_t ref_height, int origin_x,
+                  int origin_y, uint32_t sb_width, uint32_t sb_height, int x_center, int y_center, const uint16_t *hme_w,
+                  const uint16_t *hme_h, uint32_t region_w, uint32_t region_h, uint32_t total_w, uint32_t total_h,
+                  uint32_t mult_x, uint32_t mult_y, int asm_type, uint64_t *best_sad, int16_t *x_out, int16_t *y_out) {
+    MeContext_t *c = (MeContext_t *)calloc(1, sizeof(MeContext_t));
+    EbPictureBufferDesc_t *pic = (EbPictureBufferDesc_t *)calloc(1, sizeof(EbPictureBufferDesc_t));
+    uint8_t *sbuf = NULL;
+    if (!c || !pic || posix_memalign((void **)&sbuf, 64, 64 * 64)) { free(c); free(pic); return -1; }
+    memset(sbuf, 0, 64 * 64);
+    pic->buffer_y = ref_buffer;
+    pic->stride_y = (uint16_t)ref_stride;
+    pic->origin_x = (uint16_t)ref_origin_x;
+    pic->origin_y = (uint16_t)ref_origin_y;
+    pic->width = (uint16_t)ref_width;
+    pic->height = (uint16_t)ref_height;
+    const uint8_t *blk = src_pic + (ptrdiff_t)origin_y * (ptrdiff_t)src_stride + origin_x;
+    for (int i = 0; i < EB_HME_SEARCH_AREA_COLUMN_MAX_COUNT && i <= (int)region_w; i++) {
+        c->hme_level0_search_area_in_width_array[i] = hme_w[i];
+        c->hme_level1_search_area_in_width_array[i] = hme_w[i];
+        c->hme_level2_search_area_in_width_array[i] = hme_w[i];
+    }
+    for (int i = 0; i < EB_HME_SEARCH_AREA_ROW_MAX_COUNT && i <= (int)region_h; i++) {
+        c->hme_level0_search_area_in_height_array[i] = hme_h[i];
+        c->hme_level1_search_area_in_height_array[i] = hme_h[i];
+        c->hme_level2_search_area_in_height_array[i] = hme_h[i];
+    }
+    c->hme_level0_total_search_area_width = (uint16_t)total_w;
+    c->hme_level0_total_search_area_height = (uint16_t)total_h;
+    *best_sad = 0; *x_out = 0; *y_out = 0;
+    if (level == 0) {
+        c->sixteenth_sb_buffer = sbuf;
+        c->sixteenth_sb_buffer_stride = 16;
+        uint8_t *l = sbuf;
+        const uint8_t *f = blk;
+        for (uint32_t r = 0; r < sb_height; r += 2) { memcpy(l, f, sb_width); l += 16; f += (size_t)src_stride << 1; }
+        HmeLevel0(NULL, c, (int16_t)origin_x, (int16_t)origin_y, sb_width, sb_height, (int16_t)x_center, (int16_t)y_center, pic, region_w,
+                  region_h, best_sad, x_out, y_out, mult_x, mult_y, (EbAsm)asm_type);
+    } else if (level == 1) {
+        c->quarter_sb_buffer = sbuf;
+        c->quarter_sb_buffer_stride = 32;
+        for (uint32_t r = 0; r < sb_height; r++) memcpy(sbuf + 32 * r, blk + (size_t)r * src_stride, sb_width);
+        HmeLevel1(c, (int16_t)origin_x, (int16_t)origin_y, sb_width, sb_height, pic, (int16_t)hme_w[region_w], (int16_t)hme_h[region_h],
+                  (int16_t)x_center, (int16_t)y_center, best_sad, x_out, y_out, (EbAsm)asm_type);
+    } else {
+        c->sb_buffer = sbuf;
+        c->sb_buffer_stride = 64;
+        c->sb_src_ptr = sbuf;
+        c->sb_src_stride = 64;
+        for (uint32_t r = 0; r < sb_height; r++) memcpy(sbuf + 64 * r, blk + (size_t)r * src_stride, sb_width);
+        HmeLevel2(NULL, c, (int16_t)origin_x, (int16_t)origin_y, sb_width, sb_height, pic, region_w, region_h, (int16_t)x_center,
+                  (int16_t)y_center, best_sad, x_out, y_out, (EbAsm)asm_type);
+    }
+    free(sbuf); free(pic); free(c);
+    return 0;
+}

@@ -507,6 +507,57 @@ def gen_pins():
                 d[key + "_coeff"] = cos; d[key + "_dst_in"] = dst0; d[key + "_dst_out"] = dst1
     np.savez_compressed(os.path.join(HERE, "pins.npz"), **d)
 
+
+HME_FIELDS = ("level", "sb_w", "sb_h", "origin_x", "origin_y", "x_center", "y_center", "region_w", "region_h", "mult_x", "mult_y")
+
+
+def gen_hme():
+    """Hierarchical ME levels 0 / 1 / 2: the reference's OWN HmeLevel0 / HmeLevel1 / HmeLevel2
+    (EbMotionEstimation.c:5689, 5883, 6016) through oracle/ref_me.c, on one padded picture pair per level (1/16-, 1/4- and
+    full-resolution stand-ins of a 416x240 picture), incl. SBs at every picture edge (search-area clipping), partial SBs,
+    off-picture search centres, two search regions with area multipliers, ties (coarse content).  asm_type 0 (C / SSE4.1)
+    is stored; asm_type 1 is asserted equal except for 4-sample-wide blocks, where the AVX2 kernels are known to return
+    wrong SADs (same divergence as sad_loop_kernel_avx2_intrin at width 4)."""
+    rng = np.random.default_rng(13604)
+    d = {}
+    dims = {0: (104, 60, 16, 24), 1: (208, 120, 32, 40), 2: (416, 240, 64, 72)}        # level: W, H, SB size, padding
+    hme_w = np.array([40, 24], np.uint16); hme_h = np.array([20, 12], np.uint16)
+    d["hme_w"] = hme_w; d["hme_h"] = hme_h
+    for level, (W, H, sb, pad) in dims.items():
+        stride = W + 2 * pad + 5
+        ref_buf = rng.integers(0, 256, (H + 2 * pad, stride), dtype=np.uint8)
+        src = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        ref_buf[pad + H // 2:, :] = (ref_buf[pad + H // 2:, :] >> 6) << 6          # lower half coarse: ties
+        src[H // 2:, :] = (src[H // 2:, :] >> 6) << 6
+        ref_buf[pad + 8:pad + 8 + sb, pad + 20:pad + 20 + sb] = src[4:4 + sb, 10:10 + sb]   # an exact match somewhere
+        d[f"l{level}_src"] = src; d[f"l{level}_ref"] = ref_buf; d[f"l{level}_dims"] = np.array([W, H, sb, pad, stride], np.int32)
+        cases = []
+        xs = list(range(0, W - sb + 1, sb)) + ([W - (W % sb)] if W % sb else [])
+        ys = list(range(0, H - sb + 1, sb)) + ([H - (H % sb)] if H % sb else [])
+        for oy in ys:
+            for ox in xs:
+                sbw = min(sb, W - ox); sbh = min(sb, H - oy)
+                for (xc, yc) in ((0, 0), (int(rng.integers(-60, 60)), int(rng.integers(-40, 40)))):
+                    rw, rh = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+                    mx, my = (100, 100) if level else (int(rng.choice([100, 150])), int(rng.choice([100, 200])))
+                    cases.append((level, sbw, sbh, ox, oy, xc, yc, rw, rh, mx, my))
+        cases = np.array(cases, np.int32)
+        out = np.zeros((len(cases), 3), np.int64)
+        for i, (lv, sbw, sbh, ox, oy, xc, yc, rw, rh, mx, my) in enumerate(cases.tolist()):
+            res = []
+            for asm in (0, 1):
+                b = np.zeros(1, np.uint64); x = np.zeros(1, np.int16); y = np.zeros(1, np.int16)
+                rc = R.ref_hme_level(c_int(lv), ptr(src), c_int(W), ptr(ref_buf), c_int(stride), c_int(pad), c_int(pad), c_int(W), c_int(H),
+                                     c_int(ox), c_int(oy), c_int(sbw), c_int(sbh), c_int(xc), c_int(yc), ptr(hme_w), ptr(hme_h), c_int(rw), c_int(rh),
+                                     c_int(int(hme_w.sum())), c_int(int(hme_h.sum())), c_int(mx), c_int(my), c_int(asm), ptr(b), ptr(x), ptr(y))
+                assert rc == 0
+                res.append((int(b[0]), int(x[0]), int(y[0])))
+            if sbw != 4:
+                assert res[0] == res[1], (lv, sbw, sbh, ox, oy, res)
+            out[i] = res[0]
+        d[f"l{level}_cases"] = cases; d[f"l{level}_out"] = out
+    np.savez_compressed(os.path.join(HERE, "hme.npz"), **d)
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                    # one family only: python make_golden.py cfl_levels
         globals()["gen_" + sys.argv[1]]()
@@ -520,6 +571,7 @@ if __name__ == "__main__":
     gen_ois()
     gen_me()
     gen_pins()
+    gen_hme()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -91,3 +91,16 @@ def scan_tables(tx_size, tx_type):
     isc = np.zeros(1024, np.int16)
     n = L.svt_oracle_get_scan(tx_size, tx_type, ptr(sc), ptr(isc))
     return sc[:n].copy(), isc[:n].copy()
+
+
+class HmeParams(ctypes.Structure):
+    """svt_oracle_hme_params / svt_hip_hme_params (same layout)"""
+    _fields_ = [(n, ctypes.c_int32) for n in ("search_area_width", "search_area_height", "x_origin_offset", "y_origin_offset",
+                                              "pad_width", "pad_height", "ref_width", "ref_height", "round_down", "mv_shift")]
+
+
+def hme_params(level, hme_w, hme_h, region_w, region_h, mult_x, mult_y, pad, ref_w, ref_h):
+    p = HmeParams()
+    oracle().svt_oracle_hme_params_for_level(level, ptr(hme_w), ptr(hme_h), region_w, region_h, int(hme_w.sum()), int(hme_h.sum()),
+                                             mult_x, mult_y, pad, pad, ref_w, ref_h, ctypes.byref(p))
+    return p

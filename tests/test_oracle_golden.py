@@ -348,3 +348,21 @@ def test_inv_txfm2d_add_at_clamp_limits_golden():
             assert np.array_equal(d, g[key + "_dst_out"][i]), (key, i)
             n += 1
     assert n == 195
+
+
+def test_hme_levels_golden():
+    """n1: oracle HME level arithmetic (search-area derivation, clipping, sub-sampled SAD search, scaling) == the
+    reference's own HmeLevel0 / HmeLevel1 / HmeLevel2 on 3 x 56 SB / centre / region cases (tests/golden/hme.npz)"""
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "hme.npz"))
+    hme_w, hme_h = g["hme_w"], g["hme_h"]
+    for level in range(3):
+        W, H, sb, pad, stride = (int(v) for v in g[f"l{level}_dims"])
+        src = np.ascontiguousarray(g[f"l{level}_src"]); ref = np.ascontiguousarray(g[f"l{level}_ref"])
+        ref00 = ctypes.c_void_p(ref.ctypes.data + pad * stride + pad)
+        for case, exp in zip(g[f"l{level}_cases"].tolist(), g[f"l{level}_out"].tolist()):
+            lv, sbw, sbh, ox, oy, xc, yc, rw, rh, mx, my = case
+            p = svtlibs.hme_params(lv, hme_w, hme_h, rw, rh, mx, my, pad, W, H)
+            b = np.zeros(1, np.uint64); x = np.zeros(1, np.int16); y = np.zeros(1, np.int16)
+            O.svt_oracle_hme_level(ptr(src), W, ref00, stride, ox, oy, sbw, sbh, xc, yc, ctypes.byref(p), ptr(b), ptr(x), ptr(y))
+            assert [int(b[0]), int(x[0]), int(y[0])] == exp, case

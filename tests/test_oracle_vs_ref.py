@@ -363,3 +363,60 @@ def test_sad_variants_vs_reference():
         if fa is not None and w >= 32:
             fa.restype = ctypes.c_uint32
             assert fa(ptr(s), c_int(w + 3), ptr(refs[0]), c_int(w + 7)) == exp[0], (w, h, "avx2")
+
+
+def test_hme_levels_vs_reference_randomized():
+    """n1: HmeLevel0 / 1 / 2 (the reference's own functions, oracle/ref_me.c) on random pictures, SB positions incl. all
+    picture edges, partial SBs, search regions and multipliers, off-picture centres.  asm_type 1 is compared too except for
+    4-sample-wide blocks (AVX2 width-4 SAD kernels return wrong sums: DESIGN.md)."""
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(3)
+    checked = 0
+    for trial in range(160):
+        level = int(rng.integers(0, 3))
+        sbw = sbh = {0: 16, 1: 32, 2: 64}[level]
+        if trial % 5 == 0:
+            sbw = int(rng.choice({0: [4, 8, 12, 16], 1: [8, 16, 24, 32], 2: [16, 32, 40, 48, 56, 64]}[level]))
+        if trial % 7 == 0:
+            sbh = int(rng.choice({0: [4, 8, 16], 1: [8, 16, 32], 2: [16, 32, 64]}[level]))
+        W = int(rng.integers(sbw + 8, 200)); H = int(rng.integers(sbh + 8, 150))
+        pad = {0: 16, 1: 32, 2: 64}[level] + int(rng.integers(0, 20))
+        stride = W + 2 * pad + int(rng.integers(0, 7))
+        ref = rng.integers(0, 256, (H + 2 * pad, stride), dtype=np.uint8)
+        srcp = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        if trial % 3 == 0:
+            ref[:] = (ref >> 6) << 6; srcp[:] = (srcp >> 6) << 6
+        ox = int(rng.integers(0, W - sbw + 1)); oy = int(rng.integers(0, H - sbh + 1))
+        if trial % 4 == 0:
+            ox = 0
+        if trial % 4 == 1:
+            ox = W - sbw; oy = H - sbh
+        hw = rng.integers(4, 70, 2).astype(np.uint16); hh = rng.integers(2, 40, 2).astype(np.uint16)
+        rw = int(rng.integers(0, 2)); rh = int(rng.integers(0, 2))
+        mx = int(rng.choice([100, 100, 150, 200])); my = int(rng.choice([100, 100, 150]))
+        xc = int(rng.integers(-60, 60)); yc = int(rng.integers(-40, 40))
+        p = svtlibs.hme_params(level, hw, hh, rw, rh, mx, my, pad, W, H)
+        # reads must stay inside this test's buffer (the encoder's padding covers its own ranges): same arithmetic as the oracle
+        saw, sah = p.search_area_width, p.search_area_height
+        xo, yo = p.x_origin_offset + xc, p.y_origin_offset + yc
+        xo = -p.pad_width - ox if ox + xo < -p.pad_width else xo
+        xo = xo - ((ox + xo) - (W - 1)) if ox + xo > W - 1 else xo
+        saw = max(1, saw - ((ox + xo + saw) - W)) if ox + xo + saw > W else saw
+        yo = -p.pad_height - oy if oy + yo < -p.pad_height else yo
+        yo = yo - ((oy + yo) - (H - 1)) if oy + yo > H - 1 else yo
+        sah = max(1, sah - ((oy + yo + sah) - H)) if oy + yo + sah > H else sah
+        if ox + xo < -pad or ox + xo + saw - 1 + sbw > W + pad or oy + yo < -pad or oy + yo + sah - 1 + sbh > H + pad:
+            continue
+        ob = np.zeros(1, np.uint64); oxv = np.zeros(1, np.int16); oyv = np.zeros(1, np.int16)
+        O.svt_oracle_hme_level(ptr(srcp), W, ctypes.c_void_p(ref.ctypes.data + pad * stride + pad), stride, ox, oy, sbw, sbh, xc, yc, ctypes.byref(p),
+                               ptr(ob), ptr(oxv), ptr(oyv))
+        for asm in (0, 1):
+            if asm == 1 and sbw == 4:
+                continue
+            rb = np.zeros(1, np.uint64); rx = np.zeros(1, np.int16); ry = np.zeros(1, np.int16)
+            assert R.ref_hme_level(c_int(level), ptr(srcp), c_int(W), ptr(ref), c_int(stride), c_int(pad), c_int(pad), c_int(W), c_int(H), c_int(ox),
+                                   c_int(oy), c_int(sbw), c_int(sbh), c_int(xc), c_int(yc), ptr(hw), ptr(hh), c_int(rw), c_int(rh), c_int(int(hw.sum())),
+                                   c_int(int(hh.sum())), c_int(mx), c_int(my), c_int(asm), ptr(rb), ptr(rx), ptr(ry)) == 0
+            assert (rb[0], rx[0], ry[0]) == (ob[0], oxv[0], oyv[0]), (trial, level, asm, sbw, sbh)
+            checked += 1
+    assert checked > 150
