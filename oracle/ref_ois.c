@@ -44,6 +44,10 @@ void ref_ois_setup(void) {
         USE_C(aom_v_predictor_8x8); USE_C(aom_v_predictor_16x16);
         USE_C(aom_h_predictor_8x8); USE_C(aom_h_predictor_16x16);
         USE_C(aom_paeth_predictor_8x8);
+        USE_C(aom_dc_predictor_4x4); USE_C(aom_dc_top_predictor_4x4); USE_C(aom_dc_left_predictor_4x4);
+        USE_C(aom_dc_128_predictor_4x4); USE_C(aom_v_predictor_4x4); USE_C(aom_h_predictor_4x4);
+        USE_C(aom_highbd_dc_predictor_4x4); USE_C(aom_highbd_dc_predictor_8x8);
+        USE_C(aom_highbd_v_predictor_4x4); USE_C(aom_highbd_v_predictor_8x8);
 #undef USE_C
         init_intra_predictors_internal();
         g_ready = 1;

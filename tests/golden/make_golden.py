@@ -558,6 +558,68 @@ def gen_hme():
         d[f"l{level}_cases"] = cases; d[f"l{level}_out"] = out
     np.savez_compressed(os.path.join(HERE, "hme.npz"), **d)
 
+
+def gen_bip():
+    """a14 glue (VERDICT r1 missing #4): the reference's OWN has_top_right / has_bottom_left (every enumerated argument tuple,
+    packed bits), build_intra_predictors{,_high} and av1_predict_intra_block{,_16bit} (EbIntraPrediction.c:1567, 1755, 3667,
+    3857, 4078, 4336) through oracle/ref_intra.c.  The mode-info grids of the block cases are the pattern svtlibs.mi_pattern
+    builds from the stored key, so only the key travels."""
+    import svtlibs
+    from svtlibs import (BLOCK_W, BLOCK_H, TX_W, TX_H, availability_tuples, intra_block_case, mi_pattern, ref_predict_intra_block,
+                         aligned_array)
+    d = {}
+    for sb_bsize, sb_mi in ((12, 16), (15, 32)):
+        tr, bl = [], []
+        for args in availability_tuples(sb_mi):
+            tr.append(R.ref_has_top_right(sb_bsize, *args)); bl.append(R.ref_has_bottom_left(sb_bsize, *args))
+        d[f"has_tr_sb{sb_mi}"] = np.packbits(np.array(tr, np.uint8)); d[f"has_bl_sb{sb_mi}"] = np.packbits(np.array(bl, np.uint8))
+        d[f"avail_count_sb{sb_mi}"] = np.array([len(tr)], np.int64)
+    # build_intra_predictors: params / edges / packed outputs
+    rng = np.random.default_rng(3667)
+    prm, tops, lefts, outs = [], [], [], []
+    for trial in range(700):
+        s = trial % 19; w, h = TX_W[s], TX_H[s]
+        mode = (trial // 19) % 13 if trial < 19 * 13 * 2 else int(rng.integers(0, 13))
+        ad = int(rng.integers(-3, 4)) if 1 <= mode <= 8 else 0
+        is16 = int(rng.integers(0, 2)); bd = 10 if is16 else 8
+        top = rng.integers(0, 1 << bd, 176).astype(np.uint16); left = rng.integers(0, 1 << bd, 176).astype(np.uint16)
+        n_top = int(rng.choice([0, w])); n_left = int(rng.choice([0, h]))
+        if trial % 5 == 0:
+            n_top, n_left = w, h
+        if trial % 7 == 0:
+            n_top = int(rng.integers(1, w // 4 + 1)) * 4; n_left = int(rng.integers(1, h // 4 + 1)) * 4
+        n_tr = int(rng.choice([0, h, int(rng.integers(0, h + 1))])) if n_top == w else 0
+        n_bl = int(rng.choice([0, w, int(rng.integers(0, w + 1))])) if n_left == h else 0
+        dis = int(rng.integers(0, 4) == 0); ft = int(rng.integers(0, 2))
+        dt = np.uint16 if is16 else np.uint8; es = 2 if is16 else 1
+        t2 = top.astype(dt); l2 = left.astype(dt)
+        out = aligned_array((h, 128), dt)
+        R.ref_build_intra_predictors(is16, ctypes.c_void_p(t2.ctypes.data + 16 * es), ctypes.c_void_p(l2.ctypes.data + 16 * es), ptr(out), 128,
+                                     mode, ad, s, dis, n_top, n_tr, n_left, n_bl, ft, bd)
+        prm.append((is16, mode, ad, s, dis, n_top, n_tr, n_left, n_bl, ft, bd)); tops.append(top); lefts.append(left)
+        outs.append(out[:, :w].astype(np.uint16).ravel())
+    d["bip_params"] = np.array(prm, np.int32); d["bip_top"] = np.array(tops); d["bip_left"] = np.array(lefts)
+    d["bip_out"] = np.concatenate(outs)
+    # av1_predict_intra_block{,_16bit}
+    rng = np.random.default_rng(4078)
+    prm, tops, lefts, outs = [], [], [], []
+    trial = 0
+    while len(prm) < 300:
+        trial += 1
+        c = intra_block_case(rng, trial)
+        if c is None:
+            continue
+        key = int(rng.integers(0, 8))
+        c["mi_mode"], c["mi_uv_mode"] = mi_pattern(c["mi_rows"], c["mi_cols"], key)
+        got = ref_predict_intra_block(R, c)
+        prm.append((c["is16"], c["mi_rows"], c["mi_cols"], c["plane"], c["bsize"], c["partition"], c["tx"], c["mirow"], c["micol"], c["col_off"],
+                    c["row_off"], c["wpx"], c["hpx"], c["mode"], c["angle_delta"], *c["tile"].tolist(), key))
+        tops.append(c["top"].astype(np.uint16)); lefts.append(c["left"].astype(np.uint16)); outs.append(got.astype(np.uint16).ravel())
+    d["pib_params"] = np.array(prm, np.int32); d["pib_top"] = np.array(tops); d["pib_left"] = np.array(lefts)
+    d["pib_out"] = np.concatenate(outs)
+    np.savez_compressed(os.path.join(HERE, "bip.npz"), **d)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                    # one family only: python make_golden.py cfl_levels
         globals()["gen_" + sys.argv[1]]()
@@ -572,6 +634,7 @@ if __name__ == "__main__":
     gen_me()
     gen_pins()
     gen_hme()
+    gen_bip()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -104,3 +104,177 @@ def hme_params(level, hme_w, hme_h, region_w, region_h, mult_x, mult_y, pad, ref
     oracle().svt_oracle_hme_params_for_level(level, ptr(hme_w), ptr(hme_h), region_w, region_h, int(hme_w.sum()), int(hme_h.sum()),
                                              mult_x, mult_y, pad, pad, ref_w, ref_h, ctypes.byref(p))
     return p
+
+
+# ---- intra neighbour-availability cases (av1_predict_intra_block, EbIntraPrediction.c:4078) ----------------------
+BLOCK_W = [4, 4, 8, 8, 8, 16, 16, 16, 32, 32, 32, 64, 64, 64, 128, 128, 4, 16, 8, 32, 16, 64]
+BLOCK_H = [4, 8, 4, 8, 16, 8, 16, 32, 16, 32, 64, 32, 64, 128, 64, 128, 16, 4, 32, 8, 64, 16]
+# PART shape (EbDefinitions.h PART_N .. PART_S) of an AV1 PartitionType, the inverse of from_shape_to_part (EbIntraPrediction.c:42)
+SHAPE_OF_PARTITION = {0: 0, 1: 1, 2: 2, 4: 3, 5: 4, 6: 5, 7: 6, 8: 7, 9: 8, 3: 9}
+
+
+def aligned_array(shape, dt, al=64):
+    """zeroed numpy array whose data pointer is `al`-byte aligned (the reference's SIMD kernels use aligned stores)"""
+    n = int(np.prod(shape)) * np.dtype(dt).itemsize
+    raw = np.zeros(n + al, np.uint8)
+    off = (-raw.ctypes.data) % al
+    return raw[off:off + n].view(dt).reshape(shape)
+
+
+def partitions_for(bsize):
+    """partition types a block of this size can come from (VERT_A / VERT_B: squares >= 8x8 and vertical rectangles only,
+    get_has_tr_table :1552)"""
+    parts = [0, 1, 2, 3, 4, 5, 8, 9]
+    if 1 <= bsize < 16 and BLOCK_W[bsize] <= BLOCK_H[bsize]:
+        parts += [6, 7]
+    return parts
+
+
+def intra_block_case(rng, trial):
+    """one random prediction block of a random picture: dict of the arguments av1_predict_intra_block{,_16bit} takes
+    (None when the draw is not a block the encoder would predict)"""
+    is16 = int(rng.integers(0, 2))
+    mi_rows = int(rng.integers(8, 41)) * 2
+    mi_cols = int(rng.integers(8, 41)) * 2
+    plane = int(rng.integers(0, 3))
+    ss = 1 if plane else 0
+    bsize = int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16, 17, 18, 19, 20, 21]))
+    bw, bh = BLOCK_W[bsize] // 4, BLOCK_H[bsize] // 4
+    mirow = int(rng.integers(0, (mi_rows - 1) // bh + 1)) * bh
+    micol = int(rng.integers(0, (mi_cols - 1) // bw + 1)) * bw
+    if trial % 3 == 0:
+        mirow = min(mirow, int(rng.integers(0, 3)) * bh)
+    if trial % 4 == 0:
+        micol = min(micol, int(rng.integers(0, 3)) * bw)
+    if ss and (((bh & 1) and not (mirow & 1)) or ((bw & 1) and not (micol & 1))):
+        return None                                  # not a chroma reference block (:4200)
+    part = int(rng.choice(partitions_for(bsize)))
+    wpx, hpx = max(BLOCK_W[bsize] >> ss, 4), max(BLOCK_H[bsize] >> ss, 4)
+    cands = [t for t in range(19) if TX_W[t] <= wpx and TX_H[t] <= hpx
+             and ((TX_W[t] == min(wpx, 64) and TX_H[t] == min(hpx, 64)) or rng.integers(0, 4) == 0)]
+    if not cands:
+        return None
+    tx = int(rng.choice(cands))
+    co = int(rng.integers(0, wpx // TX_W[tx])) * (TX_W[tx] // 4)
+    ro = int(rng.integers(0, hpx // TX_H[tx])) * (TX_H[tx] // 4)
+    if ((micol * 4) >> ss) + co * 4 >= (mi_cols * 4 >> ss) or ((mirow * 4) >> ss) + ro * 4 >= (mi_rows * 4 >> ss):
+        return None                                  # transform block wholly outside the picture
+    mode = int(rng.integers(0, 13))
+    ad = int(rng.integers(-3, 4)) if (1 <= mode <= 8 and not plane) else 0
+    tile = np.array([0, mi_rows, 0, mi_cols], np.int32)
+    if is16 and trial % 5 == 0:
+        tile = np.array([(mirow // 16) * 16 if rng.integers(0, 2) else 0, mi_rows,
+                         (micol // 16) * 16 if rng.integers(0, 2) else 0, mi_cols], np.int32)
+    bd = 10 if is16 else 8
+    dt = np.uint16 if is16 else np.uint8
+    return dict(is16=is16, bd=bd, mi_rows=mi_rows, mi_cols=mi_cols, plane=plane, bsize=bsize, partition=part, tx=tx,
+                mirow=mirow, micol=micol, col_off=co, row_off=ro, wpx=wpx, hpx=hpx, mode=mode, angle_delta=ad, tile=tile,
+                mi_mode=rng.choice([0, 1, 2, 9, 10, 11, 12, 4], mi_rows * mi_cols).astype(np.uint8),
+                mi_uv_mode=rng.choice([0, 1, 2, 9, 10, 11, 12, 4], mi_rows * mi_cols).astype(np.uint8),
+                top=rng.integers(0, 1 << bd, 16 + 1 + 2 * 128 + 47).astype(dt),
+                left=rng.integers(0, 1 << bd, 16 + 1 + 2 * 128 + 47).astype(dt))
+
+
+def ref_predict_intra_block(R, c):
+    """the reference's own av1_predict_intra_block{,_16bit} on case c (oracle/ref_intra.c); returns the predicted block"""
+    ss = 1 if c["plane"] else 0
+    dt = np.uint16 if c["is16"] else np.uint8
+    es = np.dtype(dt).itemsize
+    ox = oy = 64
+    pw, ph = (c["mi_cols"] * 4 >> ss) + 2 * ox, (c["mi_rows"] * 4 >> ss) + 2 * oy
+    stride = (pw + 63) // 64 * 64
+    rec = aligned_array((ph, stride), dt)
+    x, y = c["micol"] * 4, c["mirow"] * 4
+    tp = ctypes.c_void_p(c["top"].ctypes.data + 17 * es)        # the caller's topNeighArray + 1 (EbCodingLoop.c:2902)
+    lp = ctypes.c_void_p(c["left"].ctypes.data + 17 * es)
+    R.ref_predict_intra_block(c["is16"], 12, c["mi_rows"], c["mi_cols"], ptr(c["mi_mode"]), ptr(c["mi_uv_mode"]), ptr(c["tile"]),
+                              SHAPE_OF_PARTITION[c["partition"]], c["bsize"], c["tx"], c["mode"], c["angle_delta"], c["plane"],
+                              x, y, c["col_off"], c["row_off"], c["wpx"], c["hpx"], tp, lp, ptr(rec), stride, ox, oy)
+    px = (((x >> 3) << 3) >> 1) if ss else x
+    py = (((y >> 3) << 3) >> 1) if ss else y
+    w, h = TX_W[c["tx"]], TX_H[c["tx"]]
+    got = rec[oy + py:oy + py + h, ox + px:ox + px + w].copy()
+    rec[oy + py:oy + py + h, ox + px:ox + px + w] = 0
+    assert not rec.any(), "the reference wrote outside the block"
+    return got
+
+
+def oracle_predict_intra_block(O, c):
+    """(prediction, out5) of the oracle's availability + build_intra_predictors restatement on case c"""
+    dt = np.uint16 if c["is16"] else np.uint8
+    es = np.dtype(dt).itemsize
+    out5 = np.zeros(5, np.int32)
+    O.svt_oracle_intra_neighbor_px(c["is16"], 16, c["mi_rows"], c["mi_cols"], ptr(c["mi_mode"]), ptr(c["mi_uv_mode"]), ptr(c["tile"]),
+                                   c["partition"], c["bsize"], c["tx"], c["plane"], c["micol"] * 4, c["mirow"] * 4, c["col_off"],
+                                   c["row_off"], c["wpx"], c["hpx"], ptr(out5))
+    w, h = TX_W[c["tx"]], TX_H[c["tx"]]
+    d = np.zeros((h, w), dt)
+    tp = ctypes.c_void_p(c["top"].ctypes.data + 17 * es)
+    lp = ctypes.c_void_p(c["left"].ctypes.data + 17 * es)
+    O.svt_oracle_build_intra_predictors(c["is16"], tp, lp, ptr(d), w, c["mode"], c["angle_delta"], c["tx"], 0, int(out5[0]),
+                                        int(out5[1]), int(out5[2]), int(out5[3]), int(out5[4]), c["bd"])
+    return d, out5
+
+
+def mi_pattern(mi_rows, mi_cols, key):
+    """deterministic mode-info grids (luma modes, chroma modes) of the committed block fixtures"""
+    ch = np.array([0, 1, 2, 9, 10, 11, 12, 4], np.uint8)
+    r = np.arange(mi_rows)[:, None]; c = np.arange(mi_cols)[None, :]
+    return (np.ascontiguousarray(ch[(r * 7 + c * 13 + key) % 8]).ravel(), np.ascontiguousarray(ch[(r * 5 + c * 11 + key + 3) % 8]).ravel())
+
+
+def availability_tuples(sb_mi):
+    """the argument tuples (bsize, mi_row, mi_col, 1, 1, partition, tx, row_off, col_off, ss_x, ss_y) the has_top_right /
+    has_bottom_left fixtures enumerate, in the order their packed bits are stored"""
+    for bsize in range(22):
+        if BLOCK_W[bsize] > sb_mi * 4 or BLOCK_H[bsize] > sb_mi * 4:
+            continue
+        bw, bh = BLOCK_W[bsize] // 4, BLOCK_H[bsize] // 4
+        for part in partitions_for(bsize):
+            for r in range(0, sb_mi, bh):
+                for c in range(0, sb_mi, bw):
+                    for tx in range(19):
+                        if TX_W[tx] > BLOCK_W[bsize] or TX_H[tx] > BLOCK_H[bsize]:
+                            continue
+                        for ss in (0, 1):
+                            if ss and (BLOCK_W[bsize] < 8 or BLOCK_H[bsize] < 8):
+                                continue
+                            tw, th = TX_W[tx] // 4, TX_H[tx] // 4
+                            offs = [(0, 0)]
+                            if tw < max(bw >> ss, 1):
+                                offs.append((0, tw))
+                            if th < max(bh >> ss, 1):
+                                offs.append((th, 0))
+                            if tw < max(bw >> ss, 1) and th < max(bh >> ss, 1):
+                                offs.append((th, tw))
+                            for ro, co in offs:
+                                yield (bsize, 64 + r, 96 + c, 1, 1, part, tx, ro, co, ss, ss)
+
+
+def bip_fixture_cases(g):
+    """(params dict, top, left, expected block) of the build_intra_predictors fixture cases; top / left are arrays of the
+    case's sample type whose element 16 is the reference's above_ref[0] / left_ref[0] (element 15 = the corner)"""
+    off = 0
+    for p, top, left in zip(g["bip_params"].tolist(), g["bip_top"], g["bip_left"]):
+        is16, mode, ad, s, dis, n_top, n_tr, n_left, n_bl, ft, bd = p
+        w, h = TX_W[s], TX_H[s]
+        dt = np.uint16 if is16 else np.uint8
+        exp = g["bip_out"][off:off + w * h].reshape(h, w).astype(dt)
+        off += w * h
+        yield (dict(is16=is16, mode=mode, angle_delta=ad, tx=s, disable_edge_filter=dis, n_top=n_top, n_tr=n_tr, n_left=n_left,
+                    n_bl=n_bl, filt_type=ft, bd=bd), top.astype(dt), left.astype(dt), exp)
+
+
+def pib_fixture_cases(g):
+    """(case dict as intra_block_case builds it, expected block) of the av1_predict_intra_block fixture cases"""
+    off = 0
+    for p, top, left in zip(g["pib_params"].tolist(), g["pib_top"], g["pib_left"]):
+        (is16, mi_rows, mi_cols, plane, bsize, part, tx, mirow, micol, co, ro, wpx, hpx, mode, ad, t0, t1, t2, t3, key) = p
+        dt = np.uint16 if is16 else np.uint8
+        w, h = TX_W[tx], TX_H[tx]
+        exp = g["pib_out"][off:off + w * h].reshape(h, w).astype(dt)
+        off += w * h
+        mm, mu = mi_pattern(mi_rows, mi_cols, key)
+        yield (dict(is16=is16, bd=10 if is16 else 8, mi_rows=mi_rows, mi_cols=mi_cols, plane=plane, bsize=bsize, partition=part, tx=tx,
+                    mirow=mirow, micol=micol, col_off=co, row_off=ro, wpx=wpx, hpx=hpx, mode=mode, angle_delta=ad,
+                    tile=np.array([t0, t1, t2, t3], np.int32), mi_mode=mm, mi_uv_mode=mu, top=top.astype(dt), left=left.astype(dt)), exp)

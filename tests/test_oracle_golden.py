@@ -366,3 +366,46 @@ def test_hme_levels_golden():
             b = np.zeros(1, np.uint64); x = np.zeros(1, np.int16); y = np.zeros(1, np.int16)
             O.svt_oracle_hme_level(ptr(src), W, ref00, stride, ox, oy, sbw, sbh, xc, yc, ctypes.byref(p), ptr(b), ptr(x), ptr(y))
             assert [int(b[0]), int(x[0]), int(y[0])] == exp, case
+
+
+def test_intra_availability_golden():
+    """has_top_right / has_bottom_left: every enumerated argument tuple against the reference's table look-ups (packed bits)"""
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "bip.npz"))
+    for sb_mi in (16, 32):
+        n = int(g[f"avail_count_sb{sb_mi}"][0])
+        tr = np.unpackbits(g[f"has_tr_sb{sb_mi}"])[:n]
+        bl = np.unpackbits(g[f"has_bl_sb{sb_mi}"])[:n]
+        i = 0
+        for args in svtlibs.availability_tuples(sb_mi):
+            assert O.svt_oracle_has_top_right(sb_mi, *args) == tr[i], args
+            assert O.svt_oracle_has_bottom_left(sb_mi, *args) == bl[i], args
+            i += 1
+        assert i == n
+
+
+def test_build_intra_predictors_golden():
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "bip.npz"))
+    n = 0
+    for p, top, left, exp in svtlibs.bip_fixture_cases(g):
+        es = top.dtype.itemsize
+        h, w = exp.shape
+        d = np.zeros((h, w), top.dtype)
+        O.svt_oracle_build_intra_predictors(p["is16"], ctypes.c_void_p(top.ctypes.data + 16 * es), ctypes.c_void_p(left.ctypes.data + 16 * es),
+                                            ptr(d), w, p["mode"], p["angle_delta"], p["tx"], p["disable_edge_filter"], p["n_top"], p["n_tr"],
+                                            p["n_left"], p["n_bl"], p["filt_type"], p["bd"])
+        assert np.array_equal(d, exp), p
+        n += 1
+    assert n == 700
+
+
+def test_predict_intra_block_golden():
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "bip.npz"))
+    n = 0
+    for c, exp in svtlibs.pib_fixture_cases(g):
+        got, out5 = svtlibs.oracle_predict_intra_block(O, c)
+        assert np.array_equal(got, exp), ({k: v for k, v in c.items() if np.isscalar(v)}, out5)
+        n += 1
+    assert n == 300

@@ -420,3 +420,88 @@ def test_hme_levels_vs_reference_randomized():
             assert (rb[0], rx[0], ry[0]) == (ob[0], oxv[0], oyv[0]), (trial, level, asm, sbw, sbh)
             checked += 1
     assert checked > 150
+
+
+def test_has_top_right_bottom_left_vs_reference_tables():
+    """the oracle replays the coding order; the reference looks it up in has_tr_* / has_bl_* bit tables
+    (EbIntraPrediction.c:1435-1826).  Every block size x position in the superblock x partition x transform size x offset."""
+    from svtlibs import BLOCK_W, BLOCK_H, partitions_for
+    O = svtlibs.oracle()
+    n = 0
+    for sb_bsize, sb_mi in ((12, 16), (15, 32)):
+        for bsize in range(22):
+            if BLOCK_W[bsize] > sb_mi * 4 or BLOCK_H[bsize] > sb_mi * 4:
+                continue
+            bw, bh = BLOCK_W[bsize] // 4, BLOCK_H[bsize] // 4
+            for part in partitions_for(bsize):
+                for r in range(0, sb_mi, bh):
+                    for c in range(0, sb_mi, bw):
+                        for tx in range(19):
+                            if TX_W[tx] > BLOCK_W[bsize] or TX_H[tx] > BLOCK_H[bsize]:
+                                continue
+                            if (r + c + tx + part) % 3:            # a third of the transform sizes per position keeps this in seconds
+                                continue
+                            for ss in (0, 1):
+                                if ss and (BLOCK_W[bsize] < 8 or BLOCK_H[bsize] < 8):
+                                    continue
+                                tw, th = TX_W[tx] // 4, TX_H[tx] // 4
+                                offs = [(0, 0)]
+                                if tw < max(bw >> ss, 1):
+                                    offs.append((0, tw))
+                                if th < max(bh >> ss, 1):
+                                    offs.append((th, 0))
+                                for ro, co in offs:
+                                    args = (bsize, 64 + r, 96 + c, 1, 1, part, tx, ro, co, ss, ss)
+                                    assert R.ref_has_top_right(sb_bsize, *args) == O.svt_oracle_has_top_right(sb_mi, *args), args
+                                    assert R.ref_has_bottom_left(sb_bsize, *args) == O.svt_oracle_has_bottom_left(sb_mi, *args), args
+                                    n += 1
+    assert n > 50000
+
+
+def test_build_intra_predictors_vs_reference_randomized():
+    """build_intra_predictors{,_high} (EbIntraPrediction.c:3667, 3857) through oracle/ref_intra.c: every mode, size, angle delta,
+    availability pattern (none / full / partial counts), edge-filter type and switch, 8 and 10 bit"""
+    from svtlibs import aligned_array
+    O = svtlibs.oracle(); P = ptr
+    rng = np.random.default_rng(9)
+    seen = set()
+    for trial in range(6000):
+        s = int(rng.integers(0, 19)); w, h = TX_W[s], TX_H[s]
+        mode = int(rng.integers(0, 13)); ad = int(rng.integers(-3, 4)) if 1 <= mode <= 8 else 0
+        is16 = int(rng.integers(0, 2)); bd = 10 if is16 else 8
+        dt = np.uint16 if is16 else np.uint8
+        top = rng.integers(0, 1 << bd, 16 + 2 * 64 + 32).astype(dt); left = rng.integers(0, 1 << bd, 16 + 2 * 64 + 32).astype(dt)
+        n_top = int(rng.choice([0, w])); n_left = int(rng.choice([0, h]))
+        if trial % 5 == 0:
+            n_top, n_left = w, h
+        if trial % 7 == 0:
+            n_top = int(rng.integers(1, w // 4 + 1)) * 4; n_left = int(rng.integers(1, h // 4 + 1)) * 4
+        n_tr = int(rng.choice([0, h, int(rng.integers(0, h + 1))])) if n_top == w else 0      # :3974 asserts n_top_px == txwpx
+        n_bl = int(rng.choice([0, w, int(rng.integers(0, w + 1))])) if n_left == h else 0
+        dis = int(rng.integers(0, 4) == 0); ft = int(rng.integers(0, 2))
+        es = 2 if is16 else 1
+        tp = ctypes.c_void_p(top.ctypes.data + 16 * es); lp = ctypes.c_void_p(left.ctypes.data + 16 * es)
+        d1 = aligned_array((h, 128), dt); d2 = aligned_array((h, 128), dt)
+        R.ref_build_intra_predictors(is16, tp, lp, P(d1), 128, mode, ad, s, dis, n_top, n_tr, n_left, n_bl, ft, bd)
+        O.svt_oracle_build_intra_predictors(is16, tp, lp, P(d2), 128, mode, ad, s, dis, n_top, n_tr, n_left, n_bl, ft, bd)
+        assert np.array_equal(d1, d2), (TX_SIZES[s], mode, ad, is16, n_top, n_tr, n_left, n_bl, dis, ft)
+        seen.add((s, mode))
+    assert len(seen) == 19 * 13
+
+
+def test_predict_intra_block_vs_reference_randomized():
+    """av1_predict_intra_block / av1_predict_intra_block_16bit (EbIntraPrediction.c:4078, 4336) end to end: picture position ->
+    availability -> sample counts -> edge preparation -> prediction, luma and chroma, picture and tile borders"""
+    from svtlibs import intra_block_case, ref_predict_intra_block, oracle_predict_intra_block
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(5)
+    n = 0
+    for trial in range(5000):
+        c = intra_block_case(rng, trial)
+        if c is None:
+            continue
+        got = ref_predict_intra_block(R, c)
+        exp, out5 = oracle_predict_intra_block(O, c)
+        assert np.array_equal(got, exp), ({k: v for k, v in c.items() if np.isscalar(v)}, out5)
+        n += 1
+    assert n > 3500
