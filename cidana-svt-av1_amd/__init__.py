@@ -120,6 +120,11 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_me_fullpel_search_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_void_p, c_uint32, c_size_t, c_void_p,
                                                   c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_uint32,
                                                   c_size_t, c_void_p]
+    L.svt_hip_build_intra_predictors_batch.argtypes = [c_void_p, c_int32, c_size_t, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int,
+                                                       c_int, c_int, c_size_t, c_void_p]
+    L.svt_hip_intra_neighbor_px.argtypes = [c_void_p, c_void_p]
+    L.svt_hip_intra_has_top_right.argtypes = [c_int] * 12
+    L.svt_hip_intra_has_bottom_left.argtypes = [c_int] * 12
     return L
 
 
@@ -558,6 +563,43 @@ class SvtHipDsp:
                                                      ctypes.byref(params), self._p(best), self._p(mv), n, self._stream()),
                     "svt_hip_hme_level_batch")
         return best, mv
+
+    class IntraPos(ctypes.Structure):
+        """svt_hip_intra_pos: where one prediction block sits (the arguments of av1_predict_intra_block, EbIntraPrediction.c:4078)"""
+        _fields_ = [(n, ctypes.c_int32) for n in ("is_16bit", "sb_size_mi", "mi_rows", "mi_cols", "tile_mi_row_start", "tile_mi_row_end",
+                                                  "tile_mi_col_start", "tile_mi_col_end", "partition", "bsize", "tx_size", "plane",
+                                                  "bl_org_x_pict", "bl_org_y_pict", "col_off", "row_off", "wpx", "hpx")]
+
+    class IntraBlk(ctypes.Structure):
+        """svt_hip_intra_blk: per-block descriptor of svt_hip_build_intra_predictors_batch"""
+        _fields_ = [("mode", ctypes.c_uint8), ("angle_delta", ctypes.c_int8), ("filt_type", ctypes.c_uint8),
+                    ("disable_edge_filter", ctypes.c_uint8), ("n_top_px", ctypes.c_uint8), ("n_topright_px", ctypes.c_uint8),
+                    ("n_left_px", ctypes.c_uint8), ("n_bottomleft_px", ctypes.c_uint8)]
+
+    def intra_neighbor_px(self, pos):
+        """HOST: (n_top_px, n_topright_px, n_left_px, n_bottomleft_px) of one prediction block (svt_hip_intra_neighbor_px)"""
+        blk = self.IntraBlk()
+        self._check(self.lib.svt_hip_intra_neighbor_px(ctypes.addressof(pos), ctypes.addressof(blk)), "svt_hip_intra_neighbor_px")
+        return blk.n_top_px, blk.n_topright_px, blk.n_left_px, blk.n_bottomleft_px
+
+    def build_intra_predictors(self, top_neigh, left_neigh, blocks, tx_size, bd=8, dst=None, dst_stride=None, dst_offsets=None):
+        """build_intra_predictors{,_high} on a batch (svt_hip_build_intra_predictors_batch).  top_neigh / left_neigh: uint8 or int16
+        (uint16 values) [n, pitch] with element 0 = the corner sample; blocks: uint8 [n, 8] descriptors (IntraBlk layout).
+        -> dst [n, h, w] (dense) unless dst / dst_offsets address a picture."""
+        t = self.torch
+        n = top_neigh.shape[0]
+        is16 = top_neigh.dtype != t.uint8
+        w, h = TX_W[tx_size], TX_H[tx_size]
+        if dst is None:
+            dst = t.empty((n, h, w), dtype=top_neigh.dtype, device=top_neigh.device)
+            dst_stride, pitch = w, w * h
+        else:
+            pitch = 0 if dst_offsets is not None else h * dst_stride
+        self._check(self.lib.svt_hip_build_intra_predictors_batch(self._p(dst), dst_stride, pitch, self._p(dst_offsets) if dst_offsets is not None else None,
+                                                                  self._p(top_neigh), self._p(left_neigh), top_neigh.shape[1], self._p(blocks),
+                                                                  tx_size, int(is16), bd, n, self._stream()),
+                    "svt_hip_build_intra_predictors_batch")
+        return dst
 
     ME_PUS_ALL = 209
     FLAVOUR_C, FLAVOUR_AVX2 = 0, 1

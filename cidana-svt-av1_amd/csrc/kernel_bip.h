@@ -1,0 +1,268 @@
+// kernel_bip.h — build_intra_predictors / build_intra_predictors_high (EbIntraPrediction.c:3667-3855, 3857-4076) for a
+// batch of prediction blocks of one transform size, fused into one launch: edge selection and extension, corner, the
+// directional modes' smoothing filters and 2x up-sampling, DC by availability, and the prediction.
+//
+// One WAVE per block, four blocks per workgroup.  Both edges of a block live in LDS as 16-bit samples (at most
+// 16 + 2*64 + 16 each) and go through the reference's stages in place; every stage is a read phase into registers, a
+// barrier and a write phase, so the result is what the reference's sequential loops produce.  The stage sequence (and so
+// the number of barriers) is the same for every wave whatever its block's mode; stages a block does not need are
+// predicated off.  Output: 4 samples per lane per step (one 4- or 8-byte store when the address allows).
+//
+// Write-bound like the other predictors (1-2 B out per pixel, ~2(W+H) samples in per block) but with per-block modes the
+// kernel cannot be specialised per mode the way intra_pred_kernel is; it is the encode-pass glue, not the search loop.
+#pragma once
+#include "kernel_intra.h"
+
+namespace svtdev {
+
+struct BipBlk {                 // == svt_hip_intra_blk
+    uint8_t mode;
+    int8_t angle_delta;
+    uint8_t filt_type, disable_edge_filter;
+    uint8_t n_top_px, n_topright_px, n_left_px, n_bottomleft_px;
+};
+static_assert(sizeof(BipBlk) == 8, "descriptor layout");
+
+// dr_intra_derivative (EbIntraPrediction.c:299; AV1 spec 7.11.2.4): defined at the 27 angles the prediction can take
+__device__ __forceinline__ int bip_dr_derivative(int angle) {
+    constexpr uint16_t v[27] = {1023, 547, 372, 273, 215, 178, 151, 132, 116, 102, 90, 80, 71, 64, 57, 51, 45, 40, 35, 31, 27, 23, 19, 15, 11, 7, 3};
+    constexpr uint8_t a[27] = {3, 6, 9, 14, 17, 20, 23, 26, 29, 32, 36, 39, 42, 45, 48, 51, 54, 58, 61, 64, 67, 70, 73, 76, 81, 84, 87};
+    int r = 1;
+#pragma unroll
+    for (int i = 0; i < 27; i++) r = a[i] == angle ? (int)v[i] : r;
+    return r;
+}
+// intra_edge_filter_strength (:225-268)
+__device__ __forceinline__ int bip_filter_strength(int bs0, int bs1, int delta, int type) {
+    const int d = abs(delta), wh = bs0 + bs1;
+    int s = 0;
+    if (type == 0) {
+        if (wh <= 8) s = d >= 56;
+        else if (wh <= 16) s = d >= 40;
+        else if (wh <= 24) s = d >= 32 ? 3 : (d >= 16 ? 2 : (d >= 8 ? 1 : 0));
+        else if (wh <= 32) s = d >= 32 ? 3 : (d >= 4 ? 2 : (d >= 1 ? 1 : 0));
+        else s = d >= 1 ? 3 : 0;
+    } else {
+        if (wh <= 8) s = d >= 64 ? 2 : (d >= 40 ? 1 : 0);
+        else if (wh <= 16) s = d >= 48 ? 2 : (d >= 20 ? 1 : 0);
+        else if (wh <= 24) s = d >= 4 ? 3 : 0;
+        else s = d >= 1 ? 3 : 0;
+    }
+    return s;
+}
+// use_intra_edge_upsample (:167-172)
+__device__ __forceinline__ int bip_use_upsample(int bs0, int bs1, int delta, int type) {
+    const int d = abs(delta), wh = bs0 + bs1;
+    if (d <= 0 || d >= 40) return 0;
+    return type ? (wh <= 8) : (wh <= 16);
+}
+
+constexpr int BIP_EDGE = 16 + 160;          // staged samples per edge: positions [-16, 160)
+constexpr int BIP_WAVES = 4;
+
+template <typename PixT>
+__global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
+    PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
+    const PixT* __restrict__ top_all, const PixT* __restrict__ left_all, int32_t neigh_pitch, const BipBlk* __restrict__ blks,
+    int w, int h, int bd, uint32_t nblocks) {
+    __shared__ uint16_t s_edge[BIP_WAVES][2][BIP_EDGE];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t blk_id = blockIdx.x * BIP_WAVES + (uint32_t)wv;
+    const bool live = blk_id < nblocks;
+    const uint32_t b = live ? blk_id : 0u;                    // a spare wave replays block 0 without storing
+    const BipBlk d = blks[b];
+    const PixT* __restrict__ top = top_all + (size_t)b * neigh_pitch + 1;       // element 0 is the corner: top[-1]
+    const PixT* __restrict__ left = left_all + (size_t)b * neigh_pitch + 1;
+    uint16_t* A = s_edge[wv][0] + 16;
+    uint16_t* L = s_edge[wv][1] + 16;
+    const int maxv = (1 << bd) - 1, base = 128 << (bd - 8);
+
+    const int mode = d.mode > 12 ? 12 : d.mode;
+    const int n_top = min((int)d.n_top_px, w), n_left = min((int)d.n_left_px, h);
+    const int n_tr = min((int)d.n_topright_px, w), n_bl = min((int)d.n_bottomleft_px, h);
+    const int ft = d.filt_type ? 1 : 0;
+    const bool is_dr = mode >= 1 && mode <= 8;
+    // extend_modes (:1410-1424) and the directional angle classes (:3702-3722)
+    bool need_left, need_above, need_above_left, need_right, need_bottom;
+    int p_angle = 0;
+    if (is_dr) {
+        const int delta = max(-3, min(3, (int)d.angle_delta));
+        const int ang[9] = {0, 90, 180, 45, 135, 113, 157, 203, 67};      // mode_to_angle_map (EbCodingUnit.h:129)
+        int a0 = 0;
+#pragma unroll
+        for (int i = 1; i < 9; i++) a0 = i == mode ? ang[i] : a0;
+        p_angle = a0 + 3 * delta;
+        need_above = p_angle < 180; need_left = p_angle > 90; need_above_left = true;
+        need_right = p_angle < 90; need_bottom = p_angle > 180;
+    } else {
+        need_left = true; need_above = true;                  // DC, SMOOTH*, PAETH (V / H are directional here)
+        need_above_left = mode == 12;
+        need_right = false; need_bottom = false;
+    }
+    const bool const_fill = (!need_above && n_left == 0) || (!need_left && n_top == 0);
+    const int const_val = need_left ? (n_top > 0 ? (int)top[0] : base + 1) : (n_left > 0 ? (int)left[0] : base - 1);
+
+    // ---- stage 1: edge extension (:3747-3800) -----------------------------------------------------------------
+    {
+        const int need_l = need_left ? h + (need_bottom ? w : 0) : 0;
+        const int avail_l = (need_bottom && n_bl > 0) ? h + n_bl : n_left;
+        const int def_l = n_top > 0 ? (int)top[0] : base + 1;
+        for (int i = lane; i < need_l; i += 64) L[i] = (uint16_t)(n_left > 0 ? (int)left[min(i, avail_l - 1)] : def_l);
+        const int need_a = need_above ? w + (need_right ? h : 0) : 0;
+        const int avail_a = (need_right && n_tr > 0) ? n_top + n_tr : n_top;
+        const int def_a = n_left > 0 ? (int)left[0] : base - 1;
+        for (int i = lane; i < need_a; i += 64) A[i] = (uint16_t)(n_top > 0 ? (int)top[min(i, avail_a - 1)] : def_a);
+        if (lane == 0 && need_above_left) {
+            const int c = (n_top > 0 && n_left > 0) ? (int)top[-1] : (n_top > 0 ? (int)top[0] : (n_left > 0 ? (int)left[0] : base));
+            A[-1] = (uint16_t)c; L[-1] = (uint16_t)c;
+        }
+    }
+    __syncthreads();
+    const bool filt = is_dr && !d.disable_edge_filter && !const_fill;
+    const bool angled = filt && p_angle != 90 && p_angle != 180;
+    // ---- stage 2: corner filter (filter_intra_edge_corner, :3383) ----------------------------------------------------
+    if (angled && need_above && need_left && w + h >= 24 && lane == 0) {
+        const int s = ((int)L[0] * 5 + (int)A[-1] * 6 + (int)A[0] * 5 + 8) >> 4;
+        A[-1] = (uint16_t)s; L[-1] = (uint16_t)s;
+    }
+    __syncthreads();
+    // ---- stage 3: edge smoothing (av1_filter_intra_edge, :3539): sample 0 of the run is kept ---------------------------
+    {
+        const int ab_le = need_above_left ? 1 : 0;
+        const int sa = (angled && need_above && n_top > 0) ? bip_filter_strength(w, h, p_angle - 90, ft) : 0;
+        const int sl = (angled && need_left && n_left > 0) ? bip_filter_strength(h, w, p_angle - 180, ft) : 0;
+        const int na = n_top + ab_le + (need_right ? h : 0), nl = n_left + ab_le + (need_bottom ? w : 0);      // <= 129
+        int va[3], vl[3];
+        auto taps = [](const uint16_t* p, int i, int sz, int st) {
+            const int k0 = st == 3 ? 2 : 0, k1 = st == 2 ? 5 : 4, k2 = st == 1 ? 8 : (st == 2 ? 6 : 4);
+            auto at = [&](int q) { return (int)p[min(max(q, 0), sz - 1)]; };
+            return (k0 * at(i - 2) + k1 * at(i - 1) + k2 * at(i) + k1 * at(i + 1) + k0 * at(i + 2) + 8) >> 4;
+        };
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int i = lane + 64 * t;
+            va[t] = (sa && i >= 1 && i < na) ? taps(A - ab_le, i, na, sa) : -1;
+            vl[t] = (sl && i >= 1 && i < nl) ? taps(L - ab_le, i, nl, sl) : -1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int i = lane + 64 * t;
+            if (va[t] >= 0) A[i - ab_le] = (uint16_t)va[t];
+            if (vl[t] >= 0) L[i - ab_le] = (uint16_t)vl[t];
+        }
+    }
+    __syncthreads();
+    // ---- stage 4: 2x up-sampling (av1_upsample_intra_edge, :3597): p[-2 .. 2 sz - 2] from p[-1 .. sz - 1] ---------------
+    const int up_a = (filt && need_above) ? bip_use_upsample(w, h, p_angle - 90, ft) : 0;
+    const int up_l = (filt && need_left) ? bip_use_upsample(h, w, p_angle - 180, ft) : 0;
+    {
+        const int sza = w + (need_right ? h : 0), szl = h + (need_bottom ? w : 0);                 // <= 16 when up-sampling
+        int ia[4] = {0, 0, 0, 0}, il[4] = {0, 0, 0, 0};
+        auto in_at = [](const uint16_t* p, int k, int sz) { return (int)p[k < 2 ? -1 : (k < sz + 2 ? k - 2 : sz - 1)]; };
+        if (up_a && lane < sza)
+#pragma unroll
+            for (int k = 0; k < 4; k++) ia[k] = in_at(A, lane + k, sza);
+        if (up_l && lane < szl)
+#pragma unroll
+            for (int k = 0; k < 4; k++) il[k] = in_at(L, lane + k, szl);
+        __syncthreads();
+        if (up_a && lane < sza) {
+            if (lane == 0) A[-2] = (uint16_t)ia[0];
+            A[2 * lane - 1] = (uint16_t)min(max((-ia[0] + 9 * ia[1] + 9 * ia[2] - ia[3] + 8) >> 4, 0), maxv);
+            A[2 * lane] = (uint16_t)ia[2];
+        }
+        if (up_l && lane < szl) {
+            if (lane == 0) L[-2] = (uint16_t)il[0];
+            L[2 * lane - 1] = (uint16_t)min(max((-il[0] + 9 * il[1] + 9 * il[2] - il[3] + 8) >> 4, 0), maxv);
+            L[2 * lane] = (uint16_t)il[2];
+        }
+    }
+    __syncthreads();
+    // ---- stage 5: prediction ---------------------------------------------------------------------------------------------
+    // resolve to one of the predictor kinds
+    int kind, dx = 1, dy = 1;
+    if (const_fill) kind = IM_DC_128;
+    else if (is_dr) {
+        if (p_angle == 90) kind = IM_V;
+        else if (p_angle == 180) kind = IM_H;
+        else if (p_angle < 90) { kind = IM_Z1; dx = bip_dr_derivative(p_angle); }
+        else if (p_angle < 180) { kind = IM_Z2; dx = bip_dr_derivative(180 - p_angle); dy = bip_dr_derivative(p_angle - 90); }
+        else { kind = IM_Z3; dy = bip_dr_derivative(270 - p_angle); }
+    } else if (mode == 0) kind = n_left > 0 ? (n_top > 0 ? IM_DC : IM_DC_LEFT) : (n_top > 0 ? IM_DC_TOP : IM_DC_128);       // dc_pred[left][top], :3851
+    else kind = mode == 9 ? IM_SMOOTH : (mode == 10 ? IM_SMOOTH_V : (mode == 11 ? IM_SMOOTH_H : IM_PAETH));
+    int dc = const_fill ? const_val : base;
+    if (kind == IM_DC || kind == IM_DC_TOP || kind == IM_DC_LEFT) {
+        const int na = kind != IM_DC_LEFT ? w : 0, nl = kind != IM_DC_TOP ? h : 0;
+        int sum = 0;
+        for (int i = lane; i < na + nl; i += 64) sum += i < na ? (int)A[i] : (int)L[i - na];
+        for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+        dc = (sum + ((na + nl) >> 1)) / (na + nl);
+    }
+    const size_t boff = dst_offsets ? (size_t)dst_offsets[b] : (size_t)b * dst_block_pitch;
+    PixT* __restrict__ out = dst + boff;
+    const int wq = w >> 2, items = wq * h;
+    const int wq_shift = __builtin_ctz((uint32_t)wq);
+    const int bl_s = (int)L[h - 1], tr_s = (int)A[w - 1], tl_s = (int)A[-1];
+    for (int q = lane; q < items; q += 64) {
+        const int r = q >> wq_shift, c0 = (q & (wq - 1)) << 2;
+        int px[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = c0 + k;
+            int v;
+            switch (kind) {
+            case IM_V: v = A[c]; break;
+            case IM_H: v = L[r]; break;
+            case IM_SMOOTH: {
+                const int wh = kSmWeights[h + r], ww = kSmWeights[w + c];
+                v = (wh * (int)A[c] + (256 - wh) * bl_s + ww * (int)L[r] + (256 - ww) * tr_s + 256) >> 9;
+            } break;
+            case IM_SMOOTH_V: { const int wh = kSmWeights[h + r]; v = (wh * (int)A[c] + (256 - wh) * bl_s + 128) >> 8; } break;
+            case IM_SMOOTH_H: { const int ww = kSmWeights[w + c]; v = (ww * (int)L[r] + (256 - ww) * tr_s + 128) >> 8; } break;
+            case IM_PAETH: {
+                const int t = A[c], l = L[r], pb = t + l - tl_s;
+                const int pl = abs(pb - l), pt = abs(pb - t), ptl = abs(pb - tl_s);
+                v = (pl <= pt && pl <= ptl) ? l : (pt <= ptl ? t : tl_s);
+            } break;
+            case IM_Z1: {     // av1_dr_prediction_z1 (:370 / :3394)
+                const int max_base = (w + h - 1) << up_a;
+                const int x = dx * (r + 1), bs = (x >> (6 - up_a)) + (c << up_a), sh = ((x << up_a) & 0x3f) >> 1;
+                v = bs < max_base ? ((int)A[bs] * (32 - sh) + (int)A[bs + 1] * sh + 16) >> 5 : (int)A[max_base];
+                v = min(v, maxv);
+            } break;
+            case IM_Z3: {     // av1_dr_prediction_z3 (:447 / :3475)
+                const int max_base = (w + h - 1) << up_l;
+                const int y = dy * (c + 1), bs = (y >> (6 - up_l)) + (r << up_l), sh = ((y << up_l) & 0x3f) >> 1;
+                v = bs < max_base ? ((int)L[bs] * (32 - sh) + (int)L[bs + 1] * sh + 16) >> 5 : (int)L[max_base];
+                v = min(v, maxv);
+            } break;
+            case IM_Z2: {     // av1_dr_prediction_z2 (:405 / :3431)
+                const int x = -dx * (r + 1), base1 = (x >> (6 - up_a)) + (c << up_a);
+                if (base1 >= -(1 << up_a)) {
+                    const int sh = ((x * (1 << up_a)) & 0x3f) >> 1;
+                    v = ((int)A[base1] * (32 - sh) + (int)A[base1 + 1] * sh + 16) >> 5;
+                } else {
+                    const int y = (r << 6) - dy * (c + 1), base2 = y >> (6 - up_l), sh = ((y * (1 << up_l)) & 0x3f) >> 1;
+                    v = ((int)L[base2] * (32 - sh) + (int)L[base2 + 1] * sh + 16) >> 5;
+                }
+                v = min(v, maxv);
+            } break;
+            default: v = dc; break;          // IM_DC, IM_DC_TOP, IM_DC_LEFT, IM_DC_128 and the constant fill
+            }
+            px[k] = v;
+        }
+        if (live) {
+            PixT* o = out + (size_t)r * dst_stride + c0;
+            if ((reinterpret_cast<uintptr_t>(o) & (4 * sizeof(PixT) - 1)) == 0) {
+                if (sizeof(PixT) == 1) *reinterpret_cast<uint32_t*>(o) = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)px[3] << 24);
+                else *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)px[0] | ((uint32_t)px[1] << 16), (uint32_t)px[2] | ((uint32_t)px[3] << 16));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[k] = (PixT)px[k];
+            }
+        }
+    }
+}
+
+}  // namespace svtdev

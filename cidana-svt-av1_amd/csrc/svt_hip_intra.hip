@@ -3,6 +3,7 @@
 #include "host_common.h"
 #include "kernel_cfl.h"
 #include "kernel_intra.h"
+#include "kernel_bip.h"
 #include "kernel_ois.h"
 
 using namespace svtdev;
@@ -242,6 +243,36 @@ extern "C" int svt_hip_upsample_intra_edge_batch(void* d_edges, int32_t nb_pitch
 
 // ===========================================================================
 // (A) drop-in entry points: host pointers, one block, synchronous
+// ---- build_intra_predictors{,_high} for a batch (EbIntraPrediction.c:3667-4076), see kernel_bip.h ----
+static_assert(sizeof(svt_hip_intra_blk) == sizeof(BipBlk), "svt_hip_intra_blk layout");
+extern "C" int svt_hip_build_intra_predictors_batch(void* d_dst, int32_t dst_stride, size_t dst_block_pitch,
+                                                    const uint32_t* d_dst_offsets, const void* d_top_neigh,
+                                                    const void* d_left_neigh, int32_t neigh_pitch,
+                                                    const svt_hip_intra_blk* d_blocks, int tx_size, int is_16bit, int bd,
+                                                    size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_dst || !d_top_neigh || !d_left_neigh || !d_blocks) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (tx_size < 0 || tx_size >= SVT_TX_SIZES_ALL) return set_err(SVT_HIP_ERR_INVALID, "tx_size %d", tx_size);
+    if ((is_16bit && bd != 10 && bd != 12 && bd != 8) || (!is_16bit && bd != 8)) return set_err(SVT_HIP_ERR_INVALID, "bit depth %d", bd);
+    const int w = kTxW[tx_size], h = kTxH[tx_size];
+    if (neigh_pitch < 1 + 2 * (w > h ? w : h)) return set_err(SVT_HIP_ERR_INVALID, "neigh_pitch %d < %d", neigh_pitch, 1 + 2 * (w > h ? w : h));
+    if (dst_stride < w) return set_err(SVT_HIP_ERR_INVALID, "dst_stride %d < width %d", dst_stride, w);
+    if (!d_dst_offsets && dst_block_pitch == 0) return set_err(SVT_HIP_ERR_INVALID, "dst_block_pitch 0 without offsets");
+    const size_t grid = (nblocks + BIP_WAVES - 1) / BIP_WAVES;
+    if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+    hipStream_t s = (hipStream_t)stream;
+    if (is_16bit)
+        hipLaunchKernelGGL(bip_kernel<uint16_t>, dim3((uint32_t)grid), dim3(64 * BIP_WAVES), 0, s, (uint16_t*)d_dst, dst_stride, dst_block_pitch,
+                           d_dst_offsets, (const uint16_t*)d_top_neigh, (const uint16_t*)d_left_neigh, neigh_pitch, (const BipBlk*)d_blocks, w, h,
+                           bd, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL(bip_kernel<uint8_t>, dim3((uint32_t)grid), dim3(64 * BIP_WAVES), 0, s, (uint8_t*)d_dst, dst_stride, dst_block_pitch,
+                           d_dst_offsets, (const uint8_t*)d_top_neigh, (const uint8_t*)d_left_neigh, neigh_pitch, (const BipBlk*)d_blocks, w, h,
+                           bd, (uint32_t)nblocks);
+    return launch_status("build_intra_predictors");
+}
+
 // ---- open-loop intra search ----
 static size_t ois_nb_pitch(uint32_t bsize) { return (size_t)NB_ORIGIN + 4 * bsize + 16; }     // multiple of 16
 static size_t ois_align(size_t v) { return (v + 255) & ~(size_t)255; }

@@ -501,6 +501,57 @@ int svt_hip_intra_pred_batch(void *d_dst, int32_t dst_stride, size_t dst_block_p
                              int32_t nb_pitch, int mode, int bw, int bh, int upsample_above,
                              int upsample_left, int dx, int dy, int is_16bit, int bd,
                              size_t nblocks, void *stream);
+/* build_intra_predictors / build_intra_predictors_high (EbIntraPrediction.c:3667-3855, 3857-4076): the
+ * neighbour-availability glue of av1_predict_intra_block, fused into ONE launch for a batch of prediction blocks of one
+ * transform size with per-block mode and availability.  Per block: which edges the mode needs, the constant fill when the
+ * needed edge is missing, edge extension (last available sample replicated; base +- 1 defaults), the corner sample, for
+ * directional modes the corner / edge smoothing filters and 2x up-sampling chosen from size, angle and filt_type, DC by
+ * availability, then the prediction itself.
+ *   d_top_neigh / d_left_neigh: the caller's topNeighArray / leftNeighArray (EbCodingLoop.c:2862-2893), one per block,
+ *     `neigh_pitch` samples apart: element 0 = the above-left corner sample, element 1 + i = above[i] / left[i];
+ *     neigh_pitch >= 1 + 2 * max(width, height).  Samples uint8 (is_16bit = 0, bd 8) or uint16.
+ *   d_blocks: one descriptor per block (device memory); counts larger than the block allows are clamped.
+ *   Destination addressing as in svt_hip_inv_txfm2d_add_batch. */
+typedef struct svt_hip_intra_blk {
+    uint8_t mode;                 /* AV1 PredictionMode: DC 0, V 1, H 2, D45 3, D135 4, D113 5, D157 6, D203 7, D67 8,
+                                     SMOOTH 9, SMOOTH_V 10, SMOOTH_H 11, PAETH 12 */
+    int8_t angle_delta;           /* -3 .. 3 (directional modes; angle = mode_to_angle_map[mode] + 3 * delta) */
+    uint8_t filt_type;            /* get_filt_type (:146): 1 when the above or left block is a smooth-mode block */
+    uint8_t disable_edge_filter;
+    uint8_t n_top_px, n_topright_px, n_left_px, n_bottomleft_px;   /* available samples (svt_hip_intra_neighbor_px) */
+} svt_hip_intra_blk;
+int svt_hip_build_intra_predictors_batch(void *d_dst, int32_t dst_stride, size_t dst_block_pitch,
+                                         const uint32_t *d_dst_offsets, const void *d_top_neigh,
+                                         const void *d_left_neigh, int32_t neigh_pitch,
+                                         const svt_hip_intra_blk *d_blocks, int tx_size, int is_16bit, int bd,
+                                         size_t nblocks, void *stream);
+
+/* HOST helper, no device work: the first half of av1_predict_intra_block / av1_predict_intra_block_16bit
+ * (EbIntraPrediction.c:4078-4333, 4336-4566) - up / left availability from the block's mode-info position,
+ * has_top_right (:1567) and has_bottom_left (:1755), and the four sample counts handed to build_intra_predictors.
+ * The reference reads "is that neighbour block already coded" from bit tables (has_tr_* / has_bl_*); here it is the
+ * comparison of two coding-order keys (Morton order of the enclosing squares; PARTITION_VERT_A / VERT_B visit the last
+ * split column first).  is_16bit selects the tile handling of the 16-bit function (the 8-bit one treats the picture as
+ * one tile, :4124-4137).  Fills blk->n_*_px; returns SVT_HIP_OK or SVT_HIP_ERR_INVALID. */
+typedef struct svt_hip_intra_pos {
+    int32_t is_16bit;
+    int32_t sb_size_mi;                       /* mi_size_high[sb_size]: 16 (64x64 superblocks) or 32 */
+    int32_t mi_rows, mi_cols;                 /* Av1Common */
+    int32_t tile_mi_row_start, tile_mi_row_end, tile_mi_col_start, tile_mi_col_end;   /* TileInfo */
+    int32_t partition;                        /* AV1 PartitionType (from_shape_to_part[blk_geom->shape]) */
+    int32_t bsize;                            /* AV1 block_size, BLOCK_4X4 = 0 .. BLOCK_64X16 = 21 */
+    int32_t tx_size, plane;
+    int32_t bl_org_x_pict, bl_org_y_pict;     /* luma sample position of the block */
+    int32_t col_off, row_off;                 /* transform block offset inside the block, 4-sample units of the plane */
+    int32_t wpx, hpx;                         /* block size in samples of the plane */
+} svt_hip_intra_pos;
+int svt_hip_intra_neighbor_px(const svt_hip_intra_pos *pos, svt_hip_intra_blk *blk);
+int svt_hip_intra_has_top_right(int sb_size_mi, int bsize, int mi_row, int mi_col, int top_available, int right_available,
+                                int partition, int tx_size, int row_off, int col_off, int ss_x, int ss_y);
+int svt_hip_intra_has_bottom_left(int sb_size_mi, int bsize, int mi_row, int mi_col, int bottom_available,
+                                  int left_available, int partition, int tx_size, int row_off, int col_off, int ss_x,
+                                  int ss_y);
+
 /* av1_filter_intra_edge{,_high} / av1_upsample_intra_edge{,_high} (aom_dsp_rtcd.h:152,
  * 431; C: EbIntraPrediction.c:3539-3660) on nblocks edges laid out like d_above. */
 int svt_hip_filter_intra_edge_batch(void *d_edges, int32_t nb_pitch, int sz, int strength,

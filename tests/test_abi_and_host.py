@@ -213,3 +213,48 @@ def test_c_caller_compiles_and_links_against_the_library(tmp_path):
         pytest.skip("a GPU is present: tests/test_gpu_dropin.py runs it")
     pr = subprocess.run([exe], capture_output=True, text=True)
     assert pr.returncode == 3, (pr.returncode, pr.stdout, pr.stderr)      # 3 = override refused (no device), nothing called
+
+
+def test_intra_availability_host_helper_equals_reference_tables_and_oracle(pkg):
+    """svt_hip_intra_has_top_right / _has_bottom_left (coding-order keys, csrc/host_tables.cpp) against every enumerated look-up of
+    the reference's has_tr_* / has_bl_* tables (tests/golden/bip.npz), and svt_hip_intra_neighbor_px against the oracle's
+    restatement of av1_predict_intra_block's availability half on the committed block cases and on random ones"""
+    import numpy as np
+    import svtlibs
+    lib = pkg.load_library()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bip.npz"))
+    for sb_mi in (16, 32):
+        n = int(g[f"avail_count_sb{sb_mi}"][0])
+        tr = np.unpackbits(g[f"has_tr_sb{sb_mi}"])[:n]
+        bl = np.unpackbits(g[f"has_bl_sb{sb_mi}"])[:n]
+        i = 0
+        for args in svtlibs.availability_tuples(sb_mi):
+            assert lib.svt_hip_intra_has_top_right(sb_mi, *args) == tr[i], args
+            assert lib.svt_hip_intra_has_bottom_left(sb_mi, *args) == bl[i], args
+            i += 1
+        assert i == n
+    # arguments the reference asserts on are refused, not answered
+    assert lib.svt_hip_intra_has_top_right(16, 0, 64, 96, 1, 1, 6, 0, 0, 0, 0, 0) < 0          # 4x4 has no VERT_A order
+    assert lib.svt_hip_intra_has_top_right(24, 3, 64, 96, 1, 1, 0, 0, 0, 0, 0, 0) < 0
+    O = svtlibs.oracle()
+    H = pkg.SvtHipDsp.__new__(pkg.SvtHipDsp)          # host helpers only: no device
+    H.lib = lib
+
+    def product_px(c):
+        pos = pkg.SvtHipDsp.IntraPos(c["is16"], 16, c["mi_rows"], c["mi_cols"], int(c["tile"][0]), int(c["tile"][1]), int(c["tile"][2]),
+                                     int(c["tile"][3]), c["partition"], c["bsize"], c["tx"], c["plane"], c["micol"] * 4, c["mirow"] * 4,
+                                     c["col_off"], c["row_off"], c["wpx"], c["hpx"])
+        blk = pkg.SvtHipDsp.IntraBlk()
+        assert lib.svt_hip_intra_neighbor_px(ctypes.addressof(pos), ctypes.addressof(blk)) == 0
+        return [blk.n_top_px, blk.n_topright_px, blk.n_left_px, blk.n_bottomleft_px]
+
+    cases = [c for c, _ in svtlibs.pib_fixture_cases(g)]
+    rng = np.random.default_rng(77)
+    for trial in range(4000):
+        c = svtlibs.intra_block_case(rng, trial)
+        if c is not None:
+            cases.append(c)
+    assert len(cases) > 3000
+    for c in cases:
+        _, out5 = svtlibs.oracle_predict_intra_block(O, c)
+        assert product_px(c) == out5[:4].tolist(), {k: v for k, v in c.items() if np.isscalar(v)}
