@@ -589,7 +589,7 @@ class SvtHipDsp:
         t = self.torch
         n = top_neigh.shape[0]
         is16 = top_neigh.dtype != t.uint8
-        w, h = TX_W[tx_size], TX_H[tx_size]
+        w, h = (TX_W[tx_size], TX_H[tx_size]) if 0 <= tx_size < 19 else (4, 4)        # the library reports a bad tx_size
         if dst is None:
             dst = t.empty((n, h, w), dtype=top_neigh.dtype, device=top_neigh.device)
             dst_stride, pitch = w, w * h

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
 
     const int mode = d.mode > 12 ? 12 : d.mode;
     const int n_top = min((int)d.n_top_px, w), n_left = min((int)d.n_left_px, h);
-    const int n_tr = min((int)d.n_topright_px, w), n_bl = min((int)d.n_bottomleft_px, h);
+    // (the edge loops below never read past need - 1 <= w + h - 1, so the two corner counts need no clamp)
+    const int n_tr = d.n_topright_px, n_bl = d.n_bottomleft_px;
     const int ft = d.filt_type ? 1 : 0;
     const bool is_dr = mode >= 1 && mode <= 8;
     // extend_modes (:1410-1424) and the directional angle classes (:3702-3722)

@@ -510,7 +510,7 @@ int svt_hip_intra_pred_batch(void *d_dst, int32_t dst_stride, size_t dst_block_p
  *   d_top_neigh / d_left_neigh: the caller's topNeighArray / leftNeighArray (EbCodingLoop.c:2862-2893), one per block,
  *     `neigh_pitch` samples apart: element 0 = the above-left corner sample, element 1 + i = above[i] / left[i];
  *     neigh_pitch >= 1 + 2 * max(width, height).  Samples uint8 (is_16bit = 0, bd 8) or uint16.
- *   d_blocks: one descriptor per block (device memory); counts larger than the block allows are clamped.
+ *   d_blocks: one descriptor per block (device memory); n_top_px / n_left_px above the block's width / height are clamped.
  *   Destination addressing as in svt_hip_inv_txfm2d_add_batch. */
 typedef struct svt_hip_intra_blk {
     uint8_t mode;                 /* AV1 PredictionMode: DC 0, V 1, H 2, D45 3, D135 4, D113 5, D157 6, D203 7, D67 8,

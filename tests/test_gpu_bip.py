@@ -92,10 +92,8 @@ def test_build_intra_predictors_random_batches_vs_oracle(dsp, is16):
             mode = i % 13
             ad = int(rng.integers(-3, 4)) if 1 <= mode <= 8 else 0
             n_top = int(rng.choice([0, w, int(rng.integers(1, w // 4 + 1)) * 4])); n_left = int(rng.choice([0, h, int(rng.integers(1, h // 4 + 1)) * 4]))
-            n_tr = int(rng.choice([0, h, int(rng.integers(0, min(w, h) + 1))])) if n_top == w else 0
-            n_tr = min(n_tr, w)
-            n_bl = int(rng.choice([0, w, int(rng.integers(0, min(w, h) + 1))])) if n_left == h else 0
-            n_bl = min(n_bl, h)
+            n_tr = int(rng.choice([0, h, int(rng.integers(0, h + 1))])) if n_top == w else 0
+            n_bl = int(rng.choice([0, w, int(rng.integers(0, w + 1))])) if n_left == h else 0
             dis = int(rng.integers(0, 5) == 0); ft = int(rng.integers(0, 2))
             d = np.zeros((h, w), dt)
             O.svt_oracle_build_intra_predictors(is16, ctypes.c_void_p(tops[i].ctypes.data + 16 * es), ctypes.c_void_p(lefts[i].ctypes.data + 16 * es),
