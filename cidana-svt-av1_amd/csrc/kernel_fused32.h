@@ -254,6 +254,29 @@ __global__ __launch_bounds__(F32_WAVES * 64, MIN_WAVES_PER_SIMD) void fwd32_kern
     }
 }
 
+
+// One 32-point inverse pass of a lane (row or column x[0..31], raw as loaded): input clamp + idct32 / identity.
+// Clamp-free fast path: with L1 = sum |x[i]|, every stage clamp of idct32 is a no-op while gain * L1 + slack <= the stage bound
+// (txfm_net.clamp_free_bound, constants in gen/txfm1d_gen.h) and, L1 bounding every element, so is the input clamp when
+// L1 <= the input bound.  The test is wave-uniform (one ballot); a wave with a louder row / column runs the clamped form.
+// 32 v_sad_u32 + xor (~86 issue units) buy 160 v_med3_i32 (~272).  g_tune "no_clamp_free" (FAST = false) keeps the old form.
+template <int IN_BITS, int STAGE_BITS, bool FAST>
+__device__ __forceinline__ void idct32_pass(int (&x)[32], int is_idtx, int in_lo, int in_hi, int st_lo, int st_hi) {
+    constexpr int in_max = (1 << (IN_BITS - 1)) - 1, st_max = (1 << (STAGE_BITS - 1)) - 1;
+    constexpr int lim_net = svtgen::svt_clamp_free_l1(svtgen::svt_idct32_gain_q10, svtgen::svt_idct32_slack, st_max);
+    constexpr int lim = lim_net < in_max ? lim_net : in_max;
+    if (FAST && !is_idtx) {
+        const int l1 = svtgen::svt_l1<32>(x);
+        if (__builtin_amdgcn_ballot_w64(l1 > lim) == 0) {
+            svtgen::svt_idct32<12, false, false>(x, 0, 0);
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; i++) x[i] = svtgen::svt_clamp(x[i], in_lo, in_hi);
+    if (is_idtx) svtgen::svt_iidentity32<12>(x, 0, 0); else svtgen::svt_idct32<12>(x, st_lo, st_hi);
+}
+
 // ---------------------------------------------------------------------------
 // inverse 32x32 + add (inv_txfm2d_add_c, EbTransforms.c:8180-8265): the mirror of
 // the forward kernel.  Coefficients are read linearly (coalesced), a swizzled tile
@@ -276,11 +299,13 @@ __global__ __launch_bounds__(F32_WAVES * 64, MIN_WAVES_PER_SIMD) void fwd32_kern
 // (ds_read_b128: 4 x 16 lanes over 64 banks; ds_write_b128: 8 x 8 lanes over 32 banks).
 // ---------------------------------------------------------------------------
 // WAVES / VAR are tuning knobs (tools/tune_inv32.py): VAR bit0 = no destination prefetch,
-// bit1 = skip the transforms (memory-only probe), bit2 = skip the global loads (compute-only probe).
+// bit1 = skip the transforms (memory-only probe), bit2 = skip the global loads (compute-only probe), bit3 = always clamp
+// (no clamp-free fast path, see idct32_pass; 5 waves / SIMD as before - the two-path form needs 117 VGPRs, so it runs at 4:
+// measured 1.254 ms against 1.361 ms per 2^20 blocks, and 1.70 ms when squeezed into 96 VGPRs with 92 B of scratch).
 // (A persistent, software-pipelined variant - next pair's coefficients fetched into registers during
 // the transforms, 168 VGPRs, 3 waves/SIMD - measured 14 % SLOWER: the VALU needs the 5 waves/SIMD.)
 template <typename PixT, int BD, int WAVES = F32_WAVES, int VAR = 0>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(5))) void inv32_kernel(
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((VAR & 8) ? 5 : 4))) void inv32_kernel(
     const int32_t* __restrict__ coeff, PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch,
     const uint32_t* __restrict__ dst_offsets, int is_idtx, uint32_t nblocks) {
     constexpr int bd = BD;
@@ -339,13 +364,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(5)))
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             const int4 v = *reinterpret_cast<const int4*>(tile + (a_r ^ (s << 4)));
-            x[s * 4 + 0] = svtgen::svt_clamp(v.x, in_lo, in_hi); x[s * 4 + 1] = svtgen::svt_clamp(v.y, in_lo, in_hi);
-            x[s * 4 + 2] = svtgen::svt_clamp(v.z, in_lo, in_hi); x[s * 4 + 3] = svtgen::svt_clamp(v.w, in_lo, in_hi);
+            x[s * 4 + 0] = v.x; x[s * 4 + 1] = v.y; x[s * 4 + 2] = v.z; x[s * 4 + 3] = v.w;
         }
-        // ---- row pass ------------------------------------------------------------------
+        // ---- row pass (input clamp inside) -------------------------------------------------
         if (VAR & 2) {}
-        else if (is_idtx) svtgen::svt_iidentity32<12>(x, 0, 0);
-        else svtgen::svt_idct32<12>(x, row_lo, row_hi);
+        else idct32_pass<in_bits, row_bits, !(VAR & 8)>(x, is_idtx, in_lo, in_hi, row_lo, row_hi);
         wave_lds_fence();
         // ---- tile B: row li written with slot swizzle li&7, columns read back ----------------
 #pragma unroll
@@ -356,13 +379,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(5)))
         // element (r, li): slot (li>>2) ^ (r&7), word li&3
 #pragma unroll
         for (int r = 0; r < 32; r++) {
-            const int v = *reinterpret_cast<const int*>(tile + (b_r ^ ((r & 7) << 4)) + r * 128);
-            x[r] = svtgen::svt_clamp(v, cin_lo, cin_hi);
+            x[r] = *reinterpret_cast<const int*>(tile + (b_r ^ ((r & 7) << 4)) + r * 128);
         }
-        // ---- column pass ---------------------------------------------------------------
+        // ---- column pass (input clamp inside) ----------------------------------------------
         if (VAR & 2) {}
-        else if (is_idtx) svtgen::svt_iidentity32<12>(x, 0, 0);
-        else svtgen::svt_idct32<12>(x, col_lo, col_hi);
+        else idct32_pass<cin_bits, col_bits, !(VAR & 8)>(x, is_idtx, cin_lo, cin_hi, col_lo, col_hi);
         wave_lds_fence();
         // ---- tile C: residual words in row order.  Word (r, c) lives in 16-B slot sigma = r*8 + c/4;
         // the reader takes SPL consecutive slots per lane, so slots are swizzled by
@@ -607,10 +628,9 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         const int4 v = *reinterpret_cast<const int4*>(tile + (a_r ^ (s << 4)));
-        x[s * 4 + 0] = svtgen::svt_clamp(v.x, i_lo, i_hi); x[s * 4 + 1] = svtgen::svt_clamp(v.y, i_lo, i_hi);
-        x[s * 4 + 2] = svtgen::svt_clamp(v.z, i_lo, i_hi); x[s * 4 + 3] = svtgen::svt_clamp(v.w, i_lo, i_hi);
+        x[s * 4 + 0] = v.x; x[s * 4 + 1] = v.y; x[s * 4 + 2] = v.z; x[s * 4 + 3] = v.w;
     }
-    if (is_idtx) svtgen::svt_iidentity32<12>(x, 0, 0); else svtgen::svt_idct32<12>(x, r_lo, r_hi);
+    idct32_pass<in_bits, row_bits, true>(x, is_idtx, i_lo, i_hi, r_lo, r_hi);
     wave_lds_fence();
 #pragma unroll
     for (int s = 0; s < 8; s++)
@@ -619,10 +639,9 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     wave_lds_fence();
 #pragma unroll
     for (int r = 0; r < 32; r++) {
-        const int v = *reinterpret_cast<const int*>(tile + (b_r ^ ((r & 7) << 4)) + r * 128);
-        x[r] = svtgen::svt_clamp(v, c_lo, c_hi);
+        x[r] = *reinterpret_cast<const int*>(tile + (b_r ^ ((r & 7) << 4)) + r * 128);
     }
-    if (is_idtx) svtgen::svt_iidentity32<12>(x, 0, 0); else svtgen::svt_idct32<12>(x, o_lo, o_hi);
+    idct32_pass<cin_bits, col_bits, true>(x, is_idtx, c_lo, c_hi, o_lo, o_hi);
     wave_lds_fence();
     constexpr int PPL = 16 / (int)sizeof(PixT), SPL = PPL / 4, maxpix = (1 << BD) - 1;
 #pragma unroll

@@ -68,8 +68,27 @@ __device__ __forceinline__ void fwd1d(int kind, int (&x)[N]) {
 template <int N, bool WIDE = false>
 __device__ __forceinline__ void inv1d(int kind, int (&x)[N], int lo, int hi) {
     using namespace svtgen;
-    lo = svt_vgpr(lo); hi = svt_vgpr(hi);     // clamp bounds live in two VGPRs (see svt_clamp)
     constexpr int BIT = 12;   // inv_cos_bit_* are all INV_COS_BIT = 12 (EbTransforms.h:252-267)
+    // Clamp-free fast path (N >= 16, where it pays): while gain * sum|x| + slack <= hi every stage clamp returns its argument
+    // (txfm_net.clamp_free_bound; constants in gen/txfm1d_gen.h), so a wave whose active lanes all pass the test runs the
+    // network without its v_med3_i32 (20-35 % of a pass's issue slots).  x is already clamped to the pass's input range.
+    if constexpr (N >= 16 && !WIDE) {
+        if (kind != K1D_IDTX) {
+            constexpr int NL = N == 64 ? 32 : N;          // live inputs
+            int lim;
+            if constexpr (N == 16) lim = kind == K1D_DCT ? svt_clamp_free_l1(svt_idct16_gain_q10, svt_idct16_slack, hi) : svt_clamp_free_l1(svt_iadst16_gain_q10, svt_iadst16_slack, hi);
+            else if constexpr (N == 32) lim = svt_clamp_free_l1(svt_idct32_gain_q10, svt_idct32_slack, hi);
+            else lim = svt_clamp_free_l1(svt_idct64_low32_gain_q10, svt_idct64_low32_slack, hi);
+            const int l1 = svt_l1<N>(x, NL);
+            if (__builtin_amdgcn_ballot_w64(l1 > lim) == 0) {
+                if constexpr (N == 16) { if (kind == K1D_DCT) svt_idct16<BIT, false, false>(x, 0, 0); else svt_iadst16<BIT, false, false>(x, 0, 0); }
+                else if constexpr (N == 32) svt_idct32<BIT, false, false>(x, 0, 0);
+                else svt_idct64_low32<BIT, false, false>(x, 0, 0);
+                return;
+            }
+        }
+    }
+    lo = svt_vgpr(lo); hi = svt_vgpr(hi);     // clamp bounds live in two VGPRs (see svt_clamp)
     if constexpr (N == 4) {
         if (kind == K1D_DCT) svt_idct4<BIT, WIDE>(x, lo, hi); else if (kind == K1D_IDTX) svt_iidentity4<BIT, WIDE>(x, lo, hi); else svt_iadst4<BIT, WIDE>(x, lo, hi);
     } else if constexpr (N == 8) {

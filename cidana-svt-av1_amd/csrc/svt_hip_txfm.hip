@@ -221,7 +221,7 @@ extern "C" int svt_hip_inv_txfm2d_add_batch(const int32_t* d_coeff, void* d_dst,
             hipLaunchKernelGGL((inv32_kernel<uint8_t, 8, WV, VR>), dim3((uint32_t)((nblocks + 2 * WV - 1) / (2 * WV))), dim3(WV * 64), 0, s, d_coeff, \
                                (uint8_t*)d_dst, dst_stride, dst_block_pitch, d_dst_offsets, tx_type == SVT_IDTX ? 1 : 0, (uint32_t)nblocks); \
             return launch_status("inv32 probe"); }
-            INVV(4, 1) INVV(4, 2) INVV(4, 4) INVV(4, 5) INVV(2, 0)
+            INVV(4, 1) INVV(4, 2) INVV(4, 4) INVV(4, 5) INVV(2, 0) INVV(4, 8)
 #undef INVV
             return set_err(SVT_HIP_ERR_INVALID, "inv32 probe variant not built");
         }

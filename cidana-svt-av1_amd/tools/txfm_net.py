@@ -476,6 +476,55 @@ def build_inv(kind: str, n: int) -> Net:
     return INV_BUILDERS[kind](n)
 
 
+
+def clamp_free_bound(net: Net, bit: int = 12):
+    """(gain, slack) such that EVERY value the network clamps satisfies |v| <= gain * sum_i |x_i| + slack, by the triangle
+    inequality carried through the ops (|a +- b| <= |a| + |b|; a half_btf adds at most 1 for its rounding).  While
+    gain * L1(x) + slack <= the clamp bound, every clamp of the network returns its argument, so the network without its clamps
+    computes the same values (by induction over the ops in order).  Used by the kernels to take a clamp-free copy of an
+    inverse transform for the (wave-uniform) common case; tests/test_txfm_net.py checks the claim on random and extreme inputs."""
+    import math
+
+    def wabs(w):
+        if w[0] == "sin":
+            return abs(SINPI[bit][w[2]]) / float(1 << bit)
+        return cospi_table(bit)[w[1]] / float(1 << bit)
+    n = net.n_in
+    G: List[List[float]] = []
+    E: List[float] = []
+    gmax, emax = 0.0, 0.0
+    for op in net.ops:
+        k = op[0]
+        if k == "in":
+            g = [0.0] * n; g[op[1]] = 1.0; e = 0.0
+        elif k in ("add", "sub"):
+            g = [a + b for a, b in zip(G[op[1]], G[op[2]])]; e = E[op[1]] + E[op[2]]
+        elif k == "neg":
+            g = list(G[op[1]]); e = E[op[1]]
+        elif k == "hb":
+            wa, wb = wabs(op[1]), wabs(op[3])
+            g = [wa * a + wb * b for a, b in zip(G[op[2]], G[op[4]])]; e = wa * E[op[2]] + wb * E[op[4]] + 1.0
+        elif k == "hb1":
+            wa = wabs(op[1]); g = [wa * a for a in G[op[2]]]; e = wa * E[op[2]] + 1.0
+        elif k == "mulc":
+            wa = wabs(op[1]) * (1 << bit); g = [wa * a for a in G[op[2]]]; e = wa * E[op[2]]
+        elif k == "rsr":
+            g = [a / float(1 << bit) for a in G[op[1]]]; e = E[op[1]] / float(1 << bit) + 1.0
+        elif k == "sqrt2":
+            f = op[2] * 5793 / 4096.0; g = [f * a for a in G[op[1]]]; e = f * E[op[1]] + 1.0
+        elif k == "shl":
+            f = float(1 << op[2]); g = [f * a for a in G[op[1]]]; e = f * E[op[1]]
+        elif k == "clamp":
+            g = G[op[1]]; e = E[op[1]]
+            gmax = max(gmax, max(g)); emax = max(emax, e)
+        elif k == "zero":
+            g = [0.0] * n; e = 0.0
+        else:
+            raise ValueError(k)
+        G.append(g); E.append(e)
+    return gmax, emax
+
+
 def specialize_zero_inputs(net: Net, nz: int, name: str) -> Net:
     """Network for inputs whose elements >= nz are known to be zero (AV1 64-point
     inverse: only the first 32 coefficients of a row / column can be non-zero,

@@ -112,3 +112,41 @@ def test_config1_8x8_dct_1k_blocks_cpu():
         f = _ref_dct2d_float(x.astype(np.float64)) * 2.0     # 8x8: shifts 2,-1,0 -> net x2 (FwdTxfm2dTest.cc:108-118)
         worst = max(worst, float(np.abs(o.reshape(8, 8) - np.round(f)).max()) / 2.0)
     assert worst <= 5.0
+
+
+def test_clamp_free_bound_makes_every_stage_clamp_a_no_op():
+    """txfm_net.clamp_free_bound: while gain * L1(x) + slack <= the clamp bound, the inverse networks with and without their stage
+    clamps agree.  Inputs AT the bound, with the mass on one, two, a few or all inputs and every sign pattern drawn at random
+    (the kernels branch on exactly this L1 test, csrc/kernel_txfm.h inv1d)."""
+    import math
+    rng = np.random.default_rng(4242)
+    nets = [T.build_inv(kind, n) for kind, sizes in (("dct", (4, 8, 16, 32, 64)), ("adst", (8, 16))) for n in sizes]
+    nets.append(T.specialize_zero_inputs(T.build_inv("dct", 64), 32, "idct64_low32"))
+    for net in nets:
+        g, e = T.clamp_free_bound(net)
+        assert g > 0
+        live = 32 if net.name == "idct64_low32" else net.n_in
+        for bits in (16, 18):
+            hi = (1 << (bits - 1)) - 1
+            l1 = int(((hi - (math.ceil(e) + 1)) << 10) // (math.ceil(g * 1024) + 1))          # svt_clamp_free_l1
+            rows = []
+            for i in range(live):                                    # all the mass on one input, both signs
+                for sgn in (1, -1):
+                    v = np.zeros(net.n_in, np.int64); v[i] = sgn * min(l1, hi); rows.append(v)
+            for _ in range(600):                                     # random splits of exactly l1 over k inputs, random signs
+                k = int(rng.choice([2, 3, 4, live // 2, live]))
+                idx = rng.choice(live, size=min(k, live), replace=False)
+                cuts = np.sort(rng.integers(0, l1 + 1, size=len(idx) - 1))
+                mag = np.diff(np.concatenate([[0], cuts, [l1]]))
+                v = np.zeros(net.n_in, np.int64); v[idx] = mag * rng.choice([-1, 1], size=len(idx)); rows.append(v)
+            for _ in range(200):                                     # flat: the same magnitude everywhere
+                v = np.zeros(net.n_in, np.int64); v[:live] = (l1 // live) * rng.choice([-1, 1], size=live); rows.append(v)
+            x = np.stack(rows)
+            assert np.abs(x).sum(axis=1).max() <= l1
+            a = T.evaluate(net, x, 12, {"stage": bits})
+            b = T.evaluate(net, x, 12, {"stage": 40})                # clamps that can never act
+            assert np.array_equal(a, b), (net.name, bits)
+    # and the bound is not vacuous: far above it the clamps do act
+    net = T.build_inv("dct", 32)
+    x = np.full((1, 32), 30000, np.int64)
+    assert not np.array_equal(T.evaluate(net, x, 12, {"stage": 16}), T.evaluate(net, x, 12, {"stage": 40}))

@@ -34,6 +34,13 @@ elif name == "me_sb":
     n = 510
     src = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 127, 128), dtype=torch.uint8, device=dev)
     fn = lambda: dsp.me_sb_search(src, ref, 64, 64)
+elif name.startswith("enc"):          # enc32 / enc64 / enc16 / enc8: fused encode_recon (qcoeff + recon), as tools/bench_kernels.py
+    S = int(name[3:]); s_ = {8: 1, 16: 2, 32: 3, 64: 4}[S]
+    n = (1 << 20) * 1024 // (S * S) if S <= 32 else 1 << 18
+    src = torch.randint(0, 256, (n, S, S), dtype=torch.uint8, device=dev)
+    pred = (src.to(torch.int16) + torch.randint(-20, 21, (n, S, S), dtype=torch.int16, device=dev)).clamp(0, 255).to(torch.uint8)
+    iscan = torch.from_numpy(pkg.tables.scan_tables(s_, 0)[1]).to(dev)
+    fn = lambda: dsp.encode_recon(src, pred, s_, 0, qrow, iscan, keep_coeff=False)
 else:
     raise SystemExit("unknown " + name)
 for _ in range(5): fn()
