@@ -30,6 +30,7 @@ extern int g_tune_f32_qmode1;
 extern int g_tune_no_staged;
 extern int g_tune_no_qsad;
 extern int g_tune_no_q2;
+extern int g_tune_no_q2p;
 extern int g_tune_no_q16;
 extern int g_tune_q2_su4;
 extern int g_tune_ois_no_fold;

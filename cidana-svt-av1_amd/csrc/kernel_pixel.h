@@ -571,6 +571,195 @@ __global__ __launch_bounds__(256) void sad_search_q2_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// sad_search_q2p_kernel: sad_search_q2_kernel as a PERSISTENT, software-pipelined kernel.  The one-shot form is latency
+// bound (3 waves / SIMD by LDS, a wave lives ~8 us for ~1.3 us of v_qsad work: staging loads, a workgroup barrier, then
+// the search, nothing overlapping inside a wave).  Here a wave owns its LDS region (no workgroup barrier), loops over
+// sets of 64 / lpb blocks, and fetches the NEXT set's source + window chunks into registers (at most 8 x 16 B per lane)
+// right after it has handed the current set's chunks to LDS - so every wave keeps global loads in flight for the whole
+// time it spends in v_qsad.  Same staging layout, search loop, argmin key and outputs as sad_search_q2_kernel; a wave's
+// results leave as one contiguous store per output array (lanes 0 .. bpw-1).
+// Host precondition: (source chunks + window chunks) <= 8 * lpb.
+// ---------------------------------------------------------------------------
+template <int CW, int CH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void sad_search_q2p_kernel(
+    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
+    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
+    unsigned long long* __restrict__ best_sad, int16_t* __restrict__ best_x, int16_t* __restrict__ best_y,
+    uint32_t ref_lds_bytes, uint32_t lpb, uint32_t cpr_magic, const uint32_t* __restrict__ src_offs,
+    const uint32_t* __restrict__ ref_offs, uint32_t nblocks) {
+    static_assert(CW % 4 == 0 && CW * CH <= 256, "source block must fit 64 VGPRs");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int WQ = CW / 4, SU = 8;
+    constexpr uint32_t SRC_BYTES = (CW * CH + 15) & ~15;
+    constexpr uint32_t CS = CW % 16 == 0 ? 16 : (CW % 8 == 0 ? 8 : 4);
+    constexpr uint32_t NSRC = CW * CH / CS;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lsh = __builtin_ctz(lpb), bpw = 64u >> lsh;
+    const uint32_t wslot = lane >> lsh, l = lane & (lpb - 1);
+    const uint32_t win_w = CW + search_w - 1;
+    const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+    const uint32_t nrows = (uint32_t)(search_h + CH - 1);
+    const uint32_t cpr = (win_w + 15) >> 4;
+    const uint32_t nref = nrows * cpr;
+    const size_t span = (size_t)(nrows - 1) * ref_stride + win_w;
+    uint8_t* wbase = smem + (size_t)wave * bpw * (SRC_BYTES + ref_lds_bytes);
+    uint8_t* s_src = wbase + (size_t)wslot * SRC_BYTES;
+    uint8_t* s_ref = wbase + (size_t)bpw * SRC_BYTES + (size_t)wslot * ref_lds_bytes;
+    const uint32_t nsets = (nblocks + bpw - 1) >> __builtin_ctz(bpw);
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    uint32_t set = blockIdx.x * (blockDim.x >> 6) + wave;
+
+    // chunk k of this lane is list entry i = l + k * lpb: entries [0, NSRC) are source chunks of CS bytes, the rest the
+    // window's 16-B chunks (row-major, cpr per row).  Loads are unconditional (clamped entry / block).
+    uint4 v[SU];
+    auto issue = [&](uint32_t st) {
+        const uint32_t b = min(st * bpw + wslot, nblocks - 1);
+        const uint8_t* gs = src + (src_offs ? (size_t)src_offs[b] : (size_t)b * src_block_pitch);
+        const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[b] : (size_t)b * ref_block_pitch);
+#pragma unroll
+        for (int k = 0; k < SU; k++) {
+            const uint32_t i = min(l + k * lpb, NSRC + nref - 1);
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (i < NSRC) {
+                __builtin_memcpy(&v[k], gs + (size_t)(i / (CW / CS)) * src_stride + (i % (CW / CS)) * CS, CS);
+            } else {
+                const uint32_t j = i - NSRC;
+                const uint32_t rr = cpr == 1 ? j : __umulhi(j, cpr_magic), c = j - rr * cpr;
+                const size_t off = (size_t)rr * ref_stride + c * 16;
+                const size_t offc = off + 16 <= span ? off : span - 16;     // footprint tail: the last 16 bytes instead
+                __builtin_memcpy(&v[k], gr + offc, 16);
+            }
+        }
+    };
+    if (set < nsets) issue(set);
+    for (; set < nsets; set += nwaves) {
+        // ---- hand the prefetched chunks to LDS (the previous set's reads are complete: same wave, program order) ----
+        asm volatile("" ::"v"(v[0].x), "v"(v[1].x), "v"(v[2].x), "v"(v[3].x), "v"(v[4].x), "v"(v[5].x), "v"(v[6].x), "v"(v[7].x));
+#pragma unroll
+        for (int k = 0; k < SU; k++) {
+            const uint32_t i = l + k * lpb;
+            if (i < NSRC) {
+                __builtin_memcpy(s_src + i * CS, &v[k], CS);
+            } else if (i < NSRC + nref) {
+                const uint32_t j = i - NSRC;
+                const uint32_t rr = cpr == 1 ? j : __umulhi(j, cpr_magic), c = j - rr * cpr;
+                const size_t off = (size_t)rr * ref_stride + c * 16;
+                const uint32_t dst = rr * wpitch + c * 16;
+                if (off + 16 <= span) {
+                    uint2* rd = reinterpret_cast<uint2*>(s_ref + dst);
+                    rd[0] = make_uint2(v[k].x, v[k].y); rd[1] = make_uint2(v[k].z, v[k].w);
+                } else {                                   // stored `delta` bytes earlier, byte-granular
+                    const uint32_t delta = (uint32_t)(off + 16 - span);
+                    const uint32_t vw[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                    for (int bb = 0; bb < 16; bb++) s_ref[dst - delta + bb] = (uint8_t)(vw[bb >> 2] >> (8 * (bb & 3)));
+                }
+            }
+        }
+        wave_lds_fence();
+        // ---- next set's chunks: in flight during the search below ----------------------------------------------------
+        if (set + nwaves < nsets) issue(set + nwaves);
+        // ---- search (sad_search_q2_kernel) -------------------------------------------------------------------------------
+        const uint32_t blk = set * bpw + wslot;
+        const bool valid = blk < nblocks;
+        unsigned long long best = ~0ull;
+        {
+            const int gx = (search_w + 3) >> 2, gy = (search_h + 1) >> 1;
+            const int ngroups = gx * gy;
+            for (int g = (int)l; g < ngroups; g += (int)lpb) {
+                const int yp = g / gx, xg = g - yp * gx;
+                const int ysA = 2 * yp;
+                const bool hasB = ysA + 1 < search_h;
+                unsigned long long accA = 0, accB = 0;
+                const uint8_t* rbase = s_ref + (size_t)ysA * wpitch + xg * 4;
+                // source rows are streamed from LDS (broadcast reads, the lanes of a block share the address): two rows live
+                // instead of the whole block in 64 VGPRs - the registers hold the next set's chunks meanwhile
+                uint32_t sprev[WQ];
+                auto load_src = [&](int r, uint32_t (&d)[WQ]) {
+                    if constexpr (WQ % 4 == 0) {
+#pragma unroll
+                        for (int i = 0; i < WQ / 4; i++) {
+                            const uint4 a = *reinterpret_cast<const uint4*>(s_src + r * CW + 16 * i);
+                            d[4 * i] = a.x; d[4 * i + 1] = a.y; d[4 * i + 2] = a.z; d[4 * i + 3] = a.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < WQ; q++) d[q] = *reinterpret_cast<const uint32_t*>(s_src + r * CW + 4 * q);
+                    }
+                };
+                {   // window row 0 feeds search row A only
+                    const uint32_t* rrow = reinterpret_cast<const uint32_t*>(rbase);
+                    uint32_t rw[WQ + 1];
+#pragma unroll
+                    for (int q = 0; q <= WQ; q++) rw[q] = rrow[q];
+                    load_src(0, sprev);
+#pragma unroll
+                    for (int q = 0; q < WQ; q++) accA = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)rw[q + 1] << 32) | rw[q], sprev[q], accA);
+                }
+                // (a bounded unroll: fully unrolled, the scheduler hoists all 17 rows' LDS reads and the kernel needs 280 VGPRs)
+#pragma unroll 4
+                for (int r = 1; r < CH; r++) {
+                    const uint32_t* rrow = reinterpret_cast<const uint32_t*>(rbase + (size_t)r * wpitch);
+                    uint32_t rw[WQ + 1], scur[WQ];
+#pragma unroll
+                    for (int q = 0; q <= WQ; q++) rw[q] = rrow[q];
+                    load_src(r, scur);
+#pragma unroll
+                    for (int q = 0; q < WQ; q++) {
+                        const unsigned long long pr = ((unsigned long long)rw[q + 1] << 32) | rw[q];
+                        accA = __builtin_amdgcn_qsad_pk_u16_u8(pr, scur[q], accA);
+                        accB = __builtin_amdgcn_qsad_pk_u16_u8(pr, sprev[q], accB);
+                    }
+#pragma unroll
+                    for (int q = 0; q < WQ; q++) sprev[q] = scur[q];
+                }
+                {   // window row CH feeds search row B only (past the window when the pair has no second row: re-read the last one)
+                    const uint32_t* rrow = reinterpret_cast<const uint32_t*>(rbase + (size_t)(hasB ? CH : CH - 1) * wpitch);
+                    uint32_t rw[WQ + 1];
+#pragma unroll
+                    for (int q = 0; q <= WQ; q++) rw[q] = rrow[q];
+#pragma unroll
+                    for (int q = 0; q < WQ; q++) accB = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)rw[q + 1] << 32) | rw[q], sprev[q], accB);
+                }
+                const int xs0 = xg * 4;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    if (xs0 + jj < search_w) {
+                        const unsigned sa = (unsigned)((accA >> (16 * jj)) & 0xffffu), sb = (unsigned)((accB >> (16 * jj)) & 0xffffu);
+                        const unsigned long long ka = ((unsigned long long)sa << 32) | (unsigned)(ysA * search_w + xs0 + jj);
+                        best = ka < best ? ka : best;
+                        if (hasB) {
+                            const unsigned long long kb = ((unsigned long long)sb << 32) | (unsigned)((ysA + 1) * search_w + xs0 + jj);
+                            best = kb < best ? kb : best;
+                        }
+                    }
+                }
+            }
+        }
+        for (uint32_t m = lpb >> 1; m >= 1; m >>= 1) {
+            const unsigned long long o = __shfl_xor(best, (int)m, 64);
+            best = o < best ? o : best;
+        }
+        // lane t < bpw takes block slot t's result: contiguous stores
+        const unsigned long long key = __shfl(best, (int)((lane & (bpw - 1)) << lsh), 64);
+        const uint32_t ob = set * bpw + lane;
+        if (lane < bpw && ob < nblocks) {
+            const unsigned sadv = (unsigned)(key >> 32);
+            const int cand = (int)(key & 0xffffffffu);
+            if (sadv < 0xffffffu) {          // reference initialises best_sad = 0xffffff, strict '<'
+                best_sad[ob] = sadv;
+                best_x[ob] = (int16_t)(cand % search_w);
+                best_y[ob] = (int16_t)(cand / search_w);
+            } else {
+                best_sad[ob] = 0xffffffu;
+            }
+        }
+        (void)valid;
+        wave_lds_fence();                                  // the search's LDS reads are done before the next set overwrites
+    }
+}
+
+// ---------------------------------------------------------------------------
 // SAD search for 16-, 32- and 64-wide blocks (any height that is a multiple of 256 / CW), plain reference
 // window.  sad_search_q_kernel issues two ds_read_b32 per v_qsad_pk_u16_u8 (a reference and a source
 // dword), which makes the LDS pipe - shared by the CU's four SIMDs, 128 B/clk - its limiter at about

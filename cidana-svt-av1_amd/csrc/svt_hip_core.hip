@@ -19,6 +19,7 @@ int g_tune_f32_qmode1 = 0;
 int g_tune_no_staged = 0;
 int g_tune_no_qsad = 0;
 int g_tune_no_q2 = 0;
+int g_tune_no_q2p = 0;
 int g_tune_no_q16 = 0;
 int g_tune_q2_su4 = 0;
 int g_tune_ois_no_fold = 0;
@@ -121,6 +122,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "no_staged")) { g_tune_no_staged = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_qsad")) { g_tune_no_qsad = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_q2")) { g_tune_no_q2 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "no_q2p")) { g_tune_no_q2p = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_q16")) { g_tune_no_q16 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "q2_su4")) { g_tune_q2_su4 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "ois_no_fold")) { g_tune_ois_no_fold = value; return SVT_HIP_OK; }

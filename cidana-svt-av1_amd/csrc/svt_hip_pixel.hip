@@ -141,6 +141,26 @@ static int sad_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src
             // latency per block instead of two: the kernel is latency-bound at 3 waves per SIMD)
             const uint32_t nchunk = ((win_w + 15) >> 4) * nrows;
             const bool deep = !g_tune_q2_su4 && nchunk > 4 * lpb;
+            // persistent, software-pipelined form (loads of the next set of blocks in flight during the search): whenever a
+            // lane's share of one block's chunks fits 8 registers-of-16-B
+            const uint32_t nsrc_chunks = width * height / (width % 16 == 0 ? 16u : 8u);
+            if (!g_tune_no_q2p && nsrc_chunks + nchunk <= 8 * lpb) {
+                const uint32_t nsets = (uint32_t)((nblocks + 64 / lpb - 1) / (64 / lpb));
+                const uint32_t wg_per_cu = (uint32_t)(160 * 1024 / ((size_t)slots * per_blk));
+                uint32_t pgrid = (uint32_t)g_num_cu * (wg_per_cu ? wg_per_cu : 1);
+                const uint32_t need = (nsets + threads / 64 - 1) / (threads / 64);
+                if (pgrid > need) pgrid = need;
+#define SSQ2P(CW, CH)                                                                                                   \
+    hipLaunchKernelGGL((sad_search_q2p_kernel<CW, CH>), dim3(pgrid), dim3(threads), (size_t)slots * per_blk, (hipStream_t)stream, \
+                       d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, (int)search_area_width,         \
+                       (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, ref_bytes, lpb, cpr_magic,           \
+                       d_src_offs, d_ref_offs, (uint32_t)nblocks)
+                if (threads >= 64) {
+                    if (width == 16) SSQ2P(16, 16); else SSQ2P(8, 8);
+#undef SSQ2P
+                    return launch_status("sad_search_q2p");
+                }
+            }
             if (width == 16) { if (deep) SSQ2(16, 16, 8); else SSQ2(16, 16, 4); }
             else { if (deep) SSQ2(8, 8, 8); else SSQ2(8, 8, 4); }
 #undef SSQ2

@@ -499,3 +499,48 @@ def test_fused32_nonstandard_quant_tables_take_the_general_path(dsp):
     rco, rq, rdq, reob, rsad = oracle_chain(src, pred, 3, 0, qrow)
     assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(dq.cpu().numpy(), rdq)
     assert np.array_equal(eob.cpu().numpy().view(np.uint16), reob)
+
+
+@pytest.mark.parametrize("tx_size", [2, 3, 4, 9, 10, 17, 18])
+@pytest.mark.parametrize("bd", [8, 10])
+def test_inverse_clamp_free_threshold(dsp, tx_size, bd):
+    """the inverse kernels drop the stage clamps while gain * L1(row or column) + slack <= the stage bound (csrc/kernel_txfm.h
+    inv1d, kernel_fused32.h idct32_pass).  Blocks whose rows carry all their L1 mass in one or two coefficients, with magnitudes
+    that straddle that limit (the worst case of the bound), and blocks that pass the row test but fail the column one."""
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(900 + tx_size + bd)
+    w, h = TX_W[tx_size], TX_H[tx_size]
+    kw, kh = min(w, 32), min(h, 32)
+    hi = (1 << (bd + 8 - 1)) - 1
+    mags = sorted({hi, hi * 3 // 4, hi * 9 // 16, hi // 2, hi * 7 // 16, hi * 3 // 8, hi // 4, 18258, 18259, 13410, 13411, 25192, 25193})
+    blocks = []
+    for m in mags:
+        for rep in range(3):
+            co = np.zeros((kh, kw), np.int32)
+            if rep == 0:                      # one coefficient per row, random column and sign
+                co[np.arange(kh), rng.integers(0, kw, kh)] = m * rng.choice([-1, 1], kh)
+            elif rep == 1:                    # the mass split over two coefficients of every row
+                a = rng.integers(0, m + 1, kh)
+                c0 = rng.integers(0, kw // 2, kh); c1 = rng.integers(kw // 2, kw, kh)
+                co[np.arange(kh), c0] = a * rng.choice([-1, 1], kh); co[np.arange(kh), c1] = (m - a) * rng.choice([-1, 1], kh)
+            else:                             # one column: quiet rows, a loud column for the second pass
+                co[:, int(rng.integers(0, kw))] = (m // 2) * rng.choice([-1, 1], kh)
+            blocks.append(co.ravel())
+    co = np.stack(blocks)
+    n = co.shape[0]
+    dst = rng.integers(0, 1 << bd, size=(n, h, w)).astype(np.uint16)
+    ref = dst.copy()
+    for i in range(n):
+        O.svt_oracle_inv_txfm2d_add(ptr(co[i]), ptr(ref[i]), w, 0, tx_size, bd)
+    d = dev(dst.view(np.int16))
+    dsp.inv_txfm2d_add(dev(co), d, tx_size, 0, bd)
+    got = d.cpu().numpy().view(np.uint16)
+    bad = [i for i in range(n) if not np.array_equal(got[i], ref[i])]
+    assert not bad, (TX_SIZES[tx_size], bd, bad[:5])
+    if bd == 8:
+        d8 = dev(dst.astype(np.uint8))
+        ref8 = dst.astype(np.uint8)
+        for i in range(n):
+            O.svt_oracle_inv_txfm2d_add_u8(ptr(co[i]), ptr(ref8[i]), w, 0, tx_size)
+        dsp.inv_txfm2d_add(dev(co), d8, tx_size, 0, 8)
+        assert np.array_equal(d8.cpu().numpy(), ref8)

@@ -91,6 +91,36 @@ def test_inverse_on_planes_variants(dsp, knob, tx_size, bd):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("n,bw,sw,sh", [(1, 16, 8, 8), (7, 16, 8, 8), (8, 16, 8, 8), (9, 16, 8, 8), (5000, 16, 8, 8), (4099, 8, 8, 8), (333, 16, 5, 3), (333, 8, 13, 5),
+                                        (333, 16, 11, 8), (77, 8, 4, 2), (77, 16, 1, 1)])
+def test_sad_search_pipelined_vs_one_shot(dsp, n, bw, sw, sh):
+    """sad_search_q2p_kernel (persistent, next set's chunks prefetched during the search) against sad_search_q2_kernel: batch sizes
+    around one wave's set of blocks, more sets than waves, ragged search areas, ties, footprint-tail chunks; both against the
+    SADs recomputed in numpy for a few blocks"""
+    rng = np.random.default_rng(n + bw + sw)
+    src = rng.integers(0, 256, size=(n, bw, bw), dtype=np.uint8)
+    ref = rng.integers(0, 256, size=(n, bw + sh - 1, bw + sw - 1), dtype=np.uint8)
+    ref[0] = 3; src[0] = 4                                   # ties everywhere: the first candidate wins
+    if n > 2:
+        ref[n - 1, sh - 1:, sw - 1:] = src[n - 1]            # exact match at the LAST candidate of the LAST block
+    try:
+        _tune(dsp, "no_q2p", 0); a = dsp.sad_search(dev(src), dev(ref), sw, sh)
+        _tune(dsp, "no_q2p", 1); b = dsp.sad_search(dev(src), dev(ref), sw, sh)
+    finally:
+        _tune(dsp, "no_q2p", 0)
+    torch.cuda.synchronize()
+    assert _eq(a, b)
+    sad, bx, by = (t.cpu().numpy() for t in a)
+    for i in sorted({0, n - 1, n // 2}):
+        best = None
+        for y in range(sh):
+            for x in range(sw):
+                v = int(np.abs(src[i].astype(int) - ref[i, y:y + bw, x:x + bw].astype(int)).sum())
+                if best is None or v < best[0]:
+                    best = (v, x, y)
+        assert (int(sad[i]), int(bx[i]), int(by[i])) == best, (i, best)
+
+
 @pytest.mark.parametrize("knob,bw,sw,sh", [("q2_su4", 16, 8, 8), ("q2_su4", 8, 16, 16), ("no_q2", 16, 8, 8), ("no_q2", 8, 13, 5), ("no_qsad", 16, 8, 8), ("no_qsad", 32, 9, 6),
                                              ("no_q16", 32, 9, 6), ("no_q16", 64, 16, 16), ("no_q16", 32, 37, 3)])
 def test_sad_search_variants(dsp, knob, bw, sw, sh):
