@@ -581,36 +581,74 @@ __global__ __launch_bounds__(256) void sad_search_q2_kernel(
 // Host precondition: (source chunks + window chunks) <= 8 * lpb.
 // ---------------------------------------------------------------------------
 template <int CW, int CH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void sad_search_q2p_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void sad_search_q2p_kernel(
     const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
     const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
     unsigned long long* __restrict__ best_sad, int16_t* __restrict__ best_x, int16_t* __restrict__ best_y,
-    uint32_t ref_lds_bytes, uint32_t lpb, uint32_t cpr_magic, const uint32_t* __restrict__ src_offs,
+    uint32_t wstride, uint32_t wpitch, uint32_t lpb, uint32_t cpr_magic, const uint32_t* __restrict__ src_offs,
     const uint32_t* __restrict__ ref_offs, uint32_t nblocks) {
     static_assert(CW % 4 == 0 && CW * CH <= 256, "source block must fit 64 VGPRs");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int WQ = CW / 4, SU = 8;
-    constexpr uint32_t SRC_BYTES = (CW * CH + 15) & ~15;
+    // source blocks sit 16 B apart from a multiple of 256 B: the broadcast b128 reads of a row (one address per block) then
+    // fall on different banks (at a stride of 256 B all eight blocks of a wave hit the same four: PMC showed 38 % of the LDS
+    // cycles as bank conflicts)
+    constexpr uint32_t SRC_BYTES = ((CW * CH + 15) & ~15) + 16;
     constexpr uint32_t CS = CW % 16 == 0 ? 16 : (CW % 8 == 0 ? 8 : 4);
     constexpr uint32_t NSRC = CW * CH / CS;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t lsh = __builtin_ctz(lpb), bpw = 64u >> lsh;
     const uint32_t wslot = lane >> lsh, l = lane & (lpb - 1);
     const uint32_t win_w = CW + search_w - 1;
-    const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
     const uint32_t nrows = (uint32_t)(search_h + CH - 1);
     const uint32_t cpr = (win_w + 15) >> 4;
     const uint32_t nref = nrows * cpr;
     const size_t span = (size_t)(nrows - 1) * ref_stride + win_w;
-    uint8_t* wbase = smem + (size_t)wave * bpw * (SRC_BYTES + ref_lds_bytes);
+    // LDS of a wave: its source blocks, then its windows at a row pitch of wpitch = 16 * cpr + 8 bytes and a block stride
+    // wstride == 64 (mod 128) bytes, every second pair of blocks 8 bytes further on: the window origins of four consecutive
+    // blocks then sit at dword residues {0, 16, 2, 18} (mod 32), and with the 40-B pitch of a 23-wide window the 32 lanes of a
+    // ds_read_b32 group (4 blocks x 4 row pairs x 2 column groups) hit 32 different banks.  920 B per 16x16 / 8x8-search
+    // window instead of 1 288: 4 workgroups (16 waves) per CU instead of 3.
+    uint8_t* wbase = smem + (size_t)wave * bpw * (SRC_BYTES + wstride);
     uint8_t* s_src = wbase + (size_t)wslot * SRC_BYTES;
-    uint8_t* s_ref = wbase + (size_t)bpw * SRC_BYTES + (size_t)wslot * ref_lds_bytes;
+    uint8_t* s_ref = wbase + (size_t)bpw * SRC_BYTES + (size_t)wslot * wstride + 8u * ((wslot >> 1) & 1u);
     const uint32_t nsets = (nblocks + bpw - 1) >> __builtin_ctz(bpw);
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     uint32_t set = blockIdx.x * (blockDim.x >> 6) + wave;
 
     // chunk k of this lane is list entry i = l + k * lpb: entries [0, NSRC) are source chunks of CS bytes, the rest the
-    // window's 16-B chunks (row-major, cpr per row).  Loads are unconditional (clamped entry / block).
+    // window's 16-B chunks (row-major, cpr per row).  Where a chunk comes from (byte offset from the block's source / window
+    // origin) and where it goes in LDS depend on the lane only: computed once, 2 VGPRs per chunk.  Loads are unconditional
+    // (entries past the list repeat the last one and are not stored).
+    uint32_t goff[SU], ldst[SU];             // ldst: byte offset in smem | kind in bits 30-31 (0 none, 1 source, 2 window, 3 window tail)
+#pragma unroll
+    for (int k = 0; k < SU; k++) {
+        const uint32_t iw = l + k * lpb, i = min(iw, NSRC + nref - 1);
+        const bool want = iw < NSRC + nref;
+        if (i < NSRC) {
+            goff[k] = (i / (CW / CS)) * src_stride + (i % (CW / CS)) * CS;
+            ldst[k] = (uint32_t)(s_src + i * CS - smem) | (want ? 1u << 30 : 0u);
+        } else {
+            const uint32_t j = i - NSRC;
+            const uint32_t rr = cpr == 1 ? j : __umulhi(j, cpr_magic), c = j - rr * cpr;
+            const size_t off = (size_t)rr * ref_stride + c * 16;
+            const bool tail = off + 16 > span;              // footprint tail: the LAST 16 bytes of the footprint instead, stored earlier
+            const uint32_t delta = tail ? (uint32_t)(off + 16 - span) : 0u;
+            goff[k] = (uint32_t)off - delta;
+            ldst[k] = (uint32_t)(s_ref + rr * wpitch + c * 16 - delta - smem) | (want ? (tail ? 3u : 2u) << 30 : 0u);
+        }
+    }
+    // the kind of chunk k is the same in every lane for most k (a block's source chunks fill whole rounds of lanes, the tail
+    // and the end of the list touch one round each): kept as a scalar so that the hand-over below branches without VALU work
+    uint32_t ukind[SU];
+#pragma unroll
+    for (int k = 0; k < SU; k++) {
+        const uint32_t kd = ldst[k] >> 30, k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)kd);
+        ukind[k] = __builtin_amdgcn_ballot_w64(kd != k0) == 0 ? k0 : 4u;
+        ldst[k] &= 0x3fffffffu;
+        if (ukind[k] == 4u) ldst[k] |= kd << 30;
+    }
+    const bool k_is_src[SU] = {l < NSRC, l + lpb < NSRC, l + 2 * lpb < NSRC, l + 3 * lpb < NSRC, l + 4 * lpb < NSRC, l + 5 * lpb < NSRC, l + 6 * lpb < NSRC, l + 7 * lpb < NSRC};
     uint4 v[SU];
     auto issue = [&](uint32_t st) {
         const uint32_t b = min(st * bpw + wslot, nblocks - 1);
@@ -618,16 +656,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
         const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[b] : (size_t)b * ref_block_pitch);
 #pragma unroll
         for (int k = 0; k < SU; k++) {
-            const uint32_t i = min(l + k * lpb, NSRC + nref - 1);
-            v[k] = make_uint4(0, 0, 0, 0);
-            if (i < NSRC) {
-                __builtin_memcpy(&v[k], gs + (size_t)(i / (CW / CS)) * src_stride + (i % (CW / CS)) * CS, CS);
-            } else {
-                const uint32_t j = i - NSRC;
-                const uint32_t rr = cpr == 1 ? j : __umulhi(j, cpr_magic), c = j - rr * cpr;
-                const size_t off = (size_t)rr * ref_stride + c * 16;
-                const size_t offc = off + 16 <= span ? off : span - 16;     // footprint tail: the last 16 bytes instead
-                __builtin_memcpy(&v[k], gr + offc, 16);
+            const uint8_t* p = (k_is_src[k] ? gs : gr) + goff[k];
+            if constexpr (CS == 16) {
+                __builtin_memcpy(&v[k], p, 16);
+            } else {                                        // 8-B source chunks: never read past the source block
+                v[k] = make_uint4(0, 0, 0, 0);
+                if (k_is_src[k]) __builtin_memcpy(&v[k], p, CS); else __builtin_memcpy(&v[k], p, 16);
             }
         }
     };
@@ -637,24 +671,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
         asm volatile("" ::"v"(v[0].x), "v"(v[1].x), "v"(v[2].x), "v"(v[3].x), "v"(v[4].x), "v"(v[5].x), "v"(v[6].x), "v"(v[7].x));
 #pragma unroll
         for (int k = 0; k < SU; k++) {
-            const uint32_t i = l + k * lpb;
-            if (i < NSRC) {
-                __builtin_memcpy(s_src + i * CS, &v[k], CS);
-            } else if (i < NSRC + nref) {
-                const uint32_t j = i - NSRC;
-                const uint32_t rr = cpr == 1 ? j : __umulhi(j, cpr_magic), c = j - rr * cpr;
-                const size_t off = (size_t)rr * ref_stride + c * 16;
-                const uint32_t dst = rr * wpitch + c * 16;
-                if (off + 16 <= span) {
-                    uint2* rd = reinterpret_cast<uint2*>(s_ref + dst);
+            auto put = [&](uint32_t kind, uint8_t* d) {
+                if (kind == 1) {
+                    __builtin_memcpy(d, &v[k], CS);
+                } else if (kind == 2) {                    // two 8-B halves (window origins are 8-B aligned only)
+                    uint2* rd = reinterpret_cast<uint2*>(d);
                     rd[0] = make_uint2(v[k].x, v[k].y); rd[1] = make_uint2(v[k].z, v[k].w);
-                } else {                                   // stored `delta` bytes earlier, byte-granular
-                    const uint32_t delta = (uint32_t)(off + 16 - span);
-                    const uint32_t vw[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-#pragma unroll
-                    for (int bb = 0; bb < 16; bb++) s_ref[dst - delta + bb] = (uint8_t)(vw[bb >> 2] >> (8 * (bb & 3)));
+                } else if (kind == 3) {                    // byte-granular address: gfx950 LDS takes the unaligned 16-B store
+                    struct __attribute__((packed, aligned(1))) U4 { uint32_t a, b, c, e; };
+                    *reinterpret_cast<U4*>(d) = U4{v[k].x, v[k].y, v[k].z, v[k].w};
                 }
-            }
+            };
+            const uint32_t uk = (uint32_t)__builtin_amdgcn_readfirstlane((int)ukind[k]);      // scalar: s_cmp + s_cbranch below
+            if (uk == 1u) put(1u, smem + ldst[k]);
+            else if (uk == 2u) put(2u, smem + ldst[k]);
+            else if (uk == 3u) put(3u, smem + ldst[k]);
+            else if (uk == 4u) put(ldst[k] >> 30, smem + (ldst[k] & 0x3fffffffu));
         }
         wave_lds_fence();
         // ---- next set's chunks: in flight during the search below ----------------------------------------------------
@@ -662,7 +694,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
         // ---- search (sad_search_q2_kernel) -------------------------------------------------------------------------------
         const uint32_t blk = set * bpw + wslot;
         const bool valid = blk < nblocks;
-        unsigned long long best = ~0ull;
+        // argmin key = sad << 16 | y << 8 | x of the candidate (a 16x16 SAD is at most 65 280; the host sends search areas
+        // wider or taller than 256 to the one-shot kernel): one v_min_u32 per candidate, first strict minimum as the reference
+        uint32_t best = 0xffffffffu;
         {
             const int gx = (search_w + 3) >> 2, gy = (search_h + 1) >> 1;
             const int ngroups = gx * gy;
@@ -722,37 +756,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                     for (int q = 0; q < WQ; q++) accB = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)rw[q + 1] << 32) | rw[q], sprev[q], accB);
                 }
                 const int xs0 = xg * 4;
+                const uint32_t idxA = (uint32_t)((ysA << 8) | xs0), idxB = idxA + 256u;      // y << 8 | x: raster order, no division
+                const uint32_t aw[2] = {(uint32_t)accA, (uint32_t)(accA >> 32)}, bw[2] = {(uint32_t)accB, (uint32_t)(accB >> 32)};
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++) {
-                    if (xs0 + jj < search_w) {
-                        const unsigned sa = (unsigned)((accA >> (16 * jj)) & 0xffffu), sb = (unsigned)((accB >> (16 * jj)) & 0xffffu);
-                        const unsigned long long ka = ((unsigned long long)sa << 32) | (unsigned)(ysA * search_w + xs0 + jj);
-                        best = ka < best ? ka : best;
-                        if (hasB) {
-                            const unsigned long long kb = ((unsigned long long)sb << 32) | (unsigned)((ysA + 1) * search_w + xs0 + jj);
-                            best = kb < best ? kb : best;
-                        }
-                    }
+                    const bool in = xs0 + jj < search_w;
+                    const uint32_t sa = (jj & 1) ? (aw[jj >> 1] & 0xffff0000u) : (aw[jj >> 1] << 16);
+                    const uint32_t sb = (jj & 1) ? (bw[jj >> 1] & 0xffff0000u) : (bw[jj >> 1] << 16);
+                    const uint32_t ka = in ? (sa | (idxA + jj)) : 0xffffffffu;
+                    const uint32_t kb = (in && hasB) ? (sb | (idxB + jj)) : 0xffffffffu;
+                    best = min(best, min(ka, kb));
                 }
             }
         }
-        for (uint32_t m = lpb >> 1; m >= 1; m >>= 1) {
-            const unsigned long long o = __shfl_xor(best, (int)m, 64);
-            best = o < best ? o : best;
-        }
+        for (uint32_t m = lpb >> 1; m >= 1; m >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, (int)m, 64));
         // lane t < bpw takes block slot t's result: contiguous stores
-        const unsigned long long key = __shfl(best, (int)((lane & (bpw - 1)) << lsh), 64);
+        const uint32_t key = (uint32_t)__shfl((int)best, (int)((lane & (bpw - 1)) << lsh), 64);
         const uint32_t ob = set * bpw + lane;
         if (lane < bpw && ob < nblocks) {
-            const unsigned sadv = (unsigned)(key >> 32);
-            const int cand = (int)(key & 0xffffffffu);
-            if (sadv < 0xffffffu) {          // reference initialises best_sad = 0xffffff, strict '<'
-                best_sad[ob] = sadv;
-                best_x[ob] = (int16_t)(cand % search_w);
-                best_y[ob] = (int16_t)(cand / search_w);
-            } else {
-                best_sad[ob] = 0xffffffu;
-            }
+            best_sad[ob] = key >> 16;                     // (a SAD below the reference's initial best 0xffffff always exists)
+            best_x[ob] = (int16_t)(key & 0xffu);
+            best_y[ob] = (int16_t)((key >> 8) & 0xffu);
         }
         (void)valid;
         wave_lds_fence();                                  // the search's LDS reads are done before the next set overwrites

@@ -144,18 +144,29 @@ static int sad_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src
             // persistent, software-pipelined form (loads of the next set of blocks in flight during the search): whenever a
             // lane's share of one block's chunks fits 8 registers-of-16-B
             const uint32_t nsrc_chunks = width * height / (width % 16 == 0 ? 16u : 8u);
-            if (!g_tune_no_q2p && nsrc_chunks + nchunk <= 8 * lpb) {
-                const uint32_t nsets = (uint32_t)((nblocks + 64 / lpb - 1) / (64 / lpb));
-                const uint32_t wg_per_cu = (uint32_t)(160 * 1024 / ((size_t)slots * per_blk));
-                uint32_t pgrid = (uint32_t)g_num_cu * (wg_per_cu ? wg_per_cu : 1);
-                const uint32_t need = (nsets + threads / 64 - 1) / (threads / 64);
-                if (pgrid > need) pgrid = need;
+            if (!g_tune_no_q2p && nsrc_chunks + nchunk <= 8 * lpb && search_area_width <= 256 && search_area_height <= 256) {
+                // LDS per block: source + 16 B, window rows at 16 * cpr + 8 bytes, block stride == 64 (mod 128) (bank spread, see the kernel)
+                const uint32_t cpr = (win_w + 15) >> 4, wpitch_p = 16 * cpr + 8;
+                uint32_t wstride = wpitch_p * nrows + 8;
+                wstride = ((wstride + 63) & ~127u) + 64;
+                if (wstride < wpitch_p * nrows + 8) wstride += 128;
+                const uint32_t per_blk_p = src_bytes + 16 + wstride;
+                uint32_t pthreads = 256;
+                while (pthreads > 64 && (size_t)(pthreads / lpb) * per_blk_p > 64 * 1024) pthreads >>= 1;
+                const uint32_t pslots = pthreads / lpb, pwaves = pthreads / 64;
+                const size_t plds = (size_t)pslots * per_blk_p;
+                if (lpb <= 64 && pslots >= pwaves && plds <= 64 * 1024) {
+                    const uint32_t nsets = (uint32_t)((nblocks + 64 / lpb - 1) / (64 / lpb));
+                    const uint32_t wg_per_cu = (uint32_t)(160 * 1024 / plds);
+                    const uint32_t by_waves = 16 / pwaves;                       // 4 waves per SIMD (124 VGPRs)
+                    uint32_t pgrid = (uint32_t)g_num_cu * (wg_per_cu < by_waves ? (wg_per_cu ? wg_per_cu : 1) : by_waves);
+                    const uint32_t need = (nsets + pwaves - 1) / pwaves;
+                    if (pgrid > need) pgrid = need;
 #define SSQ2P(CW, CH)                                                                                                   \
-    hipLaunchKernelGGL((sad_search_q2p_kernel<CW, CH>), dim3(pgrid), dim3(threads), (size_t)slots * per_blk, (hipStream_t)stream, \
+    hipLaunchKernelGGL((sad_search_q2p_kernel<CW, CH>), dim3(pgrid), dim3(pthreads), plds, (hipStream_t)stream,                     \
                        d_src, src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, (int)search_area_width,         \
-                       (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, ref_bytes, lpb, cpr_magic,           \
+                       (int)search_area_height, (unsigned long long*)d_best_sad, d_x, d_y, wstride, wpitch_p, lpb, cpr_magic,    \
                        d_src_offs, d_ref_offs, (uint32_t)nblocks)
-                if (threads >= 64) {
                     if (width == 16) SSQ2P(16, 16); else SSQ2P(8, 8);
 #undef SSQ2P
                     return launch_status("sad_search_q2p");
