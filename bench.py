@@ -256,13 +256,18 @@ def main():
     if rank == 0:
         total_blocks = n * world * args.steps
         achieved = BYTES_PER_BLOCK * n / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the PMC counters are NOT measured by this run: they come from the committed profile of the
+        # same command (tools/profile_round.sh: separate rocprofv3 --pmc passes); the line says which file, and for which
+        # kernel build (git commit of the profiled tree) it stands.
+        traffic = traffic_source = traffic_commit = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("blocks") == n:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = tj.get("source")
+                    traffic_commit = tj.get("commit")
             except Exception:
                 traffic = None
         result = {
@@ -284,7 +289,8 @@ def main():
                        "blocks_per_gpu": n, "global_blocks": n * world, "tx_size": "TX_32X32",
                        "tx_type": "DCT_DCT", "parallelism": f"block-range shard x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_profiled_commit": traffic_commit,
                          "bytes_per_block": BYTES_PER_BLOCK, "kernel_ms": kernel_ms,
                          "kernel": "fwd32_kernel<IN_U8,QUANT,WITH_SAD>"},
             "device": dsp.device_name(),

@@ -25,7 +25,7 @@ for f in glob.glob(f"{out}/pmc_*.csv"):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 mean = {k: sum(v) / len(v) for k, v in agg.items()}
 blocks = 1 << 20
-res = {"round": 1, "tag": tag, "kernel": "fwd32_kernel<true,true,true,1,false,2> (headline fused chain)", "blocks": blocks,
+res = {"round": int(tag[1:3]) if tag[:1] == "r" and tag[1:3].isdigit() else None, "tag": tag, "kernel": "fwd32_kernel<true,true,true,1,false,2> (headline fused chain)", "blocks": blocks,
        "command": "rocprofv3 --kernel-trace --pmc <C> -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline (one pass per counter group)"}
 if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
     rd = 2 * mean["FETCH_SIZE"] * 1024; wr = mean["WRITE_SIZE"] * 1024
@@ -33,7 +33,8 @@ if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
                 "correction": "gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md HBM): read bytes = 2*FETCH_SIZE*1024; WRITE_SIZE exact",
                 "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                 "algorithmic_bytes_per_launch": 14342 * blocks, "traffic_over_algorithmic": (rd + wr) / (14342 * blocks)})
-    json.dump({"blocks": blocks, "hbm_bytes_per_launch": rd + wr, "source": f"profiles/{tag}_pmc.json"}, open(f"{out}/traffic_latest.json", "w"))
+    commit = open("GIT_COMMIT").read().strip() if __import__("os").path.exists("GIT_COMMIT") else None
+    json.dump({"blocks": blocks, "hbm_bytes_per_launch": rd + wr, "source": f"profiles/{tag}_pmc.json", "commit": commit}, open(f"{out}/traffic_latest.json", "w"))
 for k, v in mean.items():
     if k not in ("FETCH_SIZE", "WRITE_SIZE"): res[k] = v
 json.dump(res, open(f"{out}/pmc.json", "w"), indent=1)
