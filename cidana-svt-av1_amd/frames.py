@@ -37,8 +37,17 @@ class FramePass:
                 if side < 4:
                     continue
                 ts = TX_OF_SIDE[side]
-                ph, pw = src.shape
-                xy, offs = tile_origins(pw, ph, side)
+                if src.dim() == 3:                # a stack of F pictures [F, H, W] (a GOP): every picture tiled on its own, one launch
+                    nf, ph, pw = src.shape
+                    if nf * ph > 0xffff:
+                        raise ValueError("a stack of pictures must stay below 65 536 rows (16-bit origins)")
+                    xy1, offs1 = tile_origins(pw, ph, side)
+                    rows = (np.arange(nf, dtype=np.uint32) * np.uint32(ph))[:, None]
+                    xy = (xy1[None, :] + (rows << 16)).reshape(-1).astype(np.uint32)
+                    offs = (offs1[None, :] + rows * np.uint32(pw)).reshape(-1).astype(np.uint32)
+                else:
+                    ph, pw = src.shape
+                    xy, offs = tile_origins(pw, ph, side)
                 n = xy.size
                 if n == 0:
                     continue

@@ -4,6 +4,7 @@ residual -> FwdTxfm2d -> quantise / dequantise -> InvTxfm2d + add on planes.  Th
   sequential   one entry-point call per (plane, size) group on one stream (round 1's figure)
   frame        ONE svt_hip_encode_recon_frame call: the groups run concurrently on the library's internal streams
   frame_graph  that call captured once into a HIP graph and replayed
+  frame_gop16_per_frame  16 independent frames stacked into one call (13 launches for the GOP), time per frame
 Bytes: 7 B/px kept outputs (src, pred u8 in; qcoeff i32 + recon u8 out) - SURVEY 8(d)'s fused figure; the 4x4 groups also
 write coeff / dqcoeff.  One JSON line per mode + a summary; also written to gpurun_out/frame_c4.json."""
 import json
@@ -62,6 +63,15 @@ per_size = {}
 for S in frames.LUMA_SIZES:
     f1 = frames.FramePass(dsp, pkg, src, pred, luma_sizes=(S,))
     per_size[S] = {"ms": round(timeit(lambda: f1.run(qrow)), 4), "blocks": f1.blocks, "pixels": f1.pixels}
+# a GOP of 16 such frames in one call (the frames of this path are independent: SURVEY 8e): launch cost amortised
+NF = 16
+srcg = {k: torch.randint(0, 256, (NF,) + s, dtype=torch.uint8, device=dev, generator=g) for k, s in shapes.items()}
+predg = {k: torch.randint(0, 256, (NF,) + s, dtype=torch.uint8, device=dev, generator=g) for k, s in shapes.items()}
+fpg = frames.FramePass(dsp, pkg, srcg, predg)
+assert fpg.pixels == NF * fp.pixels
+rows["frame_gop16_per_frame"] = timeit(lambda: fpg.run(qrow), iters=10) / NF
+if os.environ.get("FRAME_ONLY_GOP"):          # for rocprofv3: only the GOP call's kernels in the trace
+    sys.exit(0)
 out = {"config": "configs[3]: one 1920x1080 yuv420p frame, luma sizes 64/32/16/8/4 + chroma at half the side, 8-bit, qindex 100",
        "groups": len(fp.groups), "blocks": fp.blocks, "pixel_passes": fp.pixels,
        "ms_per_frame": {k: round(v, 4) for k, v in rows.items()},
