@@ -5,6 +5,7 @@
 #include "kernel_quant.h"
 #include "kernel_txfm.h"
 #include "kernel_txfm_staged.h"
+#include "kernel_enc64.h"
 
 using namespace svtdev;
 using namespace svthost;
@@ -379,6 +380,16 @@ static int encode_recon_impl(const void* d_src_v, uint32_t src_stride, const voi
         for (int i = 0; i < 2; i++) ok = ok && qp.quant_shift[i] >= 0 && qp.dequant[i] >= 0 && qp.round[i] >= 0;
         ok = ok && (((uintptr_t)d_qcoeff | (uintptr_t)d_coeff | (uintptr_t)d_dqcoeff) & 15) == 0;
         ok = ok && (d_xy || (((uintptr_t)d_src | (uintptr_t)d_pred | (uintptr_t)d_recon) & 15) == 0);
+        if (ok && tx_size == SVT_TX_64X64 && !g_tune_no_enc64) {
+            // two blocks per wave, pruned 64-point networks (kernel_enc64.h)
+            const dim3 grid((uint32_t)((nblocks + 2 * E64_WAVES - 1) / (2 * E64_WAVES)));
+#define ENC64(T, B, KEEP) hipLaunchKernelGGL((enc64_kernel<T, B, KEEP>), grid, dim3(E64_WAVES * 64), 0, s, (const T*)d_src_v, (const T*)d_pred_v, (T*)d_recon_v, \
+                                            d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks, d_xy, src_stride, pred_stride, recon_stride)
+            if (is_16bit) { if (d_coeff) ENC64(uint16_t, 10, true); else ENC64(uint16_t, 10, false); }
+            else { if (d_coeff) ENC64(uint8_t, 8, true); else ENC64(uint8_t, 8, false); }
+#undef ENC64
+            return launch_status("encode_recon_64x64");
+        }
         if (ok) {
 #define ENCS(W, H) launch_enc_staged<W, H>(d_src_v, d_pred_v, d_recon_v, is_16bit, d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, tx_type, nblocks, d_xy, src_stride, pred_stride, recon_stride, s)
             TX_SWITCH(tx_size, ENCS)

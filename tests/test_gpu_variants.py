@@ -67,6 +67,56 @@ def test_encode_recon_variants(dsp, knob, tx_size):
     assert _eq(a, b)
 
 
+@pytest.mark.parametrize("n,keep,kind", [(1, False, "smooth"), (2, True, "smooth"), (5, False, "random"), (64, True, "extreme"), (33, False, "edge")])
+def test_encode_recon_64x64_two_blocks_per_wave_vs_one(dsp, n, keep, kind):
+    """enc64_kernel (two blocks per wave, pruned 64-point networks, clamp-free inverse under the L1 bound) against the generic
+    staged kernel: odd batches (the last wave's second block is a repeat), quiet / noisy / saturated residuals (the last takes
+    the clamped inverse), with and without coeff / dqcoeff outputs"""
+    rng = np.random.default_rng(640 + n)
+    if kind == "edge":       # full-swing residuals: rows whose L1 exceeds the clamp-free bound
+        src = np.where(rng.integers(0, 2, size=(n, 64, 64)) > 0, 255, 0).astype(np.uint8); pred = 255 - src
+        src[: n // 2] = rng.integers(0, 256, size=(n // 2, 64, 64)); pred[: n // 2] = 128
+    else:
+        src, pred = make_pixels(rng, n, 64, 64, kind)
+    _, iscan = svtlibs.scan_tables(4, 0)
+    for q in (30, 200):
+        call = lambda: dsp.encode_recon(dev(src), dev(pred), 4, 0, _qrow(8, q), dev(iscan), keep_coeff=keep)
+        try:
+            _tune(dsp, "no_enc64", 0); a = call()
+            _tune(dsp, "no_enc64", 1); b = call()
+        finally:
+            _tune(dsp, "no_enc64", 0)
+        torch.cuda.synchronize()
+        assert _eq(a, b), (n, keep, kind, q)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_encode_recon_64x64_planes_two_blocks_per_wave_vs_one(dsp, bd):
+    """the same A/B on picture planes (origin table, in-place reconstruction into a copy of the prediction), 8 and 10 bit"""
+    rng = np.random.default_rng(6400 + bd)
+    PH, PW = 3 * 64 + 8, 5 * 64 + 24
+    dt = np.uint8 if bd == 8 else np.uint16
+    srcp = rng.integers(0, 1 << bd, size=(PH, PW)).astype(dt)
+    predp = np.clip(srcp.astype(np.int32) + rng.integers(-30, 31, size=(PH, PW)), 0, (1 << bd) - 1).astype(dt)
+    xs = np.arange(0, PW - 63, 64); ys = np.arange(0, PH - 63, 64)
+    xy = ((ys[:, None] << 16) | xs[None, :]).reshape(-1).astype(np.uint32)
+    _, iscan = svtlibs.scan_tables(4, 0)
+    view = (lambda a: a) if bd == 8 else (lambda a: a.view(np.int16))
+    outs = []
+    try:
+        for knob in (0, 1):
+            _tune(dsp, "no_enc64", knob)
+            recon = dev(view(predp))
+            r = dsp.encode_recon_planes(dev(view(srcp)), PW, dev(view(predp)), PW, recon, PW, dev(xy.view(np.int32)), 4, 0, _qrow(bd, 90), dev(iscan), bd=bd)
+            r["recon"] = recon
+            outs.append(r)
+    finally:
+        _tune(dsp, "no_enc64", 0)
+    torch.cuda.synchronize()
+    assert _eq(outs[0], outs[1])
+    assert not torch.equal(outs[0]["recon"], dev(view(predp)))            # something was reconstructed
+
+
 @pytest.mark.parametrize("knob", ["no_inv_planes", "no_staged"])
 @pytest.mark.parametrize("tx_size,bd", [(2, 8), (1, 8), (4, 8), (11, 8), (2, 10), (4, 10)])
 def test_inverse_on_planes_variants(dsp, knob, tx_size, bd):
