@@ -34,6 +34,7 @@ extern int g_tune_no_q2p;
 extern int g_tune_no_q16;
 extern int g_tune_q2_su4;
 extern int g_tune_ois_no_fold;
+extern int g_tune_ois_no_nd;
 extern int g_tune_no_me16;
 extern int g_tune_me_exact;
 extern int g_tune_no_f32p;

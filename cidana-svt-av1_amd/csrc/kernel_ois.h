@@ -132,4 +132,132 @@ __global__ __launch_bounds__(256) void ois_sad_kernel(const uint8_t* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------
+// ois_nd_kernel: every NON-directional candidate of the list (DC under the availability rule, V / H - the directional modes at 90 /
+// 180 degrees -, SMOOTH, SMOOTH_V, SMOOTH_H, PAETH) predicted and compared with the source block in one pass, nothing written
+// but the sums: a lane takes its chunk of the source block and the neighbour samples that chunk needs STRAIGHT FROM THE
+// PICTURE (update_neighbor_samples_array_open_loop's rules: 127 above / 129 left / 128 corner when the picture has no such
+// sample, EbIntraPrediction.c:4707-4773), forms each candidate's prediction of its 8 or 16 pixels in registers and adds
+// |source - prediction| with v_sad_u8.  Candidates of kind OIS_K_FOLDED were summed by the directional kernels (SAD mode) and
+// are picked up from dist.  Then, as in ois_sad_kernel: the block's row of sums through LDS, one contiguous store, best index =
+// first strict minimum.  With a list that has no directional candidate (every 32x32 / 64x64 list, EbMotionEstimation.c:8747)
+// this is the whole open-loop search in ONE launch - no neighbour arrays, no prediction scratch.
+// ---------------------------------------------------------------------------
+enum { OIS_K_DC = 0, OIS_K_V, OIS_K_H, OIS_K_SMOOTH, OIS_K_SMOOTH_V, OIS_K_SMOOTH_H, OIS_K_PAETH, OIS_K_FOLDED };
+struct OisKinds { uint8_t k[OIS_MAX_CAND + 3]; };
+
+__device__ constexpr uint8_t kOisSmWeights[128] = {          // sm_weight_arrays (ASM_AVX2/EbIntraPrediction_AVX2.h:19-38), index [bs + i]
+    0, 0, 255, 128, 255, 149, 85, 64, 255, 197, 146, 105, 73, 50, 37, 32,
+    255, 225, 196, 170, 145, 123, 102, 84, 68, 54, 43, 33, 26, 20, 17, 16,
+    255, 240, 225, 210, 196, 182, 169, 157, 145, 133, 122, 111, 101, 92, 83, 74,
+    66, 59, 52, 45, 39, 34, 29, 25, 21, 17, 14, 12, 10, 9, 8, 8,
+    255, 248, 240, 233, 225, 218, 210, 203, 196, 189, 182, 176, 169, 163, 156, 150,
+    144, 138, 133, 127, 121, 116, 111, 106, 101, 96, 91, 86, 82, 77, 73, 69,
+    65, 61, 57, 54, 50, 47, 44, 41, 38, 35, 32, 29, 27, 25, 22, 20,
+    18, 16, 15, 13, 12, 10, 9, 8, 7, 6, 6, 5, 5, 4, 4, 4};
+
+template <int CS>            // pixels per lane: 8 (8x8 blocks) or 16
+__global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__ pic, uint32_t stride, uint32_t width, uint32_t height,
+                                                     const uint32_t* __restrict__ xy, uint32_t bsize, OisKinds kinds, uint32_t* dist,
+                                                     int8_t* __restrict__ best_index, uint32_t ncand, uint32_t nblocks) {
+    extern __shared__ uint32_t s_dist[];                  // [slots][ncand] (+ [4][ncand] wave partials and 4 DC partials for 64x64)
+    const uint32_t lpb = bsize * bsize / CS;              // 8, 16, 64, 256
+    const uint32_t lsh = __builtin_ctz(lpb);
+    const uint32_t slots = 256u >> lsh;
+    const uint32_t slot = threadIdx.x >> lsh, l = threadIdx.x & (lpb - 1);
+    const uint32_t blk = blockIdx.x * slots + slot;
+    const bool valid = blk < nblocks;
+    const uint32_t q = xy[valid ? blk : 0];
+    const uint32_t x = q & 0xffffu, y = q >> 16;
+    const uint32_t cpr_sh = __builtin_ctz(bsize / CS);
+    const uint32_t row = l >> cpr_sh, col = (l & ((1u << cpr_sh) - 1)) * CS;
+    const uint8_t* sblk = pic + (size_t)y * stride + x;
+    const bool has_a = y != 0, has_l = x != 0;
+    // ---- this lane's samples: source chunk, the above segment over it, its row's left sample, the three corners --------------
+    uint32_t sv[4] = {0, 0, 0, 0}, av[4];
+    __builtin_memcpy(sv, sblk + (size_t)row * stride + col, CS);
+    if (has_a && x + col + CS <= width) {
+        av[2] = av[3] = 0;
+        __builtin_memcpy(av, sblk - (ptrdiff_t)stride + col, CS);
+    } else {
+        uint8_t t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = (k < CS && has_a && x + col + k < width) ? sblk[(ptrdiff_t)(col + k) - (ptrdiff_t)stride] : (uint8_t)127;
+        __builtin_memcpy(av, t, 16);
+    }
+    auto left_at = [&](uint32_t r) { return (has_l && y + r < height) ? (int)sblk[(size_t)r * stride - 1] : 129; };
+    auto above_at = [&](uint32_t c) { return (has_a && x + c < width) ? (int)sblk[(ptrdiff_t)c - (ptrdiff_t)stride] : 127; };
+    const int lf = left_at(row), bl = left_at(bsize - 1), tr = above_at(bsize - 1);
+    const int tl = (has_a && has_l) ? (int)sblk[-(ptrdiff_t)stride - 1] : 128;
+    // ---- DC value: sum of the first bsize samples of each edge the picture has (dc_pred[x > 0][y > 0], :4801) ------------------
+    int dsum = 0;
+    for (uint32_t i = l; i < 2 * bsize; i += lpb) dsum += i < bsize ? (has_a ? above_at(i) : 0) : (has_l ? left_at(i - bsize) : 0);
+    const uint32_t span = lpb < 64 ? lpb : 64;
+    for (uint32_t m = span >> 1; m >= 1; m >>= 1) dsum += __shfl_xor(dsum, (int)m, 64);
+    uint32_t* row_out = s_dist + (size_t)slot * ncand;
+    uint32_t* wave_part = s_dist + (size_t)slots * ncand;            // 64x64 only: [wave][cand], then 4 DC partials
+    if (lpb > 64) {
+        if ((threadIdx.x & 63) == 0) wave_part[4 * ncand + (threadIdx.x >> 6)] = (uint32_t)dsum;
+        __syncthreads();
+        dsum = (int)(wave_part[4 * ncand] + wave_part[4 * ncand + 1] + wave_part[4 * ncand + 2] + wave_part[4 * ncand + 3]);
+    }
+    const uint32_t lg = __builtin_ctz(bsize);
+    const int dcv = (has_a && has_l) ? (dsum + (int)bsize) >> (lg + 1) : ((has_a || has_l) ? (dsum + (int)(bsize >> 1)) >> lg : 128);
+    const int wh = kOisSmWeights[bsize + row];
+    // ---- candidates -------------------------------------------------------------------------------------------------------------
+    for (uint32_t c = 0; c < ncand; c++) {
+        const uint32_t kind = kinds.k[c];                  // uniform (kernel argument)
+        if (kind == OIS_K_FOLDED) {
+            if (valid && l == 0) row_out[c] = dist[(size_t)blk * ncand + c];
+            continue;
+        }
+        uint32_t pv[4] = {0, 0, 0, 0};
+        if (kind == OIS_K_DC) { pv[0] = pv[1] = pv[2] = pv[3] = (uint32_t)dcv * 0x01010101u; }
+        else if (kind == OIS_K_V) { pv[0] = av[0]; pv[1] = av[1]; pv[2] = av[2]; pv[3] = av[3]; }
+        else if (kind == OIS_K_H) { pv[0] = pv[1] = pv[2] = pv[3] = (uint32_t)lf * 0x01010101u; }
+        else {
+#pragma unroll
+            for (int k = 0; k < CS; k++) {
+                const int t = (int)((av[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                const int ww = kOisSmWeights[bsize + col + k];
+                int v;
+                if (kind == OIS_K_SMOOTH) v = (wh * t + (256 - wh) * bl + ww * lf + (256 - ww) * tr + 256) >> 9;
+                else if (kind == OIS_K_SMOOTH_V) v = (wh * t + (256 - wh) * bl + 128) >> 8;
+                else if (kind == OIS_K_SMOOTH_H) v = (ww * lf + (256 - ww) * tr + 128) >> 8;
+                else {                                     // PAETH: nearest of left / top / top-left to top + left - topleft
+                    const int pb = t + lf - tl, pl = abs(pb - lf), pt = abs(pb - t), ptl = abs(pb - tl);
+                    v = (pl <= pt && pl <= ptl) ? lf : (pt <= ptl ? t : tl);
+                }
+                pv[k >> 2] |= (uint32_t)v << (8 * (k & 3));
+            }
+        }
+        uint32_t sad = 0;
+        sad = __builtin_amdgcn_sad_u8(sv[0], pv[0], sad);
+        sad = __builtin_amdgcn_sad_u8(sv[1], pv[1], sad);
+        if (CS == 16) { sad = __builtin_amdgcn_sad_u8(sv[2], pv[2], sad); sad = __builtin_amdgcn_sad_u8(sv[3], pv[3], sad); }
+        for (uint32_t m = span >> 1; m >= 1; m >>= 1) sad += __shfl_xor(sad, (int)m, 64);
+        if (lpb <= 64) { if (l == 0) row_out[c] = sad; }
+        else if ((threadIdx.x & 63) == 0) wave_part[(threadIdx.x >> 6) * ncand + c] = sad;
+    }
+    __syncthreads();
+    if (lpb > 64) {                                        // 64x64: one block per workgroup, add the four waves' partials
+        for (uint32_t c = threadIdx.x; c < ncand; c += 256)
+            if (kinds.k[c] != OIS_K_FOLDED) row_out[c] = wave_part[c] + wave_part[ncand + c] + wave_part[2 * ncand + c] + wave_part[3 * ncand + c];
+        __syncthreads();
+    }
+    const uint32_t first = blockIdx.x * slots;
+    const uint32_t nb_here = first < nblocks ? (nblocks - first < slots ? nblocks - first : slots) : 0;
+    for (uint32_t i = threadIdx.x; i < nb_here * ncand; i += 256) dist[(size_t)first * ncand + i] = s_dist[i];
+    if (threadIdx.x < nb_here) {
+        const uint32_t* r = s_dist + (size_t)threadIdx.x * ncand;
+        uint32_t best = 64u * 64u * 255u;
+        int bi = 0;
+        for (uint32_t c = 0; c < ncand; c++) {
+            const uint32_t d = r[c];
+            if (d < best) { best = d; bi = (int)c; }
+        }
+        best_index[first + threadIdx.x] = (int8_t)bi;
+    }
+}
+
 }  // namespace svtdev

@@ -320,6 +320,75 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
     hipStream_t st = (hipStream_t)stream;
     const size_t pitch = ois_nb_pitch(bsize);
     char* w = (char*)d_work;
+    // ---- fused form: the directional candidates (angles other than 90 / 180) sum their SADs inside intra_dir_kernel (blocks of
+    // at most 64 lanes: 8x8, 16x16), everything else - DC, V, H, SMOOTH*, PAETH - is predicted and summed inside ois_nd_kernel
+    // straight from the picture; no prediction ever goes to memory.  Lists without directional candidates (all 32x32 / 64x64
+    // lists) are ONE launch.
+    {
+        OisKinds kinds;
+        memset(&kinds, 0, sizeof(kinds));
+        bool any_dir = false;
+        for (int c = 0; c < ncand; c++) {
+            const int m = modes[c];
+            int k;
+            if (m == 0) k = OIS_K_DC;
+            else if (m <= 8) {
+                const int a = mode_angle[m] + 3 * angle_deltas[c];
+                k = a == 90 ? OIS_K_V : (a == 180 ? OIS_K_H : OIS_K_FOLDED);
+                any_dir = any_dir || k == OIS_K_FOLDED;
+            } else k = m == 9 ? OIS_K_SMOOTH : (m == 10 ? OIS_K_SMOOTH_V : (m == 11 ? OIS_K_SMOOTH_H : OIS_K_PAETH));
+            kinds.k[c] = (uint8_t)k;
+        }
+        const bool can_fold = bsize <= 16 && !g_tune_ois_no_fold;
+        if (!g_tune_ois_no_nd && (!any_dir || can_fold)) {
+            if (any_dir) {
+                uint8_t* d_above = (uint8_t*)w;
+                uint8_t* d_left = d_above + ois_align(nblocks * pitch);
+                uint8_t* d_dc = d_left + ois_align(nblocks * pitch);
+                if (hipMemsetAsync(d_above, 0, 2 * ois_align(nblocks * pitch), st) != hipSuccess) return set_err(SVT_HIP_ERR_RUNTIME, "hipMemsetAsync");
+                const uint32_t slots = 256 / (2 * bsize);
+                hipLaunchKernelGGL(ois_gather_kernel, dim3((uint32_t)((nblocks + slots - 1) / slots)), dim3(256), 0, st, d_pic, stride, width,
+                                   height, d_xy, bsize, d_above, d_left, (uint32_t)pitch, d_dc, (uint32_t)nblocks);
+                if (int rc = launch_status("ois_gather")) return rc;
+                DirMulti zone[3];
+                for (auto& z : zone) {
+                    z.n = 0; z.batch_pitch = 0;
+                    z.sad_pic = d_pic; z.sad_stride = stride; z.sad_xy = d_xy; z.sad_dist = d_distortion; z.sad_ncand = (uint32_t)ncand;
+                }
+                auto flush = [&](int zi) -> int {
+                    DirMulti& z = zone[zi];
+                    if (!z.n) return SVT_HIP_OK;
+                    const int rc = intra_pred_impl(d_distortion /* unused in SAD mode */, (int32_t)bsize, (size_t)bsize * bsize, nullptr, d_above, d_left,
+                                                   (int32_t)pitch, SVT_INTRA_Z1 + zi, (int)bsize, (int)bsize, 0, 0, 1, 1, 0, 8, nblocks, stream, &z);
+                    z.n = 0;
+                    return rc;
+                };
+                for (int c = 0; c < ncand; c++) {
+                    if (kinds.k[c] != OIS_K_FOLDED) continue;
+                    const int a = mode_angle[modes[c]] + 3 * angle_deltas[c];
+                    const int zi = a < 90 ? 0 : (a < 180 ? 1 : 2);
+                    DirMulti& z = zone[zi];
+                    if (z.n == 20) if (int rc = flush(zi)) return rc;
+                    z.dx[z.n] = (int16_t)(zi == 0 ? ois_dr_derivative(a) : (zi == 1 ? ois_dr_derivative(180 - a) : 1));
+                    z.dy[z.n] = (int16_t)(zi == 0 ? 1 : (zi == 1 ? ois_dr_derivative(a - 90) : ois_dr_derivative(270 - a)));
+                    z.slot[z.n] = (uint8_t)c;
+                    z.n++;
+                }
+                for (int zi = 0; zi < 3; zi++) if (int rc = flush(zi)) return rc;
+            }
+            const uint32_t cs = bsize < 16 ? 8 : 16, lpb = bsize * bsize / cs;
+            const uint32_t nd_slots = 256 / lpb;
+            const uint32_t nd_grid = (uint32_t)((nblocks + nd_slots - 1) / nd_slots);
+            const size_t shmem = (((size_t)nd_slots + (lpb > 64 ? 4 : 0)) * (size_t)ncand + 4) * sizeof(uint32_t);
+            if (cs == 8)
+                hipLaunchKernelGGL(ois_nd_kernel<8>, dim3(nd_grid), dim3(256), shmem, st, d_pic, stride, width, height, d_xy, bsize, kinds, d_distortion,
+                                   d_best_index, (uint32_t)ncand, (uint32_t)nblocks);
+            else
+                hipLaunchKernelGGL(ois_nd_kernel<16>, dim3(nd_grid), dim3(256), shmem, st, d_pic, stride, width, height, d_xy, bsize, kinds, d_distortion,
+                                   d_best_index, (uint32_t)ncand, (uint32_t)nblocks);
+            return launch_status("ois_nd");
+        }
+    }
     uint8_t* d_above = (uint8_t*)w;
     uint8_t* d_left = d_above + ois_align(nblocks * pitch);
     uint8_t* d_dc = d_left + ois_align(nblocks * pitch);

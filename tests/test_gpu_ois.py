@@ -95,6 +95,27 @@ def test_ois_fold_variant(dsp, bsize):
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("bsize,tl", [(8, 0), (16, 0), (8, 2), (32, 0), (64, 0), (32, 2)])
+def test_ois_fused_non_directional_variant(dsp, bsize, tl):
+    """ois_nd_kernel (non-directional candidates predicted and summed straight from the picture, one launch when the list has no
+    directional candidate) == the gather -> per-candidate prediction batches -> SAD kernel path; blocks at every picture border"""
+    rng = np.random.default_rng(100 + bsize + tl)
+    W, H, pad = 320, 192, 0
+    buf = rng.integers(0, 256, size=(H, W + 24), dtype=np.uint8)
+    buf[: H // 2] = (buf[: H // 2] >> 5) << 5                 # coarse half: ties between candidates
+    blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
+    modes, deltas = dsp.ois_candidates(bsize, tl)
+    plane = dev(buf)
+    out = []
+    try:
+        for v in (0, 1):
+            assert dsp.lib.svt_hip_tune(b"ois_no_nd", v) == 0
+            out.append(dsp.ois_search(plane, W + 24, W, H, _xy(blocks), bsize, modes, deltas))
+    finally:
+        dsp.lib.svt_hip_tune(b"ois_no_nd", 0)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 def test_ois_candidate_lists_match_oracle(dsp):
     O = svtlibs.oracle()
     for bsize in (8, 16, 32, 64):
