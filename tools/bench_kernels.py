@@ -201,4 +201,39 @@ if want("me_sb"):
         ms = timeit(lambda: dsp.me_sb_search(src, ref, 64, 64), iters=4)
         rec(f"me_sb_search_64x64area_{n}SBs({label})", n, 4096 + 127 * 127 + 680, ms, {"search_points_per_s_G": round(n * 4096 / ms / 1e6, 3)})
         del src, ref
+if want("me_fullpel"):
+    # K6 in the reference's own layout (p_sb_best_sad / p_sb_best_mv): the 85 square PUs (fast kernel) and all 209 PUs with the NSQ
+    # shapes (exact kernel: the reference's search-point order and update rules, both flavours)
+    n = 2040
+    src = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 127, 128), dtype=torch.uint8, device=dev)
+    for nsq in (False, True):
+        ms = timeit(lambda: dsp.me_fullpel_search(src, ref, 64, 64, nsq=nsq), iters=3)
+        rec(f"me_fullpel_search_64x64area_2040SBs({'209 PUs, NSQ' if nsq else '85 PUs'})", n, 4096 + 127 * 127 + (209 if nsq else 85) * 8, ms,
+            {"search_points_per_s_G": round(n * 4096 / ms / 1e6, 3)})
+    del src, ref
+if want("bip"):
+    # build_intra_predictors glue (a14): 16x16 blocks, per-block modes (all 13 x angle deltas) and availability, one launch
+    n = 1 << 20
+    top = torch.randint(0, 256, (n, 48), dtype=torch.uint8, device=dev); left = torch.randint(0, 256, (n, 48), dtype=torch.uint8, device=dev)
+    blk = torch.zeros((n, 8), dtype=torch.uint8, device=dev)
+    blk[:, 0] = torch.arange(n, device=dev) % 13
+    blk[:, 1] = ((torch.arange(n, device=dev) // 13) % 7 - 3).to(torch.int8).view(torch.uint8) * ((blk[:, 0] >= 1) & (blk[:, 0] <= 8)).to(torch.uint8)
+    blk[:, 4] = 16; blk[:, 5] = 16; blk[:, 6] = 16; blk[:, 7] = 16
+    out = torch.empty((n, 16, 16), dtype=torch.uint8, device=dev)
+    ms = timeit(lambda: dsp.build_intra_predictors(top, left, blk, 2, dst=out, dst_stride=16))
+    rec("build_intra_predictors_16x16_u8(mixed modes)", n, 256 + 2 * 33 + 8, ms)
+    del top, left, blk, out
+if want("hme"):
+    # HME level 0 on a 1/16-resolution 4K picture pair (960x540, 16x16 SBs... the level's own SB size), every SB, one launch
+    W, H, sb, pad = 960, 540, 16, 24
+    stride = W + 2 * pad
+    refb = torch.randint(0, 256, (H + 2 * pad, stride), dtype=torch.uint8, device=dev); srcp = torch.randint(0, 256, (H, W), dtype=torch.uint8, device=dev)
+    org = np.array([(x, y) for y in range(0, H, sb) for x in range(0, W, sb)], np.int16)
+    size = np.array([(min(sb, W - x), min(sb, H - y)) for x, y in org.tolist()], np.int16)
+    hw = np.array([64, 64], np.uint16); hh = np.array([32, 32], np.uint16)
+    prm = dsp.hme_level_params(0, hw, hh, 0, 0, 128, 64, 100, 100, pad, pad, W, H)
+    d_org = torch.from_numpy(org).to(dev); d_size = torch.from_numpy(size).to(dev)
+    ref00 = refb.view(-1)[pad * stride + pad:]
+    ms = timeit(lambda: dsp.hme_level(srcp, W, ref00, stride, d_org, d_size, None, 0, prm), iters=4)
+    rec("hme_level0_960x540_64x32area", org.shape[0], 16 * 8 + 79 * 47, ms, {"search_points_per_s_G": round(org.shape[0] * 64 * 32 / ms / 1e6, 3)})
 json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "kernels.json"), "w"), indent=1)
