@@ -480,6 +480,247 @@ __host__ __device__ inline void me_pu_rect(int pu, int& x, int& y, int& w, int& 
     else { x = (pu - 205) * 2; y = 0; w = 2; h = 8; }                                                     // 16x64
 }
 
+// ---------------------------------------------------------------------------
+// me_nsq4_kernel — all 209 PUs (open_loop_me_fullpel_search_sblock, EbMotionEstimation.c:3251) for search widths that are a
+// multiple of 8, where every search point goes through the eight-point form and a PU's result is simply the first strict
+// minimum of its SAD over the search points in raster order - both result flavours agree there (the quirks
+// me_fullpel_exact_kernel restates live in the single-point form and in the square-PU AVX2 path).
+//
+// Staging as me_sb_search16_kernel (even source rows + reference window in LDS).  A lane owns FOUR adjacent search points
+// (one packed u16 x 4 accumulator per SAD), walks the SB in 8-row bands and folds each band's eight 8x8 SADs into every
+// shape as soon as its parts exist:   band: 8x8, 16x8, 32x8 | two bands: 8x16, 16x16, 32x16, 64x16 | 32-row half: 8x32,
+// 16x32, 32x32, 64x32 | SB: 16x64, 32x64, 64x64.  Sums that fit 16 bits on every other row (up to 32x16 / 16x32: 65 280) stay
+// packed; larger ones are widened per point.  Each PU's four keys (sad << 16 | point, or 2 * sad << 12 | point for the wide
+// ones) are min-reduced over the wave on the DPP path and lane 63 folds them into the workgroup's table, indexed in the
+// reference's EbMeTierZeroPu order.  With four points per lane the reference window costs one dword read per v_qsad, so the
+// LDS pipe and the 209 reductions per pass - not v_qsad - set the pace: measured 20x+ over the exact kernel.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned me_key4_min(unsigned long long a, unsigned idb) {
+    const unsigned lo = (unsigned)a, hi = (unsigned)(a >> 32);
+    const unsigned k0 = ((lo << 16) | idb) + 0u, k1 = ((lo & 0xffff0000u) | idb) + 1u;
+    const unsigned k2 = ((hi << 16) | idb) + 2u, k3 = ((hi & 0xffff0000u) | idb) + 3u;
+    return min(min(k0, k1), min(k2, k3));
+}
+__device__ __forceinline__ void me_unpack4(unsigned long long a, unsigned (&o)[4]) {
+    o[0] = (unsigned)a & 0xffffu; o[1] = ((unsigned)a) >> 16; o[2] = (unsigned)(a >> 32) & 0xffffu; o[3] = (unsigned)(a >> 48);
+}
+__device__ __forceinline__ unsigned me_bigkey4_min(const unsigned (&s2)[4], unsigned idb) {      // s2 = doubled SADs (< 2^20)
+    return min(min((s2[0] << 12) | (idb + 0u), (s2[1] << 12) | (idb + 1u)), min((s2[2] << 12) | (idb + 2u), (s2[3] << 12) | (idb + 3u)));
+}
+
+__global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void me_nsq4_kernel(
+    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
+    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
+    const int16_t* __restrict__ origins /* [n][2] x,y or NULL */, int x_origin, int y_origin,
+    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t wpitch,
+    const uint32_t* __restrict__ src_offs, const uint32_t* __restrict__ ref_offs, uint32_t nblocks, uint32_t pu_pitch) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* s_src = reinterpret_cast<uint32_t*>(smem);            // [32 even rows][16 dwords]
+    uint8_t* s_ref = smem + 32 * 64;                                // [(64+sh-1)][wpitch], wpitch % 16 == 0
+    __shared__ unsigned s_red[4][ME_PUS_ALL];
+    const uint32_t blk = blockIdx.x;
+    if (blk >= nblocks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
+    const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
+    if (tid < 128) {
+        const int r = tid >> 2, c = tid & 3;
+        uint4 v;
+        __builtin_memcpy(&v, gs + (size_t)(2 * r) * src_stride + c * 16, 16);
+        reinterpret_cast<uint4*>(s_src)[tid] = v;
+    }
+    for (int i = tid; i < 4 * ME_PUS_ALL; i += ME_THREADS) (&s_red[0][0])[i] = 0xffffffffu;
+    const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
+    {
+        const uint32_t cpr = (win_w + 15) >> 4;
+        const size_t span = (size_t)(win_h - 1) * ref_stride + win_w;
+        for (uint32_t c = tid & 15; c < cpr; c += 16)
+            for (uint32_t y = tid >> 4; y < win_h; y += 16) {
+                const size_t off = (size_t)y * ref_stride + c * 16;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (off + 16 <= span) {
+                    __builtin_memcpy(&v, gr + off, 16);
+                    *reinterpret_cast<uint4*>(s_ref + (size_t)y * wpitch + c * 16) = v;
+                } else if (off < span) {                   // footprint tail: the last 16 bytes, stored earlier (see me_sb_search_kernel)
+                    const uint32_t back = (uint32_t)(off - (span - 16));
+                    __builtin_memcpy(&v, gr + (span - 16), 16);
+                    struct __attribute__((packed, aligned(1))) U4 { uint32_t a, b, c, d; };
+                    *reinterpret_cast<U4*>(s_ref + (size_t)y * wpitch + c * 16 - back) = U4{v.x, v.y, v.z, v.w};
+                }
+            }
+    }
+    __syncthreads();
+
+    auto put = [&](int pu, unsigned key) {                 // wave minimum of a PU's key -> this wave's row of the table
+        const unsigned k = wave_min_u32_to_lane63(key);
+        if (lane == 63) s_red[wave][pu] = min(s_red[wave][pu], k);
+    };
+    const int xq = search_w >> 2;
+    const int ntasks = xq * search_h;
+    for (int t0 = 0; t0 < ntasks; t0 += ME_THREADS) {
+        const int t = t0 + tid;
+        const bool act = t < ntasks;
+        const int tc = act ? t : 0;
+        const int ys = tc / xq, xs0 = (tc - ys * xq) * 4;
+        const unsigned idb = (unsigned)(ys * search_w + xs0);
+        const unsigned dead = act ? 0u : 0xffffffffu;
+        const uint8_t* rbase = s_ref + (size_t)ys * wpitch + xs0;
+        unsigned s64[4] = {0, 0, 0, 0};
+        unsigned s32top[2][4];
+        unsigned long long v16x32top[4];
+#pragma unroll 1
+        for (int h32 = 0; h32 < 2; h32++) {
+            unsigned long long s16h0[4], v8x16h0[8], PA[2], PB[2], v16x32[4];
+#pragma unroll
+            for (int h16 = 0; h16 < 2; h16++) {
+                unsigned long long acc0[8], s16[4], v8x16[8];
+#pragma unroll
+                for (int kb = 0; kb < 2; kb++) {
+                    unsigned long long acc[8];
+#pragma unroll
+                    for (int bx = 0; bx < 8; bx++) acc[bx] = 0;
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        const int row = (h16 * 2 + kb) * 8 + rr * 2;                  // SB row inside the 32-row half
+                        const uint4* sp = reinterpret_cast<const uint4*>(s_src + (h32 * 16 + (row >> 1)) * 16);
+                        const uint32_t* rp = reinterpret_cast<const uint32_t*>(rbase + (size_t)(h32 * 32 + row) * wpitch);
+                        uint32_t sw[16], rw[17];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { const uint4 a = sp[i]; sw[4 * i] = a.x; sw[4 * i + 1] = a.y; sw[4 * i + 2] = a.z; sw[4 * i + 3] = a.w; }
+#pragma unroll
+                        for (int i = 0; i < 17; i++) rw[i] = rp[i];
+#pragma unroll
+                        for (int q = 0; q < 16; q++)
+                            acc[q >> 1] = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)rw[q + 1] << 32) | rw[q], sw[q], acc[q >> 1]);
+                    }
+                    // ---- this 8-row band: 8x8, 16x8, 32x8 ----
+                    unsigned long long p16x8[4];
+#pragma unroll
+                    for (int bx = 0; bx < 8; bx++) {
+                        const int c16 = bx >> 1, z16 = 8 * h32 + 4 * (c16 >> 1) + 2 * h16 + (c16 & 1);
+                        put(21 + 4 * z16 + 2 * kb + (bx & 1), me_key4_min(acc[bx], idb) | dead);
+                    }
+#pragma unroll
+                    for (int c16 = 0; c16 < 4; c16++) {
+                        const int z16 = 8 * h32 + 4 * (c16 >> 1) + 2 * h16 + (c16 & 1);
+                        p16x8[c16] = me_pk_add(acc[2 * c16], acc[2 * c16 + 1]);
+                        put(95 + 2 * z16 + kb, me_key4_min(p16x8[c16], idb) | dead);
+                    }
+#pragma unroll
+                    for (int c32 = 0; c32 < 2; c32++)
+                        put(169 + 4 * (2 * h32 + c32) + 2 * h16 + kb, me_key4_min(me_pk_add(p16x8[2 * c32], p16x8[2 * c32 + 1]), idb) | dead);
+                    if (kb == 0) {
+#pragma unroll
+                        for (int bx = 0; bx < 8; bx++) acc0[bx] = acc[bx];
+#pragma unroll
+                        for (int c16 = 0; c16 < 4; c16++) s16[c16] = p16x8[c16];
+                    } else {
+#pragma unroll
+                        for (int bx = 0; bx < 8; bx++) {                              // 8x16
+                            const int c16 = bx >> 1, z16 = 8 * h32 + 4 * (c16 >> 1) + 2 * h16 + (c16 & 1);
+                            v8x16[bx] = me_pk_add(acc0[bx], acc[bx]);
+                            put(137 + 2 * z16 + (bx & 1), me_key4_min(v8x16[bx], idb) | dead);
+                        }
+#pragma unroll
+                        for (int c16 = 0; c16 < 4; c16++) s16[c16] = me_pk_add(s16[c16], p16x8[c16]);
+                    }
+                }
+                // ---- this 16-row band: 16x16, 32x16, 64x16 ----
+                unsigned long long p32x16[2];
+#pragma unroll
+                for (int c16 = 0; c16 < 4; c16++)
+                    put(5 + 8 * h32 + 4 * (c16 >> 1) + 2 * h16 + (c16 & 1), me_key4_min(s16[c16], idb) | dead);
+#pragma unroll
+                for (int c32 = 0; c32 < 2; c32++) {
+                    p32x16[c32] = me_pk_add(s16[2 * c32], s16[2 * c32 + 1]);         // <= 65 280 per lane
+                    put(87 + 2 * (2 * h32 + c32) + h16, me_key4_min(p32x16[c32], idb) | dead);
+                }
+                {
+                    unsigned a[4], b[4], s2[4];
+                    me_unpack4(p32x16[0], a); me_unpack4(p32x16[1], b);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) s2[j] = (a[j] + b[j]) << 1;
+                    put(201 + 2 * h32 + h16, me_bigkey4_min(s2, idb) | dead);
+                }
+                if (h16 == 0) {
+#pragma unroll
+                    for (int c16 = 0; c16 < 4; c16++) s16h0[c16] = s16[c16];
+#pragma unroll
+                    for (int bx = 0; bx < 8; bx++) v8x16h0[bx] = v8x16[bx];
+                    PA[0] = p32x16[0]; PA[1] = p32x16[1];
+                } else {
+#pragma unroll
+                    for (int c16 = 0; c16 < 4; c16++) {                               // 16x32 (<= 65 280)
+                        v16x32[c16] = me_pk_add(s16h0[c16], s16[c16]);
+                        put(129 + 2 * (2 * h32 + (c16 >> 1)) + (c16 & 1), me_key4_min(v16x32[c16], idb) | dead);
+                    }
+#pragma unroll
+                    for (int bx = 0; bx < 8; bx++)                                    // 8x32
+                        put(185 + 4 * (2 * h32 + (bx >> 2)) + (bx & 3), me_key4_min(me_pk_add(v8x16h0[bx], v8x16[bx]), idb) | dead);
+                    PB[0] = p32x16[0]; PB[1] = p32x16[1];
+                }
+            }
+            // ---- this 32-row half: 32x32, 64x32; parts of 32x64, 16x64, 64x64 ----
+            unsigned s32[2][4];
+#pragma unroll
+            for (int c32 = 0; c32 < 2; c32++) {
+                unsigned a[4], b[4];
+                me_unpack4(PA[c32], a); me_unpack4(PB[c32], b);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { s32[c32][j] = (a[j] + b[j]) << 1; s64[j] += s32[c32][j]; }
+                put(1 + 2 * h32 + c32, me_bigkey4_min(s32[c32], idb) | dead);
+            }
+            {
+                unsigned w[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) w[j] = s32[0][j] + s32[1][j];
+                put(85 + h32, me_bigkey4_min(w, idb) | dead);
+            }
+            if (h32 == 0) {
+#pragma unroll
+                for (int c32 = 0; c32 < 2; c32++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) s32top[c32][j] = s32[c32][j];
+#pragma unroll
+                for (int c16 = 0; c16 < 4; c16++) v16x32top[c16] = v16x32[c16];
+            } else {
+#pragma unroll
+                for (int c32 = 0; c32 < 2; c32++) {                                   // 32x64
+                    unsigned w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) w[j] = s32top[c32][j] + s32[c32][j];
+                    put(127 + c32, me_bigkey4_min(w, idb) | dead);
+                }
+#pragma unroll
+                for (int c16 = 0; c16 < 4; c16++) {                                   // 16x64
+                    unsigned a[4], b[4], w[4];
+                    me_unpack4(v16x32top[c16], a); me_unpack4(v16x32[c16], b);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) w[j] = (a[j] + b[j]) << 1;
+                    put(205 + c16, me_bigkey4_min(w, idb) | dead);
+                }
+            }
+        }
+        put(0, me_bigkey4_min(s64, idb) | dead);
+    }
+    __syncthreads();
+    if (tid < ME_PUS_ALL) {
+        const unsigned key = min(min(s_red[0][tid], s_red[1][tid]), min(s_red[2][tid], s_red[3][tid]));
+        // wide PUs carry (2 * sad) << 12 | point; the others sad16 << 16 | point with the SAD still to be doubled
+        const bool wide = tid < 5 || tid == 85 || tid == 86 || tid == 127 || tid == 128 || tid >= 201;
+        const unsigned sad = wide ? key >> 12 : (key >> 16) << 1;
+        const unsigned cand = key & 0xfffu;
+        const int ys = (int)cand / search_w, xs = (int)cand - ys * search_w;
+        const int ox = origins ? origins[2 * blk] : x_origin, oy = origins ? origins[2 * blk + 1] : y_origin;
+        uint32_t* bs = best_sad + (size_t)blk * pu_pitch;
+        uint32_t* bm = best_mv + (size_t)blk * pu_pitch;
+        if (sad < bs[tid]) {
+            bs[tid] = sad;
+            bm[tid] = (((uint32_t)(uint16_t)(ys + oy)) << 18) | (uint32_t)(uint16_t)((xs + ox) << 2);
+        }
+    }
+}
+
 // me_fullpel_exact_kernel — the reference's search, search point by search point, in its own order: every width, both
 // result flavours (0 = its C / SSE4.1 kernels, 1 = what its AVX2 build compiled by GCC / clang computes), square PUs only
 // or all 209.  This is the general path behind svt_hip_me_fullpel_search_batch; the fast kernels take the shapes they

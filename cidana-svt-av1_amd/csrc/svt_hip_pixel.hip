@@ -383,6 +383,19 @@ extern "C" int svt_hip_me_fullpel_search_batch(const uint8_t* d_src, uint32_t sr
             return launch_status("me_sb_search16 (reference layout)");
         }
     }
+    if (nsq && !g_tune_me_exact && (search_w & 7) == 0) {
+        // all 209 PUs, widths where every point takes the reference's eight-point form: 4 points per lane, every shape folded
+        // out of the packed 8x8 SADs (me_nsq4_kernel); other widths keep the exact kernel (single-point quirks)
+        const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
+        const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+        const size_t lds = 32 * 64 + (size_t)wpitch * win_h;
+        if (lds <= 58 * 1024) {
+            hipLaunchKernelGGL(me_nsq4_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src, src_stride,
+                               src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins, x_origin, y_origin,
+                               d_best_sad, d_best_mv, wpitch, d_src_offsets, d_ref_offsets, (uint32_t)nblocks, pu_pitch);
+            return launch_status("me_nsq4");
+        }
+    }
     hipLaunchKernelGGL(me_fullpel_exact_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), 0, (hipStream_t)stream, d_src, src_stride,
                        src_block_pitch, d_src_offsets, d_ref, ref_stride, ref_block_pitch, d_ref_offsets, search_w, search_h,
                        d_origins, x_origin, y_origin, flavour, nsq ? 1 : 0, d_best_sad, d_best_mv, pu_pitch, (uint32_t)nblocks);
