@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .sharding import DIGEST_MOD
+
 TX_OF_SIDE = {64: 4, 32: 3, 16: 2, 8: 1, 4: 0}          # square TxSize by side
 LUMA_SIZES = (64, 32, 16, 8, 4)
 
@@ -91,7 +93,7 @@ class FramePass:
             d[1] += (g["eob"].to(t.int64) & 0xffff).sum()
             q = g["qcoeff"].to(t.int64)
             w = (t.arange(q.shape[1], device=q.device, dtype=t.int64) % 8191) + 1
-            d[2] += (q * w).sum() % ((1 << 61) - 1)
+            d[2] += (q * w).sum() % DIGEST_MOD           # exact int64 sum (< 2^58), then the small residue
             d[3] += (g["recon"].to(t.int64) & 0xffff).sum()
-        d[2] %= (1 << 61) - 1
+        d[2] %= DIGEST_MOD
         return d

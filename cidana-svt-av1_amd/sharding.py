@@ -24,6 +24,11 @@ def gops_of_rank(n_gops: int, rank: int, world: int):
     return [g for g in range(n_gops) if gop_owner(g, world) == rank]
 
 
+# Checksum lanes are residues modulo a prime SMALL enough that thousands of them add up without leaving int64 (with 2^61 - 1,
+# which round 1 used, four residues already overflow: the sum then depended on how the work was grouped into calls).
+DIGEST_MOD = (1 << 31) - 1
+
+
 def digest(eob: np.ndarray, sad: np.ndarray, qcoeff_checksum: int) -> np.ndarray:
     """Fixed-size int64 digest of a shard's outputs: [blocks, sum eob, sum sad, checksum]."""
     return np.array([int(eob.size), int(eob.astype(np.int64).sum()), int(sad.astype(np.int64).sum()),
@@ -32,14 +37,14 @@ def digest(eob: np.ndarray, sad: np.ndarray, qcoeff_checksum: int) -> np.ndarray
 
 def checksum_i32(a: np.ndarray) -> int:
     """Order-independent-by-block, position-sensitive-within-block checksum: sum over
-    elements of value * (1 + index mod 8191), mod 2^61 - 1.  Shards add."""
+    elements of value * (1 + index mod 8191), mod 2^31 - 1.  Shards add."""
     a = np.ascontiguousarray(a).reshape(-1).astype(np.int64)
     w = (np.arange(a.size, dtype=np.int64) % 8191) + 1
-    return int((a * w % ((1 << 61) - 1)).sum() % ((1 << 61) - 1))
+    return int((a * w % DIGEST_MOD).sum() % DIGEST_MOD)
 
 
 def allreduce_digest(d: np.ndarray, device=None) -> np.ndarray:
-    """Sum digests over ranks (checksum lane modulo 2^61-1)."""
+    """Sum digests over ranks (checksum lane modulo 2^31 - 1)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -49,5 +54,5 @@ def allreduce_digest(d: np.ndarray, device=None) -> np.ndarray:
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     out = t.cpu().numpy()
-    out[3] %= (1 << 61) - 1
+    out[3] %= DIGEST_MOD
     return out

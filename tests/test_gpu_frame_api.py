@@ -126,7 +126,7 @@ def test_config5_one_full_4k_10bit_frame_and_gop_digest(dsp, pkg):
                 assert int((g["recon"].to(torch.int32) & 0xffff).max()) <= 1023
         digs.append(fp.digest().cpu().numpy())
         del fp
-    total = digs[0] + digs[1]; total[2] %= (1 << 61) - 1
+    total = digs[0] + digs[1]; total[2] %= sharding.DIGEST_MOD
     assert total[0] == 2 * digs[0][0] and (digs[0] != digs[1]).any()
     # GOP -> rank map of the 240-frame run: 8 GOPs of 30 frames, one per GPU on an 8-GPU node
     assert [sharding.gop_owner(g, 8) for g in range(8)] == list(range(8))
@@ -143,3 +143,35 @@ def test_frame_call_rejects_bad_groups_before_enqueuing(dsp, pkg):
     with pytest.raises(pkg.SvtHipError):
         fp.run(qrow)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_stacked_gop_call_equals_per_picture_calls(dsp, pkg, bd):
+    """frames.FramePass on a stack of pictures [F, H, W] (one call for a GOP) against one FramePass per picture: every group's
+    qcoeff / eob / recon, and the digest, which must not depend on how pictures are grouped into calls"""
+    from cidana_svt_av1_amd import frames, sharding
+    dev_ = torch.device("cuda:0")
+    W, H, F = 320, 192, 5
+    qrow = {k: v[120].copy() for k, v in pkg.tables.quant_tables(bd).items()}
+    g = torch.Generator(device=dev_); g.manual_seed(50 + bd)
+    shapes = {"Y": (H, W), "U": (H // 2, W // 2), "V": (H // 2, W // 2)}
+    hi = 1 << bd
+    dt = torch.uint8 if bd == 8 else torch.int16
+    src = {k: torch.randint(0, hi, (F,) + s, dtype=torch.int32, device=dev_, generator=g).to(dt) for k, s in shapes.items()}
+    pred = {k: (src[k].to(torch.int32) + torch.randint(-40, 41, src[k].shape, dtype=torch.int32, device=dev_, generator=g)).clamp_(0, hi - 1).to(dt) for k in shapes}
+    st = frames.FramePass(dsp, pkg, src, pred, is_16bit=bd > 8)
+    st.run(qrow)
+    torch.cuda.synchronize()
+    total = torch.zeros(4, dtype=torch.int64, device=dev_)
+    for f in range(F):
+        one = frames.FramePass(dsp, pkg, {k: src[k][f] for k in shapes}, {k: pred[k][f] for k in shapes}, is_16bit=bd > 8)
+        one.run(qrow)
+        torch.cuda.synchronize()
+        for gs, go in zip(st.groups, one.groups):
+            n1 = go["xy"].numel()
+            assert torch.equal(gs["qcoeff"][f * n1:(f + 1) * n1], go["qcoeff"]), (f, gs["name"], gs["luma_size"])
+            assert torch.equal(gs["eob"][f * n1:(f + 1) * n1], go["eob"])
+            assert torch.equal(gs["recon"][f], go["recon"])
+        total += one.digest()
+    total[2] %= sharding.DIGEST_MOD
+    assert torch.equal(total, st.digest())
