@@ -43,8 +43,8 @@ def checksum_i32(a: np.ndarray) -> int:
     return int((a * w % DIGEST_MOD).sum() % DIGEST_MOD)
 
 
-def allreduce_digest(d: np.ndarray, device=None) -> np.ndarray:
-    """Sum digests over ranks (checksum lane modulo 2^31 - 1)."""
+def allreduce_digest(d: np.ndarray, device=None, checksum_lanes=(3,)) -> np.ndarray:
+    """Sum digests over ranks; the checksum lane(s) modulo 2^31 - 1 (lane 3 of `digest`, lane 2 of frames.FramePass.digest)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -54,5 +54,6 @@ def allreduce_digest(d: np.ndarray, device=None) -> np.ndarray:
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     out = t.cpu().numpy()
-    out[3] %= DIGEST_MOD
+    for k in checksum_lanes:
+        out[k] %= DIGEST_MOD
     return out
