@@ -20,6 +20,11 @@ struct QParams {
     // formula collapses to  aq = (t1 * quant_m) >> fast_sh  with fast_sh = 32 - log_scale - k
     int32_t fast_sh[2];
     int32_t fast_ok;
+    // the same collapse as ONE multiply: with quant_hi = quant_m << (31 - fast_sh) (fits 32 bits: quant_m < 2^17, fast_sh >= 16),
+    // aq = mulhi_u32(2 * t1, quant_hi) = floor(t1 * quant_m / 2^fast_sh) exactly; zbin2 / round2 are the doubled thresholds
+    uint32_t quant_hi[2];
+    int32_t zbin2[2];
+    int32_t round2[2];
 };
 
 // Orders this wave's LDS traffic: LDS instructions of one wave execute in
@@ -53,10 +58,10 @@ __device__ __forceinline__ void quant_one(int c, int ac, const QParams& qp, int&
     const int a = (c ^ s) - s;
     int aq, adq;
     if (MODE == 2) {
-        const uint32_t t1 = (uint32_t)(a + qp.round[ac]);
-        const uint64_t p = (uint64_t)(t1 & 0xffffffu) * (uint64_t)(qp.quant_m[ac] & 0xffffffu);
-        aq = (int)__builtin_amdgcn_alignbit((uint32_t)(p >> 32), (uint32_t)p, (uint32_t)qp.fast_sh[ac]);
-        aq = a >= qp.zbin[ac] ? aq : 0;
+        // (v_mul_u32_u24 + v_mul_hi_u32_u24 + v_alignbit before: three slow-rate instructions; now one add and one v_mul_hi_u32)
+        const int a2 = a + a;
+        aq = (int)__umulhi((uint32_t)(a2 + qp.round2[ac]), qp.quant_hi[ac]);
+        aq = a2 >= qp.zbin2[ac] ? aq : 0;
         adq = (int)(((uint32_t)aq & 0xffffffu) * ((uint32_t)qp.dequant[ac] & 0xffffffu)) >> qp.log_scale;
         q = (aq ^ s) - s;
         dq = (adq ^ s) - s;

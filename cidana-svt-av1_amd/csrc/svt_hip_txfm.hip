@@ -32,7 +32,10 @@ QParams make_qparams(const int16_t* zbin, const int16_t* round, const int16_t* q
         if (qs > 0 && (qs & (qs - 1)) == 0) { k = 0; while ((1 << k) != qs) k++; }
         const int sh = 32 - log_scale - k;
         qp.fast_sh[i] = sh;
-        if (k < 0 || sh < 1 || sh > 31 || dequant[i] < 0 || qp.round[i] < 0) qp.fast_ok = 0;
+        if (k < 0 || sh < 16 || sh > 31 || dequant[i] < 0 || qp.round[i] < 0 || qp.quant_m[i] >= (1u << 17)) qp.fast_ok = 0;
+        qp.quant_hi[i] = (sh >= 16 && sh <= 31) ? qp.quant_m[i] << (31 - sh) : 0u;
+        qp.zbin2[i] = 2 * qp.zbin[i];
+        qp.round2[i] = 2 * qp.round[i];
     }
     return qp;
 }
