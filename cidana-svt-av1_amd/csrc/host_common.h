@@ -41,6 +41,7 @@ extern int g_tune_no_f32p;
 extern int g_tune_no_inv_planes;
 extern int g_tune_no_enc_staged;
 extern int g_tune_no_enc64;
+extern int g_tune_frame_single_launch;
 extern int g_tune_inv32_waves;
 extern int g_tune_inv32_var;
 

@@ -43,12 +43,12 @@ __device__ __forceinline__ void idct64_pass(int (&x)[64]) {
 }
 
 template <typename PixT, int BD, bool KEEP>
-__global__ __launch_bounds__(E64_WAVES * 64) void enc64_kernel(
+__device__ __forceinline__ void enc64_body(
     const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
     int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
-    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
-    uint32_t nblocks, const uint32_t* __restrict__ xy, uint32_t src_stride, uint32_t pred_stride, uint32_t recon_stride) {
-    __shared__ __attribute__((aligned(16))) char lds[E64_WAVES * E64_WAVE_LDS];
+    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, const QParams& qp,
+    uint32_t nblocks, const uint32_t* __restrict__ xy, uint32_t src_stride, uint32_t pred_stride, uint32_t recon_stride,
+    uint32_t bid, char* lds) {
     constexpr int ES = (int)sizeof(PixT), PPC = 16 / ES, CPR = 64 / PPC, CPB = 64 * CPR, NIT = 2 * CPB / 64;
     constexpr int in_bits = BD + 8, row_bits = BD == 8 ? 16 : (BD == 10 ? 18 : 20);      // av1_gen_inv_stage_range (:5404-5456)
     constexpr int cin_bits = BD + 6 > 16 ? BD + 6 : 16, col_bits = BD == 12 ? 18 : 16, maxpix = (1 << BD) - 1;
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(E64_WAVES * 64) void enc64_kernel(
     static_assert(fwd_shift(64, 64, 0) == 0 && fwd_shift(64, 64, 1) == -2 && fwd_shift(64, 64, 2) == -2 && inv_shift0(64, 64) == -2, "64x64 shifts");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     char* wl = lds + wave * E64_WAVE_LDS;
-    const uint32_t first = (blockIdx.x * E64_WAVES + wave) * 2;
+    if (wave >= E64_WAVES) return;                         // (run inside a larger workgroup: the spare waves have nothing to do)
+    const uint32_t first = (bid * E64_WAVES + wave) * 2;
     if (first >= nblocks) return;                          // wave-uniform
     const bool two = first + 1 < nblocks;                  // the last wave of an odd batch: its second block repeats the first, unstored
     size_t sb[2], pb[2], rb[2];
@@ -258,6 +259,17 @@ __global__ __launch_bounds__(E64_WAVES * 64) void enc64_kernel(
             if (b == 0 || two) __builtin_memcpy(recon + rb[b] + (size_t)row * rs + col, ow, 16);
         }
     }
+}
+
+template <typename PixT, int BD, bool KEEP>
+__global__ __launch_bounds__(E64_WAVES * 64) void enc64_kernel(
+    const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
+    int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
+    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
+    uint32_t nblocks, const uint32_t* __restrict__ xy, uint32_t src_stride, uint32_t pred_stride, uint32_t recon_stride) {
+    __shared__ __attribute__((aligned(16))) char lds[E64_WAVES * E64_WAVE_LDS];
+    enc64_body<PixT, BD, KEEP>(src, pred, recon, coeff, qcoeff, dqcoeff, eob, sad, iscan, qp, nblocks, xy, src_stride, pred_stride, recon_stride,
+                               blockIdx.x, lds);
 }
 
 }  // namespace svtdev

@@ -452,20 +452,22 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((VAR
 // ---------------------------------------------------------------------------
 // PixT / BD: uint8_t / 8 or uint16_t / 10 (BASELINE configs[4]); the 16-bit variant differs only in how the
 // residual is formed (v_pk_sub_i16 on the loaded words), in the inverse's clamp ranges and in the final clip.
+// (body / kernel split: the body takes its workgroup index and LDS from the caller, so that enc_frame_kernel - one launch for
+// every group of a picture, kernel_frame.h - can run it for the workgroups of a 32x32 group)
+constexpr int ENC32_LDS_BYTES = F32_WAVES * 2 * F32_TILE_WORDS * 4;
 template <typename PixT, int BD, bool KEEP, bool WITH_SAD>
-__global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3))) void enc32_kernel(
+__device__ __forceinline__ void enc32_body(
     const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
     int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
-    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
-    int is_idtx, uint32_t nblocks, const uint32_t* __restrict__ xy = nullptr, uint32_t src_stride = 32,
-    uint32_t pred_stride = 32, uint32_t recon_stride = 32) {
+    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, const QParams& qp,
+    int is_idtx, uint32_t nblocks, const uint32_t* __restrict__ xy, uint32_t src_stride,
+    uint32_t pred_stride, uint32_t recon_stride, uint32_t bid, int32_t* lds) {
     // xy != NULL: blocks addressed on picture planes (origin (x, y) = (xy[b] & 0xffff, xy[b] >> 16), row strides
     // in samples; recon may be the prediction plane itself); NULL: dense 32x32 blocks.
-    __shared__ __attribute__((aligned(16))) int32_t lds[F32_WAVES * 2 * F32_TILE_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, li = lane & 31;
     char* tile = reinterpret_cast<char*>(lds + (wave * 2 + half) * F32_TILE_WORDS);
-    const uint32_t blk = (blockIdx.x * F32_WAVES + wave) * 2 + half;
+    const uint32_t blk = (bid * F32_WAVES + wave) * 2 + half;
     const bool valid = blk < nblocks;
     const size_t pix_off = (size_t)blk * 1024;
 
@@ -680,6 +682,18 @@ __global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
             else reinterpret_cast<uint4*>(recon + pix_off)[L] = ov;
         }
     }
+}
+
+template <typename PixT, int BD, bool KEEP, bool WITH_SAD>
+__global__ __launch_bounds__(F32_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3))) void enc32_kernel(
+    const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
+    int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
+    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
+    int is_idtx, uint32_t nblocks, const uint32_t* __restrict__ xy = nullptr, uint32_t src_stride = 32,
+    uint32_t pred_stride = 32, uint32_t recon_stride = 32) {
+    __shared__ __attribute__((aligned(16))) int32_t lds[F32_WAVES * 2 * F32_TILE_WORDS];
+    enc32_body<PixT, BD, KEEP, WITH_SAD>(src, pred, recon, coeff, qcoeff, dqcoeff, eob, sad, iscan, qp, is_idtx, nblocks, xy, src_stride,
+                                         pred_stride, recon_stride, blockIdx.x, lds);
 }
 
 }  // namespace svtdev

@@ -433,13 +433,22 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
 // chunks loaded for the residual stay in registers and are the destination of the reconstruction.
 // HBM traffic: 2*W*H in + 4*KW*KH (qcoeff) + W*H (recon) + 6 B out (+ coeff, dqcoeff when KEEP).
 // ---------------------------------------------------------------------------
-template <int W, int H, bool KEEP, typename PixT = uint8_t, int BD = 8>
-__global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
+template <int W, int H, typename PixT>
+struct EncStagedLds {                                    // LDS bytes per wave / per workgroup of enc_staged_body<W, H, ., PixT>
+    using S = StagedGeom<W, H>;
+    using G = TxGeom<W, H>;
+    static constexpr int ES = (int)sizeof(PixT), BB = W * H * ES, PADI = (W * ES >= 32) ? 32 : 16, IN_ONE = G::BPW * (BB + PADI);
+    static constexpr int PQ = (S::KW == 4) ? 3 : S::KW / 4 + 1;
+    static constexpr int WAVE = (cmax(cmax(cmax(IN_ONE * 2, G::BPW * G::TILE * 4), G::BPW * W * H * 4), G::BPW * S::KH * PQ * 16) + 15) & ~15;
+    static constexpr int BYTES = S::WAVES * WAVE;
+};
+template <int W, int H, bool KEEP, typename PixT, int BD>
+__device__ __forceinline__ void enc_staged_body(
     const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
     int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
-    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
-    int tx_type, uint32_t nblocks, const uint32_t* __restrict__ xy = nullptr, uint32_t src_stride = 0,
-    uint32_t pred_stride = 0, uint32_t recon_stride = 0) {
+    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, const QParams& qp,
+    int tx_type, uint32_t nblocks, const uint32_t* __restrict__ xy, uint32_t src_stride,
+    uint32_t pred_stride, uint32_t recon_stride, uint32_t bid, char* lds) {
     // xy != NULL: blocks addressed on picture planes (origin (x, y) = (xy[b] & 0xffff, xy[b] >> 16), row strides
     // in samples; recon may be the prediction plane itself); NULL: dense batches.
     using S = StagedGeom<W, H>;
@@ -451,14 +460,15 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
     constexpr int IN_ONE = G::BPW * (BB + PADI);
     constexpr int PQ = (KW == 4) ? 3 : KW / 4 + 1;
     constexpr int WAVE_LDS = (cmax(cmax(cmax(IN_ONE * 2, G::BPW * G::TILE * 4), G::BPW * W * H * 4), G::BPW * KH * PQ * 16) + 15) & ~15;
-    __shared__ __attribute__((aligned(16))) char lds[S::WAVES * WAVE_LDS];
+    static_assert(WAVE_LDS == EncStagedLds<W, H, PixT>::WAVE, "EncStagedLds out of step");
     static_assert(W * H % 16 == 0, "block must be a whole number of 16-B chunks");
     constexpr int in_bits = BD + 8, row_bits = BD == 8 ? 16 : (BD == 10 ? 18 : 20);      // av1_gen_inv_stage_range (:5404-5456)
     constexpr int cin_bits = BD + 6 > 16 ? BD + 6 : 16, col_bits = BD == 12 ? 18 : 16, maxpix = (1 << BD) - 1;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     char* wl = lds + wave * WAVE_LDS;
-    const uint32_t first = (blockIdx.x * S::WAVES + wave) * G::BPW;
+    if (wave >= S::WAVES) return;                           // (run inside a larger workgroup: the spare waves have nothing to do)
+    const uint32_t first = (bid * S::WAVES + wave) * G::BPW;
     if (first >= nblocks) return;                         // wave-uniform
     const int sub = lane / G::LPB, l = lane % G::LPB;
     const uint32_t blk = first + sub;
@@ -719,6 +729,18 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
     }
 }
 
+template <int W, int H, bool KEEP, typename PixT = uint8_t, int BD = 8>
+__global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
+    const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
+    int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
+    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
+    int tx_type, uint32_t nblocks, const uint32_t* __restrict__ xy = nullptr, uint32_t src_stride = 0,
+    uint32_t pred_stride = 0, uint32_t recon_stride = 0) {
+    __shared__ __attribute__((aligned(16))) char lds[EncStagedLds<W, H, PixT>::BYTES];
+    enc_staged_body<W, H, KEEP, PixT, BD>(src, pred, recon, coeff, qcoeff, dqcoeff, eob, sad, iscan, qp, tx_type, nblocks, xy, src_stride,
+                                          pred_stride, recon_stride, blockIdx.x, lds);
+}
+
 // ---------------------------------------------------------------------------
 // enc4_kernel<PixT, BD, KEEP> — the encode-pass chain for TX_4X4, all 16 transform types: ONE LANE PER BLOCK, the whole
 // block in registers (16 residuals, two passes of four 4-point transforms each way), no LDS.  Adjacent lanes take adjacent
@@ -730,13 +752,13 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void enc_staged_kernel(
 // qfast: the quantiser table has power-of-two quant_shift (host-checked): one-product form; else the exact 64-bit form.
 // ---------------------------------------------------------------------------
 template <typename PixT, int BD, bool KEEP>
-__global__ __launch_bounds__(256) void enc4_kernel(
+__device__ __forceinline__ void enc4_body(
     const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
     int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
-    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp, int qfast,
+    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, const QParams& qp, int qfast,
     int tx_type, uint32_t nblocks, const uint32_t* __restrict__ xy, uint32_t src_stride, uint32_t pred_stride,
-    uint32_t recon_stride) {
-    const uint32_t blk = blockIdx.x * 256u + threadIdx.x;
+    uint32_t recon_stride, uint32_t bid) {
+    const uint32_t blk = bid * 256u + threadIdx.x;
     if (blk >= nblocks) return;
     constexpr int in_bits = BD + 8, row_bits = BD == 8 ? 16 : (BD == 10 ? 18 : 20);      // av1_gen_inv_stage_range (:5404-5456)
     constexpr int cin_bits = BD + 6 > 16 ? BD + 6 : 16, col_bits = BD == 12 ? 18 : 16, maxpix = (1 << BD) - 1;
@@ -835,6 +857,17 @@ __global__ __launch_bounds__(256) void enc4_kernel(
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) __builtin_memcpy(recon + ro + (size_t)r * rs, ov[r], 4 * sizeof(PixT));
+}
+
+template <typename PixT, int BD, bool KEEP>
+__global__ __launch_bounds__(256) void enc4_kernel(
+    const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
+    int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
+    uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp, int qfast,
+    int tx_type, uint32_t nblocks, const uint32_t* __restrict__ xy, uint32_t src_stride, uint32_t pred_stride,
+    uint32_t recon_stride) {
+    enc4_body<PixT, BD, KEEP>(src, pred, recon, coeff, qcoeff, dqcoeff, eob, sad, iscan, qp, qfast, tx_type, nblocks, xy, src_stride, pred_stride,
+                              recon_stride, blockIdx.x);
 }
 
 }  // namespace svtdev

@@ -30,6 +30,7 @@ int g_tune_no_f32p = 0;
 int g_tune_no_inv_planes = 0;
 int g_tune_no_enc_staged = 0;
 int g_tune_no_enc64 = 0;
+int g_tune_frame_single_launch = 0;
 int g_tune_inv32_waves = 4;
 int g_tune_inv32_var = 0;
 
@@ -135,6 +136,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "no_inv_planes")) { g_tune_no_inv_planes = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_enc_staged")) { g_tune_no_enc_staged = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_enc64")) { g_tune_no_enc64 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "frame_single_launch")) { g_tune_frame_single_launch = value; return SVT_HIP_OK; }
     if (!strcmp(key, "inv32_waves")) { g_tune_inv32_waves = value; return SVT_HIP_OK; }
     if (!strcmp(key, "inv32_var")) { g_tune_inv32_var = value; return SVT_HIP_OK; }
     return set_err(SVT_HIP_ERR_INVALID, "unknown tuning key %s", key);

@@ -6,6 +6,7 @@
 #include "kernel_txfm.h"
 #include "kernel_txfm_staged.h"
 #include "kernel_enc64.h"
+#include "kernel_frame.h"
 
 using namespace svtdev;
 using namespace svthost;
@@ -534,6 +535,53 @@ extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int
         if ((G.d_coeff != nullptr) != (G.d_dqcoeff != nullptr)) return set_err(SVT_HIP_ERR_INVALID, "group %d: d_coeff and d_dqcoeff go together", g);
         if (G.tx_size == SVT_TX_4X4 && g_tune_no_enc_staged && (!G.d_coeff || !G.d_offsets || G.d_recon != G.d_pred || G.recon_stride != G.pred_stride))
             return set_err(SVT_HIP_ERR_INVALID, "group %d: with no_enc_staged set, 4x4 groups take the two-stage path and need d_coeff, d_dqcoeff, d_offsets and in-place reconstruction", g);
+    }
+    // ---- ONE launch for the whole call (enc_frame_kernel) when every group is one it covers: square DCT_DCT sizes 4 .. 64,
+    // qcoeff + recon outputs, power-of-two quant_shift tables.  Chosen by svt_hip_tune("frame_single_launch", 1): it is the
+    // faster form for ONE picture (one dispatch instead of 13), the per-size launches below are faster for stacked GOPs.
+    if (g_tune_frame_single_launch && ngroups <= FRAME_MAX_GROUPS) {
+        bool ok = true;
+        for (int g = 0; g < ngroups && ok; g++) {
+            const svt_hip_frame_group& G = groups[g];
+            ok = G.tx_size >= SVT_TX_4X4 && G.tx_size <= SVT_TX_64X64 && G.tx_type == SVT_DCT_DCT && !G.d_coeff && G.d_recon != G.d_src &&
+                 (((uintptr_t)G.d_qcoeff) & 15) == 0;
+        }
+        if ((is_16bit && bd != 10) || (!is_16bit && bd != 8)) ok = false;
+        FrameDesc fd;
+        memset(&fd, 0, sizeof(fd));
+        uint32_t total = 0;
+        if (ok) {
+            int order[FRAME_MAX_GROUPS];
+            for (int i = 0; i < ngroups; i++) order[i] = i;
+            for (int i = 1; i < ngroups; i++) {          // largest blocks first: the long workgroups start early
+                const int v = order[i];
+                int j = i - 1;
+                while (j >= 0 && groups[order[j]].tx_size < groups[v].tx_size) { order[j + 1] = order[j]; j--; }
+                order[j + 1] = v;
+            }
+            for (int k = 0; k < ngroups && ok; k++) {
+                const svt_hip_frame_group& G = groups[order[k]];
+                if (G.nblocks == 0) continue;
+                const int pels = kTxW[G.tx_size] * kTxH[G.tx_size];
+                FrameGroupDev& D = fd.g[fd.ngroups];
+                D.qp = make_qparams(zbin, round, quant, quant_shift, dequant, pels > 1024 ? 2 : (pels > 256 ? 1 : 0));
+                for (int i = 0; i < 2; i++) ok = ok && D.qp.quant_shift[i] >= 0 && D.qp.dequant[i] >= 0 && D.qp.round[i] >= 0;
+                ok = ok && D.qp.fast_ok;
+                D.src = G.d_src; D.pred = G.d_pred; D.recon = G.d_recon; D.qcoeff = G.d_qcoeff; D.eob = G.d_eob; D.xy = G.d_xy; D.iscan = G.d_iscan;
+                D.src_stride = G.src_stride; D.pred_stride = G.pred_stride; D.recon_stride = G.recon_stride; D.nblocks = G.nblocks; D.tx_size = G.tx_size;
+                // blocks per 256-thread workgroup of each body: 256 (4x4), 32 (8x8: 4 waves x 8), 16 (16x16: 4 x 4), 8 (32x32: 4 x 2), 4 (64x64: 2 x 2)
+                static const uint32_t per_wg[5] = {256, 32, 16, 8, 4};
+                total += (G.nblocks + per_wg[G.tx_size] - 1) / per_wg[G.tx_size];
+                D.wg_end = total;
+                fd.ngroups++;
+            }
+        }
+        if (ok) {
+            if (fd.ngroups == 0) return SVT_HIP_OK;
+            if (is_16bit) hipLaunchKernelGGL((enc_frame_kernel<uint16_t, 10>), dim3(total), dim3(256), 0, (hipStream_t)stream, fd);
+            else hipLaunchKernelGGL((enc_frame_kernel<uint8_t, 8>), dim3(total), dim3(256), 0, (hipStream_t)stream, fd);
+            return launch_status("enc_frame");
+        }
     }
     if (int rc = t_fan.ensure()) return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -175,3 +175,35 @@ def test_stacked_gop_call_equals_per_picture_calls(dsp, pkg, bd):
         total += one.digest()
     total[2] %= sharding.DIGEST_MOD
     assert torch.equal(total, st.digest())
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_frame_single_launch_equals_per_size_launches(dsp, pkg, bd):
+    """svt_hip_tune("frame_single_launch", 1): enc_frame_kernel runs the same bodies as the per-size kernels for every group of the
+    call in ONE launch - qcoeff / eob / recon of every group must be identical; odd plane sizes so that the last workgroups of the
+    groups are partly empty; also a call with a group the single launch does not cover (falls back, still correct)"""
+    from cidana_svt_av1_amd import frames
+    dev_ = torch.device("cuda:0")
+    W, H = 448 + 8, 320 + 12
+    qrow = {k: v[90].copy() for k, v in pkg.tables.quant_tables(bd).items()}
+    g = torch.Generator(device=dev_); g.manual_seed(70 + bd)
+    shapes = {"Y": (H, W), "U": (H // 2, W // 2), "V": (H // 2, W // 2)}
+    hi = 1 << bd
+    dt = torch.uint8 if bd == 8 else torch.int16
+    src = {k: torch.randint(0, hi, s, dtype=torch.int32, device=dev_, generator=g).to(dt) for k, s in shapes.items()}
+    pred = {k: (src[k].to(torch.int32) + torch.randint(-40, 41, src[k].shape, dtype=torch.int32, device=dev_, generator=g)).clamp_(0, hi - 1).to(dt) for k in shapes}
+    outs = []
+    try:
+        for knob in (0, 1):
+            assert dsp.lib.svt_hip_tune(b"frame_single_launch", knob) == 0
+            fp = frames.FramePass(dsp, pkg, src, pred, is_16bit=bd > 8)
+            fp.run(qrow)
+            torch.cuda.synchronize()
+            outs.append(fp)
+    finally:
+        dsp.lib.svt_hip_tune(b"frame_single_launch", 0)
+    assert len(outs[0].groups) == 13
+    for ga, gb in zip(outs[0].groups, outs[1].groups):
+        assert torch.equal(ga["qcoeff"], gb["qcoeff"]), (ga["name"], ga["luma_size"])
+        assert torch.equal(ga["eob"], gb["eob"]) and torch.equal(ga["recon"], gb["recon"])
+        assert not torch.equal(gb["recon"], pred[gb["name"]])

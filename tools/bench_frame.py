@@ -4,6 +4,7 @@ residual -> FwdTxfm2d -> quantise / dequantise -> InvTxfm2d + add on planes.  Th
   sequential   one entry-point call per (plane, size) group on one stream (round 1's figure)
   frame        ONE svt_hip_encode_recon_frame call: the groups run concurrently on the library's internal streams
   frame_graph  that call captured once into a HIP graph and replayed
+  frame_one_launch / _graph  svt_hip_tune("frame_single_launch", 1): every group in ONE kernel launch (enc_frame_kernel)
   frame_gop16_per_frame  16 independent frames stacked into one call (13 launches for the GOP), time per frame
 Bytes: 7 B/px kept outputs (src, pred u8 in; qcoeff i32 + recon u8 out) - SURVEY 8(d)'s fused figure; the 4x4 groups also
 write coeff / dqcoeff.  One JSON line per mode + a summary; also written to gpurun_out/frame_c4.json."""
@@ -58,6 +59,19 @@ with torch.cuda.stream(st):
         fp.run(qrow)
 torch.cuda.synchronize()
 rows["frame_graph"] = timeit(gr.replay)
+# ONE launch for the whole frame (enc_frame_kernel), plain and captured
+assert dsp.lib.svt_hip_tune(b"frame_single_launch", 1) == 0
+rows["frame_one_launch"] = timeit(lambda: fp.run(qrow))
+st2 = torch.cuda.Stream()
+with torch.cuda.stream(st2):
+    fp.run(qrow)
+    torch.cuda.synchronize()
+    gr2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr2, stream=st2):
+        fp.run(qrow)
+torch.cuda.synchronize()
+rows["frame_one_launch_graph"] = timeit(gr2.replay)
+assert dsp.lib.svt_hip_tune(b"frame_single_launch", 0) == 0
 # per luma size, frame call only (what each size costs when it has the GPU to itself)
 per_size = {}
 for S in frames.LUMA_SIZES:
@@ -70,6 +84,9 @@ predg = {k: torch.randint(0, 256, (NF,) + s, dtype=torch.uint8, device=dev, gene
 fpg = frames.FramePass(dsp, pkg, srcg, predg)
 assert fpg.pixels == NF * fp.pixels
 rows["frame_gop16_per_frame"] = timeit(lambda: fpg.run(qrow), iters=10) / NF
+assert dsp.lib.svt_hip_tune(b"frame_single_launch", 1) == 0
+rows["frame_gop16_one_launch_per_frame"] = timeit(lambda: fpg.run(qrow), iters=10) / NF
+assert dsp.lib.svt_hip_tune(b"frame_single_launch", 0) == 0
 if os.environ.get("FRAME_ONLY_GOP"):          # for rocprofv3: only the GOP call's kernels in the trace
     sys.exit(0)
 out = {"config": "configs[3]: one 1920x1080 yuv420p frame, luma sizes 64/32/16/8/4 + chroma at half the side, 8-bit, qindex 100",
