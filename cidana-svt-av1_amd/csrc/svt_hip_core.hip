@@ -30,7 +30,7 @@ int g_tune_no_f32p = 0;
 int g_tune_no_inv_planes = 0;
 int g_tune_no_enc_staged = 0;
 int g_tune_no_enc64 = 0;
-int g_tune_frame_single_launch = 0;
+int g_tune_frame_single_launch = -1;      // -1: by call size (svt_hip_encode_recon_frame), 0 never, 1 always
 int g_tune_inv32_waves = 4;
 int g_tune_inv32_var = 0;
 

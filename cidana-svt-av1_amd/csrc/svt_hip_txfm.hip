@@ -537,12 +537,20 @@ extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int
             return set_err(SVT_HIP_ERR_INVALID, "group %d: with no_enc_staged set, 4x4 groups take the two-stage path and need d_coeff, d_dqcoeff, d_offsets and in-place reconstruction", g);
     }
     // ---- ONE launch for the whole call (enc_frame_kernel) when every group is one it covers: square DCT_DCT sizes 4 .. 64,
-    // qcoeff + recon outputs, power-of-two quant_shift tables.  Chosen by svt_hip_tune("frame_single_launch", 1): it is the
-    // faster form for ONE picture (one dispatch instead of 13), the per-size launches below are faster for stacked GOPs.
-    if (g_tune_frame_single_launch && ngroups <= FRAME_MAX_GROUPS) {
+    // qcoeff + recon outputs, power-of-two quant_shift tables.  Measured (tools/bench_frame.py, tools/bench_c5.py): one 1080p
+    // picture 0.044 ms against 0.160 (13 launches on 8 streams) / 0.101 (those captured into a graph); one 4K 10-bit picture
+    // 5 390 against 3 990 pictures/s; a stack of 16 1080p pictures the same either way; a stack of 30 4K 10-bit pictures 5 270
+    // against 6 100 (the launch runs every size at the 64x64 body's register budget).  So: one launch up to 2^27 pixel passes
+    // per call, per-size launches above.  svt_hip_tune("frame_single_launch", 0 / 1) forces either; -1 (default) is this rule.
+    size_t call_pixels = 0;
+    for (int g = 0; g < ngroups; g++)
+        if (groups[g].nblocks) call_pixels += (size_t)groups[g].nblocks * kTxW[groups[g].tx_size] * kTxH[groups[g].tx_size];      // (validated above)
+    const bool want_single = g_tune_frame_single_launch > 0 || (g_tune_frame_single_launch < 0 && call_pixels <= ((size_t)1 << 27));
+    if (want_single && ngroups <= FRAME_MAX_GROUPS) {
         bool ok = true;
         for (int g = 0; g < ngroups && ok; g++) {
             const svt_hip_frame_group& G = groups[g];
+            if (G.nblocks == 0) continue;
             ok = G.tx_size >= SVT_TX_4X4 && G.tx_size <= SVT_TX_64X64 && G.tx_type == SVT_DCT_DCT && !G.d_coeff && G.d_recon != G.d_src &&
                  (((uintptr_t)G.d_qcoeff) & 15) == 0;
         }

@@ -201,7 +201,7 @@ def test_frame_single_launch_equals_per_size_launches(dsp, pkg, bd):
             torch.cuda.synchronize()
             outs.append(fp)
     finally:
-        dsp.lib.svt_hip_tune(b"frame_single_launch", 0)
+        dsp.lib.svt_hip_tune(b"frame_single_launch", -1)
     assert len(outs[0].groups) == 13
     for ga, gb in zip(outs[0].groups, outs[1].groups):
         assert torch.equal(ga["qcoeff"], gb["qcoeff"]), (ga["name"], ga["luma_size"])

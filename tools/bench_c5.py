@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--sizes", default="64,32,16,8,4")
     ap.add_argument("--qindex", type=int, default=120)
     ap.add_argument("--stack", type=int, default=1, help="pictures of a GOP handed to the device in ONE call (<= 65535 / height)")
+    ap.add_argument("--single-launch", type=int, default=-1, help="1 / 0: force svt_hip_tune(frame_single_launch); -1: library default")
     ap.add_argument("--rehearse", action="store_true")
     ap.add_argument("--json-out", default=None)
     args = ap.parse_args()
@@ -58,6 +59,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dsp = pkg.SvtHipDsp(local_rank)
+    if args.single_launch >= 0:
+        assert dsp.lib.svt_hip_tune(b"frame_single_launch", args.single_launch) == 0
     qt = pkg.tables.quant_tables(10)
     qrow = {k: v[args.qindex].copy() for k, v in qt.items()}
     sizes = tuple(int(s) for s in args.sizes.split(","))
