@@ -9,7 +9,8 @@
 //
 // What one launch costs: the register file and LDS of the launch are the maximum over the bodies (the 64x64 body), so the
 // small sizes run at its occupancy instead of their own.  For ONE picture that is cheaper than 13 dispatches; for a GOP the
-// per-size launches win.  Covered: square sizes 4 .. 64, DCT_DCT, qcoeff + eob + recon outputs, 8 / 10 bit,
+// per-size launches win.  3 waves / SIMD: at that budget (168 VGPRs) the 64x64 body spills 12 B (8-bit) / 36 B
+// (10-bit) to scratch; measured against 2 waves / SIMD without scratch (192 VGPRs): 5 350 against 4 560 4K 10-bit pictures/s.  Covered: square sizes 4 .. 64, DCT_DCT, qcoeff + eob + recon outputs, 8 / 10 bit,
 // power-of-two quant_shift tables.
 #pragma once
 #include "kernel_enc64.h"
