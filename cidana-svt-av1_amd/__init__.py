@@ -122,6 +122,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
                                                   c_size_t, c_void_p]
     L.svt_hip_build_intra_predictors_batch.argtypes = [c_void_p, c_int32, c_size_t, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int,
                                                        c_int, c_int, c_size_t, c_void_p]
+    L.svt_hip_ois_search_frame.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_int, c_void_p]
     L.svt_hip_intra_neighbor_px.argtypes = [c_void_p, c_void_p]
     L.svt_hip_intra_has_top_right.argtypes = [c_int] * 12
     L.svt_hip_intra_has_bottom_left.argtypes = [c_int] * 12
@@ -413,6 +414,35 @@ class SvtHipDsp:
                                                        self._p(best), self._p(work), wb, n, self._stream()),
                     "svt_hip_ois_search_batch")
         return dist, best
+
+    class OisGroup(ctypes.Structure):
+        """svt_hip_ois_group"""
+        _fields_ = [("d_xy", ctypes.c_void_p), ("bsize", ctypes.c_uint32), ("modes", ctypes.c_void_p), ("angle_deltas", ctypes.c_void_p),
+                    ("ncand", ctypes.c_int32), ("d_distortion", ctypes.c_void_p), ("d_best_index", ctypes.c_void_p), ("d_work", ctypes.c_void_p),
+                    ("work_bytes", ctypes.c_size_t), ("nblocks", ctypes.c_size_t)]
+
+    def ois_search_frame(self, pic, stride, width, height, groups):
+        """The open-loop intra search of a picture, every block size in ONE call (svt_hip_ois_search_frame).  groups: list of
+        (xy int32 [n], bsize, modes, angle_deltas) -> list of (distortion int32 [n, ncand], best_index int8 [n])"""
+        import numpy as np
+        t = self.torch
+        arr = (self.OisGroup * len(groups))()
+        keep, outs = [], []
+        for i, (xy, bsize, modes, deltas) in enumerate(groups):
+            n = xy.shape[0]
+            modes = np.ascontiguousarray(modes, np.uint8); deltas = np.ascontiguousarray(deltas, np.int8)
+            nc = int(modes.shape[0])
+            dist = t.zeros((n, nc), dtype=t.int32, device=xy.device)
+            best = t.zeros(n, dtype=t.int8, device=xy.device)
+            wb = self.lib.svt_hip_ois_work_bytes(bsize, nc, n)
+            work = t.empty(max(wb, 1), dtype=t.uint8, device=xy.device)
+            arr[i] = self.OisGroup(self._p(xy), bsize, modes.ctypes.data, deltas.ctypes.data, nc, self._p(dist), self._p(best), self._p(work), wb, n)
+            keep.append((xy, modes, deltas, work))
+            outs.append((dist, best))
+        self._check(self.lib.svt_hip_ois_search_frame(pic.data_ptr(), stride, width, height, arr, len(groups), self._stream()),
+                    "svt_hip_ois_search_frame")
+        self._ois_keep = keep          # host lists and work buffers outlive the enqueued kernels
+        return outs
 
     # -- K11 chroma from luma + level map ---------------------------------------------------
     CFL_BUF_LINE = 32

@@ -116,4 +116,30 @@ extern thread_local ThreadCtx t_ctx;
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+
+// Internal streams a frame-level call fans its independent groups out to (forked from, and joined back into, the caller's
+// stream: the call stays a pure enqueue and is graph-capturable).  One set per calling thread.
+constexpr int kFanStreams = 8;
+struct FanOut {
+    hipStream_t s[kFanStreams] = {};
+    hipEvent_t fork = nullptr, join[kFanStreams] = {};
+    bool ready = false;
+    int ensure() {
+        if (ready) return SVT_HIP_OK;
+        HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        for (int i = 0; i < kFanStreams; i++) {
+            HIP_TRY(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&join[i], hipEventDisableTiming));
+        }
+        ready = true;
+        return SVT_HIP_OK;
+    }
+    ~FanOut() {
+        if (!ready) return;
+        for (int i = 0; i < kFanStreams; i++) { (void)hipStreamDestroy(s[i]); (void)hipEventDestroy(join[i]); }
+        (void)hipEventDestroy(fork);
+    }
+};
+inline thread_local FanOut t_fan;
+
 }  // namespace svthost

@@ -461,6 +461,30 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
     return launch_status("ois_sad");
 }
 
+extern "C" int svt_hip_ois_search_frame(const uint8_t* d_pic, uint32_t stride, uint32_t width, uint32_t height,
+                                        const svt_hip_ois_group* groups, int ngroups, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (ngroups == 0) return SVT_HIP_OK;
+    if (!groups || ngroups < 0 || ngroups > 64) return set_err(SVT_HIP_ERR_INVALID, "group list");
+    if (int rc = t_fan.ensure()) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int nstreams = ngroups < kFanStreams ? ngroups : kFanStreams;
+    HIP_TRY(hipEventRecord(t_fan.fork, s));
+    for (int i = 0; i < nstreams; i++) HIP_TRY(hipStreamWaitEvent(t_fan.s[i], t_fan.fork, 0));
+    int rc = SVT_HIP_OK;
+    for (int g = 0; g < ngroups && rc == SVT_HIP_OK; g++) {
+        const svt_hip_ois_group& G = groups[g];
+        if (G.nblocks == 0) continue;
+        rc = svt_hip_ois_search_batch(d_pic, stride, width, height, G.d_xy, G.bsize, G.modes, G.angle_deltas, G.ncand, G.d_distortion,
+                                      G.d_best_index, G.d_work, G.work_bytes, G.nblocks, t_fan.s[g % nstreams]);
+    }
+    // always join, also after an error: the caller's stream (or capture) must not be left with dangling branches
+    for (int i = 0; i < nstreams; i++)
+        if (hipEventRecord(t_fan.join[i], t_fan.s[i]) != hipSuccess || hipStreamWaitEvent(s, t_fan.join[i], 0) != hipSuccess)
+            if (rc == SVT_HIP_OK) rc = set_err(SVT_HIP_ERR_RUNTIME, "stream join failed");
+    return rc;
+}
+
 // one intra block: stage [lo, hi) of above / left around the origin, predict, copy the block back
 static void dropin_intra(int mode, int bw, int bh, void* dst, ptrdiff_t stride, const void* above, const void* left,
                          int a_lo, int a_hi, int l_lo, int l_hi, int ua, int ul, int dx, int dy, int is16, int bd,

@@ -496,28 +496,6 @@ extern "C" int svt_hip_fwd_quant_planes_batch(const void* d_src, uint32_t src_st
 
 // ---- frame-level fan-out: independent groups on internal streams, forked from and joined into the caller's stream ----
 namespace {
-constexpr int kFanStreams = 8;
-struct FanOut {
-    hipStream_t s[kFanStreams] = {};
-    hipEvent_t fork = nullptr, join[kFanStreams] = {};
-    bool ready = false;
-    int ensure() {
-        if (ready) return SVT_HIP_OK;
-        HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-        for (int i = 0; i < kFanStreams; i++) {
-            HIP_TRY(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&join[i], hipEventDisableTiming));
-        }
-        ready = true;
-        return SVT_HIP_OK;
-    }
-    ~FanOut() {
-        if (!ready) return;
-        for (int i = 0; i < kFanStreams; i++) { (void)hipStreamDestroy(s[i]); (void)hipEventDestroy(join[i]); }
-        (void)hipEventDestroy(fork);
-    }
-};
-thread_local FanOut t_fan;
 }  // namespace
 
 extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int ngroups, int is_16bit, int bd,

@@ -443,6 +443,24 @@ int svt_hip_ois_search_batch(const uint8_t *d_pic, uint32_t stride, uint32_t wid
                              int8_t *d_best_index, void *d_work, size_t work_bytes, size_t nblocks,
                              void *stream);
 
+/* The open-loop intra search of a whole PICTURE in one call: one group per block size (what svt_hip_ois_search_batch takes),
+ * run concurrently on the library's internal streams (forked from / joined into `stream`; the call only enqueues).  The four
+ * sizes of open_loop_intra_search_sb (EbMotionEstimation.c:8694) are independent, so the picture costs its slowest size, not
+ * their sum. */
+typedef struct svt_hip_ois_group {
+    const uint32_t *d_xy;                 /* block origins x | y << 16 */
+    uint32_t bsize;                       /* 8, 16, 32, 64 */
+    const uint8_t *modes;                 /* HOST candidate list (svt_hip_ois_candidates) */
+    const int8_t *angle_deltas;
+    int32_t ncand;
+    uint32_t *d_distortion;               /* [nblocks][ncand] */
+    int8_t *d_best_index;                 /* [nblocks] */
+    void *d_work;  size_t work_bytes;     /* svt_hip_ois_work_bytes(bsize, ncand, nblocks) */
+    size_t nblocks;
+} svt_hip_ois_group;
+int svt_hip_ois_search_frame(const uint8_t *d_pic, uint32_t stride, uint32_t width, uint32_t height,
+                             const svt_hip_ois_group *groups, int ngroups, void *stream);
+
 /* K11 chroma-from-luma helpers of the encode pass (Av1EncodeLoop, EbCodingLoop.c:736-846) and the
  * entropy stage's level map - the remaining pieces of SURVEY.md 8(f) n3.
  *

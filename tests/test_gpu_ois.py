@@ -140,3 +140,23 @@ def test_ois_argument_errors(dsp):
     assert L.svt_hip_ois_search_batch(p, 64, 64, 64, p, 8, m.ctypes.data, d.ctypes.data, 2, p, p, p, wb, 4, None) != 0        # 90 + 27 has no derivative
     assert L.svt_hip_ois_search_batch(p, 64, 64, 64, p, 8, m.ctypes.data, d.ctypes.data, 1, p, p, p, L.svt_hip_ois_work_bytes(8, 1, 4) - 1, 4, None) != 0    # work buffer
     assert L.svt_hip_ois_search_batch(p, 64, 64, 64, p, 8, m.ctypes.data, d.ctypes.data, 1, p, p, p, wb, 0, None) == 0        # empty
+
+
+def test_ois_search_frame_equals_per_size_calls(dsp):
+    """svt_hip_ois_search_frame (the four block sizes of a picture concurrently on internal streams) == one
+    svt_hip_ois_search_batch per size"""
+    rng = np.random.default_rng(2024)
+    W, H = 384, 256
+    buf = rng.integers(0, 256, size=(H, W + 16), dtype=np.uint8)
+    plane = dev(buf)
+    groups, single = [], []
+    for bsize in (8, 16, 32, 64):
+        blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
+        modes, deltas = dsp.ois_candidates(bsize)
+        xy = _xy(blocks)
+        groups.append((xy, bsize, modes, deltas))
+        single.append(dsp.ois_search(plane, W + 16, W, H, xy, bsize, modes, deltas))
+    outs = dsp.ois_search_frame(plane, W + 16, W, H, groups)
+    torch.cuda.synchronize()
+    for (d1, b1), (d2, b2) in zip(single, outs):
+        assert torch.equal(d1, d2) and torch.equal(b1, b2)

@@ -194,7 +194,15 @@ if want("ois"):
         tot += ms
         rec(f"ois_search_1080p_{bsize}x{bsize}_{len(modes)}cand", len(blocks), bsize * bsize * (1 + 2 * len(modes)), ms,
             {"candidate_predictions_per_s_M": round(len(blocks) * len(modes) / ms / 1e3, 1)})
-    print(json.dumps({"ois_search_1080p_all_sizes_ms": round(tot, 3)}), flush=True)
+    groups = []
+    for bsize in (8, 16, 32, 64):
+        blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
+        xy = torch.from_numpy(np.array([(y << 16) | x for x, y in blocks], np.uint32).view(np.int32)).to(dev)
+        modes, deltas = dsp.ois_candidates(bsize)
+        groups.append((xy, bsize, modes, deltas))
+    ms_frame = timeit(lambda: dsp.ois_search_frame(pic, W + 2 * pad, W, H, groups), iters=4)
+    rows.append({"kernel": "ois_search_1080p_all_sizes_one_call", "ms": round(ms_frame, 4), "units": 1, "bytes_per_unit": 0, "Munits_per_s": 0, "GBps": 0, "frac_hbm_peak": 0})
+    print(json.dumps({"ois_search_1080p_all_sizes_ms": round(tot, 3), "ois_search_1080p_all_sizes_one_call_ms": round(ms_frame, 4)}), flush=True)
 if want("me_sb"):
     for n, label in ((510, "1 ref"), (2040, "4 refs")):      # 510 SBs of a 1080p frame x reference pictures
         src = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 127, 128), dtype=torch.uint8, device=dev)
