@@ -42,7 +42,11 @@ __device__ __forceinline__ void idct64_pass(int (&x)[64]) {
     svtgen::svt_idct64_low32<12>(x, st_lo, st_hi);
 }
 
-template <typename PixT, int BD, bool KEEP>
+// MODE: E64_FULL the whole chain; E64_FWD stops after the quantiser (svt_hip_fwd_quant_*: coeff / qcoeff / dqcoeff / eob / sad);
+// E64_INV starts at the dequantised coefficients (svt_hip_inv_txfm2d_add_*: `dqcoeff` is the INPUT, `xy` holds element
+// offsets of the destination blocks (NULL: dense), `recon` is the destination that is read, updated and written).
+enum { E64_FULL = 0, E64_FWD = 1, E64_INV = 2 };
+template <typename PixT, int BD, bool KEEP, int MODE = E64_FULL>
 __device__ __forceinline__ void enc64_body(
     const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
     int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
@@ -65,7 +69,9 @@ __device__ __forceinline__ void enc64_body(
 #pragma unroll
     for (int b = 0; b < 2; b++) {
         const uint32_t blk = (b == 1 && !two) ? first : first + b;
-        if (xy) {
+        if (xy && MODE == E64_INV) {
+            sb[b] = pb[b] = rb[b] = (size_t)xy[blk];     // element offset of the destination block
+        } else if (xy) {
             const uint32_t o = xy[blk];
             const size_t y = o >> 16, x = o & 0xffffu;
             sb[b] = y * src_stride + x; pb[b] = y * pred_stride + x; rb[b] = y * recon_stride + x;
@@ -73,11 +79,14 @@ __device__ __forceinline__ void enc64_body(
             sb[b] = pb[b] = rb[b] = (size_t)blk * 4096;
         }
     }
-    if (xy) { ss = src_stride; ps = pred_stride; rs = recon_stride; }
+    if (xy || MODE == E64_INV) { ss = src_stride; ps = pred_stride; rs = recon_stride; }
 
-    // ---- residual -> LDS (packed int16), SAD on the raw words -------------------------------------------------------------
+    const int hb = lane >> 5, hk = lane & 31;
+    char* myrow = wl + hb * E64_TILE + hk * 128;           // this lane's coefficient row (32 x int32, slots swizzled by hk & 7)
     unsigned sad_acc[2] = {0, 0};
     constexpr int BATCH = 8;
+    if constexpr (MODE != E64_INV) {
+    // ---- residual -> LDS (packed int16), SAD on the raw words -------------------------------------------------------------
 #pragma unroll
     for (int it0 = 0; it0 < NIT; it0 += BATCH) {
         uint4 sv[BATCH], pv[BATCH];
@@ -133,8 +142,6 @@ __device__ __forceinline__ void enc64_body(
     }
     wave_lds_fence();
     // ---- forward row pass, both blocks at once: lanes 0-31 rows of block A, 32-63 rows of block B ------------------------
-    const int hb = lane >> 5, hk = lane & 31;
-    char* myrow = wl + hb * E64_TILE + hk * 128;           // this lane's coefficient row (32 x int32, slots swizzled by hk & 7)
     {
         int y[64];
         const int32_t* trow = reinterpret_cast<const int32_t*>(wl + hb * E64_TILE) + hk * 65;
@@ -148,10 +155,19 @@ __device__ __forceinline__ void enc64_body(
                 make_int4((y[4 * s] + 2) >> 2, (y[4 * s + 1] + 2) >> 2, (y[4 * s + 2] + 2) >> 2, (y[4 * s + 3] + 2) >> 2);   // shift[2] = -2
     }
     wave_lds_fence();
+    }
     // ---- quantise in linear chunk order (coalesced stores); dequantised chunks stay in registers --------------------------
     {
         int4 dvs[8];
         int eob_acc[2] = {0, 0};
+        if constexpr (MODE == E64_INV) {                   // the dequantised coefficients come from memory, linear 16-B chunks
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int b = it >> 2, w = (it & 3) * 64 + lane;
+                const uint32_t blk = (b == 1 && !two) ? first : first + b;
+                dvs[it] = *reinterpret_cast<const int4*>(dqcoeff + (size_t)blk * 1024 + (size_t)w * 4);
+            }
+        } else {
 #pragma unroll
         for (int it = 0; it < 8; it++) {
             const int b = it >> 2, w = (it & 3) * 64 + lane;       // chunk w of block b: row w / 8, slot w % 8
@@ -182,6 +198,8 @@ __device__ __forceinline__ void enc64_body(
                 if (sad) sad[first + b] = sd;
             }
         }
+        }
+        if constexpr (MODE == E64_FWD) return;
         wave_lds_fence();                                  // every chunk is read: the dequantised ones take their places
 #pragma unroll
         for (int it = 0; it < 8; it++) {
@@ -270,6 +288,27 @@ __global__ __launch_bounds__(E64_WAVES * 64) void enc64_kernel(
     __shared__ __attribute__((aligned(16))) char lds[E64_WAVES * E64_WAVE_LDS];
     enc64_body<PixT, BD, KEEP>(src, pred, recon, coeff, qcoeff, dqcoeff, eob, sad, iscan, qp, nblocks, xy, src_stride, pred_stride, recon_stride,
                                blockIdx.x, lds);
+}
+
+// svt_hip_fwd_quant_*: the forward half (coeff, qcoeff, dqcoeff, eob, sad out; no three_quad_energy - the pruned networks never
+// form the discarded coefficients, so the dispatcher keeps the one-block kernel when the caller asks for the energy)
+template <typename PixT, int BD>
+__global__ __launch_bounds__(E64_WAVES * 64) void fq64_kernel(
+    const PixT* __restrict__ src, const PixT* __restrict__ pred, int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff,
+    int32_t* __restrict__ dqcoeff, uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
+    uint32_t nblocks, const uint32_t* __restrict__ xy, uint32_t src_stride, uint32_t pred_stride) {
+    __shared__ __attribute__((aligned(16))) char lds[E64_WAVES * E64_WAVE_LDS];
+    enc64_body<PixT, BD, true, E64_FWD>(src, pred, nullptr, coeff, qcoeff, dqcoeff, eob, sad, iscan, qp, nblocks, xy, src_stride, pred_stride, 0,
+                                        blockIdx.x, lds);
+}
+// svt_hip_inv_txfm2d_add_* for 64x64: the inverse half on coefficients from memory (32x32 packed per block)
+template <typename PixT, int BD>
+__global__ __launch_bounds__(E64_WAVES * 64) void inv64_kernel(const int32_t* __restrict__ coeff, PixT* __restrict__ dst, uint32_t dst_stride,
+                                                               const uint32_t* __restrict__ offsets, uint32_t nblocks) {
+    __shared__ __attribute__((aligned(16))) char lds[E64_WAVES * E64_WAVE_LDS];
+    QParams qp = {};
+    enc64_body<PixT, BD, false, E64_INV>(dst, dst, dst, nullptr, nullptr, const_cast<int32_t*>(coeff), nullptr, nullptr, nullptr, qp, nblocks, offsets,
+                                         dst_stride, dst_stride, dst_stride, blockIdx.x, lds);
 }
 
 }  // namespace svtdev

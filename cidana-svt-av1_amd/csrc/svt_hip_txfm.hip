@@ -242,6 +242,15 @@ extern "C" int svt_hip_inv_txfm2d_add_batch(const int32_t* d_coeff, void* d_dst,
                            ((uintptr_t)d_dst & 15) == 0 && (kTxW[tx_size] * kTxH[tx_size] * (dst_is_16bit ? 2 : 1)) % 16 == 0;
     // 4-sample-wide 8-bit rows would be 4-B chunks of an unaligned plane: leave those to the general kernel
     const bool plane_dst = d_dst_offsets && kTxW[tx_size] * (dst_is_16bit ? 2 : 1) >= 8 && !g_tune_no_inv_planes;
+    if (tx_size == SVT_TX_64X64 && !g_tune_no_staged && !g_tune_no_enc64 && (dense_dst || plane_dst) && ((uintptr_t)d_coeff & 15) == 0) {
+        // two blocks per wave (the inverse half of enc64_kernel): the row pass runs once for both blocks' 32 coded rows
+        const dim3 grid((uint32_t)((nblocks + 2 * E64_WAVES - 1) / (2 * E64_WAVES)));
+#define INV64(T, B) hipLaunchKernelGGL((inv64_kernel<T, B>), grid, dim3(E64_WAVES * 64), 0, s, d_coeff, (T*)d_dst, (uint32_t)dst_stride, d_dst_offsets, (uint32_t)nblocks)
+        if (dst_is_16bit) { if (bd == 8) INV64(uint16_t, 8); else INV64(uint16_t, 10); }
+        else INV64(uint8_t, 8);
+#undef INV64
+        return launch_status("inv64");
+    }
     if (!g_tune_no_staged && (dense_dst || plane_dst) && ((uintptr_t)d_coeff & 15) == 0) {
 #define CALLS(W, H) launch_inv_staged<W, H>(d_coeff, d_dst, dst_is_16bit, nblocks, tx_type, bd, d_dst_offsets, dst_stride, s)
         TX_SWITCH(tx_size, CALLS)
@@ -481,6 +490,21 @@ extern "C" int svt_hip_fwd_quant_planes_batch(const void* d_src, uint32_t src_st
         else { if (d_sad) F32P(1, true, true); else F32P(1, false, true); }
 #undef F32P
         return launch_status("fwd_quant_32x32_planes");
+    }
+    if (tx_size == SVT_TX_64X64 && !g_tune_no_staged && !g_tune_no_enc64 && qp.fast_ok && !d_energy &&
+        (d_xy || (((uintptr_t)d_src & 15) == 0 && ((uintptr_t)d_pred & 15) == 0)) &&
+        ((uintptr_t)d_coeff & 15) == 0 && ((uintptr_t)d_qcoeff & 15) == 0 && ((uintptr_t)d_dqcoeff & 15) == 0) {
+        // two blocks per wave, forward networks pruned to the 32 kept outputs (the forward half of enc64_kernel); callers that
+        // want three_quad_energy keep the one-block kernel, which forms the discarded coefficients
+        const dim3 grid((uint32_t)((nblocks + 2 * E64_WAVES - 1) / (2 * E64_WAVES)));
+        const uint32_t ss = d_xy ? src_stride : 64u, ps = d_xy ? pred_stride : 64u;
+        if (is_16bit)
+            hipLaunchKernelGGL((fq64_kernel<uint16_t, 10>), grid, dim3(E64_WAVES * 64), 0, s, (const uint16_t*)d_src, (const uint16_t*)d_pred, d_coeff,
+                               d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks, d_xy, ss, ps);
+        else
+            hipLaunchKernelGGL((fq64_kernel<uint8_t, 8>), grid, dim3(E64_WAVES * 64), 0, s, (const uint8_t*)d_src, (const uint8_t*)d_pred, d_coeff,
+                               d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks, d_xy, ss, ps);
+        return launch_status("fwd_quant_64x64");
     }
     // staged (coalesced) kernels: dense batches need 16-B aligned inputs, plane-addressed blocks do not
     if (!g_tune_no_staged && qp.fast_ok && pels > 16 && (d_xy || (((uintptr_t)d_src & 15) == 0 && ((uintptr_t)d_pred & 15) == 0)) &&

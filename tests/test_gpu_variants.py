@@ -91,6 +91,39 @@ def test_encode_recon_64x64_two_blocks_per_wave_vs_one(dsp, n, keep, kind):
 
 
 @pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("n", [1, 6, 33])
+def test_fwd_quant_and_inverse_64x64_two_blocks_per_wave_vs_one(dsp, n, bd):
+    """fq64_kernel / inv64_kernel (the forward and the inverse half of the two-blocks-per-wave 64x64 kernel) against the one-block
+    staged kernels, on planes: coeff / qcoeff / dqcoeff / eob, then the reconstruction from those dequantised coefficients"""
+    rng = np.random.default_rng(64000 + n + bd)
+    PH, PW = 2 * 64 + 8, ((n + 1) // 2) * 64 + 24
+    dt = np.uint8 if bd == 8 else np.uint16
+    srcp = rng.integers(0, 1 << bd, size=(PH, PW)).astype(dt)
+    predp = np.clip(srcp.astype(np.int32) + rng.integers(-60, 61, size=(PH, PW)), 0, (1 << bd) - 1).astype(dt)
+    if n > 2:
+        srcp[:64, :64] = (1 << bd) - 1; predp[:64, :64] = 0          # a saturated block: the clamped inverse
+    xs = np.arange(0, PW - 63, 64); ys = np.arange(0, PH - 63, 64)
+    xy = ((ys[:, None] << 16) | xs[None, :]).reshape(-1)[:n].astype(np.uint32)
+    offs = ((xy >> 16) * PW + (xy & 0xffff)).astype(np.uint32)
+    _, iscan = svtlibs.scan_tables(4, 0)
+    view = (lambda a: a) if bd == 8 else (lambda a: a.view(np.int16))
+    outs = []
+    try:
+        for knob in (0, 1):
+            _tune(dsp, "no_enc64", knob)
+            r = dsp.fwd_quant_planes(dev(view(srcp)), PW, dev(view(predp)), PW, dev(xy.view(np.int32)), 4, 0, _qrow(bd, 60), dev(iscan), bd=bd)
+            recon = dev(view(predp))
+            dsp.inv_txfm2d_add(r["dqcoeff"], recon, 4, 0, bd, dst_stride=PW, dst_block_pitch=0, offsets=dev(offs.view(np.int32)))
+            r["recon"] = recon
+            outs.append(r)
+    finally:
+        _tune(dsp, "no_enc64", 0)
+    torch.cuda.synchronize()
+    assert _eq(outs[0], outs[1])
+    assert not torch.equal(outs[0]["recon"], dev(view(predp)))
+
+
+@pytest.mark.parametrize("bd", [8, 10])
 def test_encode_recon_64x64_planes_two_blocks_per_wave_vs_one(dsp, bd):
     """the same A/B on picture planes (origin table, in-place reconstruction into a copy of the prediction), 8 and 10 bit"""
     rng = np.random.default_rng(6400 + bd)
