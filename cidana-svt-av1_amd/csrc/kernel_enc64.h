@@ -42,10 +42,10 @@ __device__ __forceinline__ void idct64_pass(int (&x)[64]) {
     svtgen::svt_idct64_low32<12>(x, st_lo, st_hi);
 }
 
-// MODE: E64_FULL the whole chain; E64_FWD stops after the quantiser (svt_hip_fwd_quant_*: coeff / qcoeff / dqcoeff / eob / sad);
-// E64_INV starts at the dequantised coefficients (svt_hip_inv_txfm2d_add_*: `dqcoeff` is the INPUT, `xy` holds element
-// offsets of the destination blocks (NULL: dense), `recon` is the destination that is read, updated and written).
-enum { E64_FULL = 0, E64_FWD = 1, E64_INV = 2 };
+// MODE: E64_FULL the whole chain; E64_FWD stops after the quantiser (svt_hip_fwd_quant_*: coeff / qcoeff / dqcoeff / eob / sad).
+// (An inverse-only mode was measured against inv_staged_kernel<64, 64> with its 16-bit tile at 4 waves / SIMD: equal, 0.93-0.96 ms
+// per 2^18 blocks, so the standalone inverse keeps that kernel.)
+enum { E64_FULL = 0, E64_FWD = 1 };
 template <typename PixT, int BD, bool KEEP, int MODE = E64_FULL>
 __device__ __forceinline__ void enc64_body(
     const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
@@ -69,9 +69,7 @@ __device__ __forceinline__ void enc64_body(
 #pragma unroll
     for (int b = 0; b < 2; b++) {
         const uint32_t blk = (b == 1 && !two) ? first : first + b;
-        if (xy && MODE == E64_INV) {
-            sb[b] = pb[b] = rb[b] = (size_t)xy[blk];     // element offset of the destination block
-        } else if (xy) {
+        if (xy) {
             const uint32_t o = xy[blk];
             const size_t y = o >> 16, x = o & 0xffffu;
             sb[b] = y * src_stride + x; pb[b] = y * pred_stride + x; rb[b] = y * recon_stride + x;
@@ -79,13 +77,13 @@ __device__ __forceinline__ void enc64_body(
             sb[b] = pb[b] = rb[b] = (size_t)blk * 4096;
         }
     }
-    if (xy || MODE == E64_INV) { ss = src_stride; ps = pred_stride; rs = recon_stride; }
+    if (xy) { ss = src_stride; ps = pred_stride; rs = recon_stride; }
 
     const int hb = lane >> 5, hk = lane & 31;
     char* myrow = wl + hb * E64_TILE + hk * 128;           // this lane's coefficient row (32 x int32, slots swizzled by hk & 7)
     unsigned sad_acc[2] = {0, 0};
     constexpr int BATCH = 8;
-    if constexpr (MODE != E64_INV) {
+    {
     // ---- residual -> LDS (packed int16), SAD on the raw words -------------------------------------------------------------
 #pragma unroll
     for (int it0 = 0; it0 < NIT; it0 += BATCH) {
@@ -160,14 +158,7 @@ __device__ __forceinline__ void enc64_body(
     {
         int4 dvs[8];
         int eob_acc[2] = {0, 0};
-        if constexpr (MODE == E64_INV) {                   // the dequantised coefficients come from memory, linear 16-B chunks
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const int b = it >> 2, w = (it & 3) * 64 + lane;
-                const uint32_t blk = (b == 1 && !two) ? first : first + b;
-                dvs[it] = *reinterpret_cast<const int4*>(dqcoeff + (size_t)blk * 1024 + (size_t)w * 4);
-            }
-        } else {
+        {
 #pragma unroll
         for (int it = 0; it < 8; it++) {
             const int b = it >> 2, w = (it & 3) * 64 + lane;       // chunk w of block b: row w / 8, slot w % 8
@@ -301,14 +292,4 @@ __global__ __launch_bounds__(E64_WAVES * 64) void fq64_kernel(
     enc64_body<PixT, BD, true, E64_FWD>(src, pred, nullptr, coeff, qcoeff, dqcoeff, eob, sad, iscan, qp, nblocks, xy, src_stride, pred_stride, 0,
                                         blockIdx.x, lds);
 }
-// svt_hip_inv_txfm2d_add_* for 64x64: the inverse half on coefficients from memory (32x32 packed per block)
-template <typename PixT, int BD>
-__global__ __launch_bounds__(E64_WAVES * 64) void inv64_kernel(const int32_t* __restrict__ coeff, PixT* __restrict__ dst, uint32_t dst_stride,
-                                                               const uint32_t* __restrict__ offsets, uint32_t nblocks) {
-    __shared__ __attribute__((aligned(16))) char lds[E64_WAVES * E64_WAVE_LDS];
-    QParams qp = {};
-    enc64_body<PixT, BD, false, E64_INV>(dst, dst, dst, nullptr, nullptr, const_cast<int32_t*>(coeff), nullptr, nullptr, nullptr, qp, nblocks, offsets,
-                                         dst_stride, dst_stride, dst_stride, blockIdx.x, lds);
-}
-
 }  // namespace svtdev

@@ -242,15 +242,6 @@ extern "C" int svt_hip_inv_txfm2d_add_batch(const int32_t* d_coeff, void* d_dst,
                            ((uintptr_t)d_dst & 15) == 0 && (kTxW[tx_size] * kTxH[tx_size] * (dst_is_16bit ? 2 : 1)) % 16 == 0;
     // 4-sample-wide 8-bit rows would be 4-B chunks of an unaligned plane: leave those to the general kernel
     const bool plane_dst = d_dst_offsets && kTxW[tx_size] * (dst_is_16bit ? 2 : 1) >= 8 && !g_tune_no_inv_planes;
-    if (tx_size == SVT_TX_64X64 && !g_tune_no_staged && !g_tune_no_enc64 && (dense_dst || plane_dst) && ((uintptr_t)d_coeff & 15) == 0) {
-        // two blocks per wave (the inverse half of enc64_kernel): the row pass runs once for both blocks' 32 coded rows
-        const dim3 grid((uint32_t)((nblocks + 2 * E64_WAVES - 1) / (2 * E64_WAVES)));
-#define INV64(T, B) hipLaunchKernelGGL((inv64_kernel<T, B>), grid, dim3(E64_WAVES * 64), 0, s, d_coeff, (T*)d_dst, (uint32_t)dst_stride, d_dst_offsets, (uint32_t)nblocks)
-        if (dst_is_16bit) { if (bd == 8) INV64(uint16_t, 8); else INV64(uint16_t, 10); }
-        else INV64(uint8_t, 8);
-#undef INV64
-        return launch_status("inv64");
-    }
     if (!g_tune_no_staged && (dense_dst || plane_dst) && ((uintptr_t)d_coeff & 15) == 0) {
 #define CALLS(W, H) launch_inv_staged<W, H>(d_coeff, d_dst, dst_is_16bit, nblocks, tx_type, bd, d_dst_offsets, dst_stride, s)
         TX_SWITCH(tx_size, CALLS)

@@ -93,8 +93,8 @@ def test_encode_recon_64x64_two_blocks_per_wave_vs_one(dsp, n, keep, kind):
 @pytest.mark.parametrize("bd", [8, 10])
 @pytest.mark.parametrize("n", [1, 6, 33])
 def test_fwd_quant_and_inverse_64x64_two_blocks_per_wave_vs_one(dsp, n, bd):
-    """fq64_kernel / inv64_kernel (the forward and the inverse half of the two-blocks-per-wave 64x64 kernel) against the one-block
-    staged kernels, on planes: coeff / qcoeff / dqcoeff / eob, then the reconstruction from those dequantised coefficients"""
+    """fq64_kernel (the forward half of the two-blocks-per-wave 64x64 kernel) against the one-block staged kernel, on planes:
+    coeff / qcoeff / dqcoeff / eob, then the reconstruction from those dequantised coefficients"""
     rng = np.random.default_rng(64000 + n + bd)
     PH, PW = 2 * 64 + 8, ((n + 1) // 2) * 64 + 24
     dt = np.uint8 if bd == 8 else np.uint16
@@ -111,11 +111,10 @@ def test_fwd_quant_and_inverse_64x64_two_blocks_per_wave_vs_one(dsp, n, bd):
     try:
         for knob in (0, 1):
             _tune(dsp, "no_enc64", knob)
-            r = dsp.fwd_quant_planes(dev(view(srcp)), PW, dev(view(predp)), PW, dev(xy.view(np.int32)), 4, 0, _qrow(bd, 60), dev(iscan), bd=bd)
+            co, q, dq, eob, _, _ = dsp.fwd_quant_planes(dev(view(srcp)), PW, dev(view(predp)), PW, dev(xy.view(np.int32)), 4, 0, _qrow(bd, 60), dev(iscan), bd=bd)
             recon = dev(view(predp))
-            dsp.inv_txfm2d_add(r["dqcoeff"], recon, 4, 0, bd, dst_stride=PW, dst_block_pitch=0, offsets=dev(offs.view(np.int32)))
-            r["recon"] = recon
-            outs.append(r)
+            dsp.inv_txfm2d_add(dq, recon, 4, 0, bd, dst_stride=PW, dst_block_pitch=0, offsets=dev(offs.view(np.int32)))
+            outs.append({"coeff": co, "qcoeff": q, "dqcoeff": dq, "eob": eob, "recon": recon})
     finally:
         _tune(dsp, "no_enc64", 0)
     torch.cuda.synchronize()
