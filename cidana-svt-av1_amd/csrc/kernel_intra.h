@@ -249,6 +249,9 @@ __device__ __forceinline__ uint32_t dir_lerp2(uint32_t pair, uint32_t w) {      
 // output batch `slot[k] * batch_pitch` samples into dst.
 struct DirMulti {
     int n;                       // 0: single-angle launch (dx, dy arguments)
+    int chunk;                   // angles per workgroup: blockIdx.y takes angles [y * chunk, y * chunk + chunk).  A picture-sized
+                                 // batch leaves the GPU a few workgroups per CU each walking all (up to 19) angles one after the
+                                 // other - a latency chain; spreading the angles over grid.y shortens it (edges are re-staged per y)
     int16_t dx[20], dy[20];
     uint8_t slot[20];
     size_t batch_pitch;
@@ -419,7 +422,10 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
         }
     };
     if (multi.n == 0) emit(dx, dy, dst, 0);
-    else for (int k = 0; k < multi.n; k++) emit(multi.dx[k], multi.dy[k], dst + (size_t)multi.slot[k] * multi.batch_pitch, (int)multi.slot[k]);
+    else {
+        const int k0 = (int)blockIdx.y * multi.chunk, k1 = min(multi.n, k0 + multi.chunk);
+        for (int k = k0; k < k1; k++) emit(multi.dx[k], multi.dy[k], dst + (size_t)multi.slot[k] * multi.batch_pitch, (int)multi.slot[k]);
+    }
 }
 
 // av1_filter_intra_edge(_high) (:3539) — out-of-place on the device: every output

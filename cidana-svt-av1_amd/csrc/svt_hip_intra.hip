@@ -173,8 +173,18 @@ static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pit
         const size_t shmem = slots * 2 * (size_t)((n_pad + 7) & ~7) * 4;            // pair dwords (see the kernel)
         DirMulti dm;
         if (multi) dm = *multi; else dm.n = 0;
+        // angles per workgroup: all of them when the batch alone fills the GPU (>= 16 workgroups per CU), else split over grid.y
+        uint32_t gy = 1;
+        dm.chunk = dm.n > 0 ? dm.n : 1;
+        if (dm.n > 1 && !g_tune_dir_no_split) {
+            const size_t want = (size_t)16 * (size_t)g_num_cu;
+            size_t parts = grid >= want ? 1 : (want + grid - 1) / grid;
+            if (parts > (size_t)dm.n) parts = (size_t)dm.n;
+            dm.chunk = (int)((dm.n + parts - 1) / parts);
+            gy = (uint32_t)((dm.n + dm.chunk - 1) / dm.chunk);
+        }
 #define IDL(T, M)                                                                                                     \
-    hipLaunchKernelGGL((intra_dir_kernel<T, M>), dim3((uint32_t)grid), dim3(256), shmem, s, (T*)d_dst, dst_stride, \
+    hipLaunchKernelGGL((intra_dir_kernel<T, M>), dim3((uint32_t)grid, gy), dim3(256), shmem, s, (T*)d_dst, dst_stride, \
                        dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh,            \
                        upsample_above, upsample_left, dx, dy, lim_a, lim_l, n_pad, bd, (uint32_t)nblocks, dm)
 #define IDM(T)                                                                                                        \

@@ -95,6 +95,25 @@ def test_ois_fold_variant(dsp, bsize):
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("bsize", [8, 16])
+def test_ois_directional_angles_split_over_grid_variant(dsp, bsize):
+    """small batches spread the directional angles of a zone over grid.y (dir_no_split = 0) == every workgroup walks all angles"""
+    rng = np.random.default_rng(300 + bsize)
+    W, H = 320, 192
+    buf = rng.integers(0, 256, size=(H, W + 24), dtype=np.uint8)
+    blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
+    modes, deltas = dsp.ois_candidates(bsize)
+    plane = dev(buf)
+    out = []
+    try:
+        for v in (0, 1):
+            assert dsp.lib.svt_hip_tune(b"dir_no_split", v) == 0
+            out.append(dsp.ois_search(plane, W + 24, W, H, _xy(blocks), bsize, modes, deltas))
+    finally:
+        dsp.lib.svt_hip_tune(b"dir_no_split", 0)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("bsize,tl", [(8, 0), (16, 0), (8, 2), (32, 0), (64, 0), (32, 2)])
 def test_ois_fused_non_directional_variant(dsp, bsize, tl):
     """ois_nd_kernel (non-directional candidates predicted and summed straight from the picture, one launch when the list has no
