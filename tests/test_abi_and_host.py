@@ -258,3 +258,24 @@ def test_intra_availability_host_helper_equals_reference_tables_and_oracle(pkg):
     for c in cases:
         _, out5 = svtlibs.oracle_predict_intra_block(O, c)
         assert product_px(c) == out5[:4].tolist(), {k: v for k, v in c.items() if np.isscalar(v)}
+
+
+FRAME_HOST = os.path.join(ROOT, "tests", "c", "frame_host.c")
+
+
+def build_frame_host(tmp_path):
+    exe = str(tmp_path / "frame_host")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"), FRAME_HOST, "-o", exe,
+                           "-L", PKG, "-lsvt_hip_dsp", "-Wl,-rpath," + PKG])
+    return exe
+
+
+def test_c_frame_host_compiles_and_fails_loudly_without_a_device(tmp_path):
+    """tests/c/frame_host.c: the batched interface driven from plain C (tables from the library's host builders, uploads, one
+    svt_hip_encode_recon_frame call, digest); builds with gcc against the header and the library, and without a device exits 3"""
+    import torch
+    exe = build_frame_host(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_frame_api.py runs it")
+    pr = subprocess.run([exe, "128", "64", "100", "7"], capture_output=True, text=True)
+    assert pr.returncode == 3, (pr.returncode, pr.stdout, pr.stderr)

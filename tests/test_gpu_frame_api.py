@@ -207,3 +207,38 @@ def test_frame_single_launch_equals_per_size_launches(dsp, pkg, bd):
         assert torch.equal(ga["qcoeff"], gb["qcoeff"]), (ga["name"], ga["luma_size"])
         assert torch.equal(ga["eob"], gb["eob"]) and torch.equal(ga["recon"], gb["recon"])
         assert not torch.equal(gb["recon"], pred[gb["name"]])
+
+
+def test_plain_c_host_of_the_frame_call_equals_the_python_path(dsp, pkg, tmp_path):
+    """tests/c/frame_host.c (gcc, -lsvt_hip_dsp, no Python on the data path) on a 208x144 picture: its digest == the digest of
+    frames.FramePass on the same samples (same LCG), i.e. the C host tables, uploads, group array and the frame call agree with
+    the ctypes mirror"""
+    import subprocess
+    from test_abi_and_host import build_frame_host
+    from cidana_svt_av1_amd import frames
+    W, H, q, seed = 208, 144, 100, 12345
+    exe = build_frame_host(tmp_path)
+    pr = subprocess.run([exe, str(W), str(H), str(q), str(seed)], capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0, (pr.returncode, pr.stdout, pr.stderr)
+    tok = pr.stdout.split()
+    got = [int(tok[1]), int(tok[3]), int(tok[5]), int(tok[7])]
+    # the same picture in numpy: LCG state * 1664525 + 1013904223, sample = state >> 8
+    s = np.uint64(seed)
+    planes_src, planes_pred = {}, {}
+    for name, (ph, pw) in (("Y", (H, W)), ("U", (H // 2, W // 2)), ("V", (H // 2, W // 2))):
+        n = ph * pw
+        st = np.zeros(2 * n, np.uint64)
+        cur = int(s)
+        for i in range(2 * n):
+            cur = (cur * 1664525 + 1013904223) & 0xffffffff
+            st[i] = cur >> 8
+        s = np.uint64(cur)
+        a = (st[0::2] & 255).astype(np.int32)
+        b = np.clip(a + (st[1::2] % 49).astype(np.int32) - 24, 0, 255)
+        planes_src[name] = torch.from_numpy(a.astype(np.uint8).reshape(ph, pw)).cuda()
+        planes_pred[name] = torch.from_numpy(b.astype(np.uint8).reshape(ph, pw)).cuda()
+    qrow = {k: v[q].copy() for k, v in pkg.tables.quant_tables(8).items()}
+    fp = frames.FramePass(dsp, pkg, planes_src, planes_pred)
+    fp.run(qrow)
+    torch.cuda.synchronize()
+    assert got == [int(v) for v in fp.digest().cpu().numpy()]
