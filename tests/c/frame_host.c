@@ -77,7 +77,7 @@ int main(int argc, char **argv) {
             for (int y = 0; y < by; y++)
                 for (int x = 0; x < bx; x++) xy[(size_t)y * bx + x] = (uint32_t)(x * side) | ((uint32_t)(y * side) << 16);
             int16_t scan[1024], iscan[1024];
-            CHECK(svt_hip_get_scan(tx, SVT_DCT_DCT, scan, iscan));
+            if (svt_hip_get_scan(tx, SVT_DCT_DCT, scan, iscan) != nc) { fprintf(stderr, "svt_hip_get_scan\n"); return 4; }   /* returns the entry count */
             svt_hip_frame_group *g = &groups[ng];
             memset(g, 0, sizeof(*g));
             g->d_src = d_src[p]; g->src_stride = (uint32_t)pw[p];
