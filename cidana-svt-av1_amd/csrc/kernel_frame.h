@@ -10,7 +10,7 @@
 // What one launch costs: the register file and LDS of the launch are the maximum over the bodies (the 64x64 body), so the
 // small sizes run at its occupancy instead of their own.  For ONE picture that is cheaper than 13 dispatches; for a GOP the
 // per-size launches win.  3 waves / SIMD: at that budget (168 VGPRs) the 64x64 body spills 12 B (8-bit) / 36 B
-// (10-bit) to scratch; measured against 2 waves / SIMD without scratch (192 VGPRs): 5 350 against 4 560 4K 10-bit pictures/s.  Covered: square sizes 4 .. 64, DCT_DCT, qcoeff + eob + recon outputs, 8 / 10 bit,
+// (10-bit) to scratch; measured against 2 waves / SIMD without scratch (192 VGPRs): 5 350 against 4 560 4K 10-bit pictures/s.  Covered: square sizes 4 .. 64, every transform type the reference defines for them, qcoeff + eob + recon outputs, 8 / 10 bit,
 // power-of-two quant_shift tables.
 #pragma once
 #include "kernel_enc64.h"
@@ -26,6 +26,7 @@ struct FrameGroupDev {
     const uint32_t* xy; const int16_t* iscan;
     uint32_t src_stride, pred_stride, recon_stride, nblocks;
     int32_t tx_size;                 // SVT_TX_4X4 .. SVT_TX_64X64 (0 .. 4)
+    int32_t tx_type;                 // any type the reference defines for the size (32x32: DCT_DCT / IDTX, 64x64: DCT_DCT)
     uint32_t wg_end;                 // one past the last workgroup of this group in the launch
     QParams qp;                      // per group: log_scale differs with the size
 };
@@ -56,19 +57,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void e
     PixT* recon = reinterpret_cast<PixT*>(G.recon);
     switch (G.tx_size) {
     case 0:
-        enc4_body<PixT, BD, false>(src, pred, recon, nullptr, G.qcoeff, nullptr, G.eob, nullptr, G.iscan, G.qp, 1, 0, G.nblocks, G.xy, G.src_stride,
+        enc4_body<PixT, BD, false>(src, pred, recon, nullptr, G.qcoeff, nullptr, G.eob, nullptr, G.iscan, G.qp, 1, G.tx_type, G.nblocks, G.xy, G.src_stride,
                                    G.pred_stride, G.recon_stride, bid);
         break;
     case 1:
-        enc_staged_body<8, 8, false, PixT, BD>(src, pred, recon, nullptr, G.qcoeff, nullptr, G.eob, nullptr, G.iscan, G.qp, 0, G.nblocks, G.xy,
+        enc_staged_body<8, 8, false, PixT, BD>(src, pred, recon, nullptr, G.qcoeff, nullptr, G.eob, nullptr, G.iscan, G.qp, G.tx_type, G.nblocks, G.xy,
                                                G.src_stride, G.pred_stride, G.recon_stride, bid, lds);
         break;
     case 2:
-        enc_staged_body<16, 16, false, PixT, BD>(src, pred, recon, nullptr, G.qcoeff, nullptr, G.eob, nullptr, G.iscan, G.qp, 0, G.nblocks, G.xy,
+        enc_staged_body<16, 16, false, PixT, BD>(src, pred, recon, nullptr, G.qcoeff, nullptr, G.eob, nullptr, G.iscan, G.qp, G.tx_type, G.nblocks, G.xy,
                                                  G.src_stride, G.pred_stride, G.recon_stride, bid, lds);
         break;
     case 3:
-        enc32_body<PixT, BD, false, false>(src, pred, recon, nullptr, G.qcoeff, nullptr, G.eob, nullptr, G.iscan, G.qp, 0, G.nblocks, G.xy, G.src_stride,
+        enc32_body<PixT, BD, false, false>(src, pred, recon, nullptr, G.qcoeff, nullptr, G.eob, nullptr, G.iscan, G.qp, G.tx_type == 9 /* IDTX */ ? 1 : 0, G.nblocks, G.xy, G.src_stride,
                                            G.pred_stride, G.recon_stride, bid, reinterpret_cast<int32_t*>(lds));
         break;
     default:

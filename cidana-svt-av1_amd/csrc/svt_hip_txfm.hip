@@ -529,7 +529,7 @@ extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int
         if (G.tx_size == SVT_TX_4X4 && g_tune_no_enc_staged && (!G.d_coeff || !G.d_offsets || G.d_recon != G.d_pred || G.recon_stride != G.pred_stride))
             return set_err(SVT_HIP_ERR_INVALID, "group %d: with no_enc_staged set, 4x4 groups take the two-stage path and need d_coeff, d_dqcoeff, d_offsets and in-place reconstruction", g);
     }
-    // ---- ONE launch for the whole call (enc_frame_kernel) when every group is one it covers: square DCT_DCT sizes 4 .. 64,
+    // ---- ONE launch for the whole call (enc_frame_kernel) when every group is one it covers: square sizes 4 .. 64 (any type),
     // qcoeff + recon outputs, power-of-two quant_shift tables.  Measured (tools/bench_frame.py, tools/bench_c5.py): one 1080p
     // picture 0.044 ms against 0.160 (13 launches on 8 streams) / 0.101 (those captured into a graph); one 4K 10-bit picture
     // 5 390 against 3 990 pictures/s; a stack of 16 1080p pictures the same either way; a stack of 30 4K 10-bit pictures 5 270
@@ -544,7 +544,7 @@ extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int
         for (int g = 0; g < ngroups && ok; g++) {
             const svt_hip_frame_group& G = groups[g];
             if (G.nblocks == 0) continue;
-            ok = G.tx_size >= SVT_TX_4X4 && G.tx_size <= SVT_TX_64X64 && G.tx_type == SVT_DCT_DCT && !G.d_coeff && G.d_recon != G.d_src &&
+            ok = G.tx_size >= SVT_TX_4X4 && G.tx_size <= SVT_TX_64X64 && !G.d_coeff && G.d_recon != G.d_src &&      // (type / size validated above)
                  (((uintptr_t)G.d_qcoeff) & 15) == 0;
         }
         if ((is_16bit && bd != 10) || (!is_16bit && bd != 8)) ok = false;
@@ -569,7 +569,7 @@ extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int
                 for (int i = 0; i < 2; i++) ok = ok && D.qp.quant_shift[i] >= 0 && D.qp.dequant[i] >= 0 && D.qp.round[i] >= 0;
                 ok = ok && D.qp.fast_ok;
                 D.src = G.d_src; D.pred = G.d_pred; D.recon = G.d_recon; D.qcoeff = G.d_qcoeff; D.eob = G.d_eob; D.xy = G.d_xy; D.iscan = G.d_iscan;
-                D.src_stride = G.src_stride; D.pred_stride = G.pred_stride; D.recon_stride = G.recon_stride; D.nblocks = G.nblocks; D.tx_size = G.tx_size;
+                D.src_stride = G.src_stride; D.pred_stride = G.pred_stride; D.recon_stride = G.recon_stride; D.nblocks = G.nblocks; D.tx_size = G.tx_size; D.tx_type = G.tx_type;
                 // blocks per 256-thread workgroup of each body: 256 (4x4), 32 (8x8: 4 waves x 8), 16 (16x16: 4 x 4), 8 (32x32: 4 x 2), 4 (64x64: 2 x 2)
                 static const uint32_t per_wg[5] = {256, 32, 16, 8, 4};
                 total += (G.nblocks + per_wg[G.tx_size] - 1) / per_wg[G.tx_size];

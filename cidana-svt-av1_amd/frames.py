@@ -28,7 +28,8 @@ class FramePass:
     """Device-side state of every group of one or more passes over one picture: origin tables, scan tables, output
     buffers, and the ctypes group array for svt_hip_encode_recon_frame.  Keeps every tensor alive."""
 
-    def __init__(self, dsp, pkg, planes_src, planes_pred, luma_sizes=LUMA_SIZES, is_16bit=False, keep_coeff=False):
+    def __init__(self, dsp, pkg, planes_src, planes_pred, luma_sizes=LUMA_SIZES, is_16bit=False, keep_coeff=False, tx_types=None):
+        """tx_types: {block side: transform type} (default DCT_DCT everywhere)"""
         import torch
         self.dsp, self.torch = dsp, torch
         self.groups = []
@@ -53,11 +54,12 @@ class FramePass:
                 n = xy.size
                 if n == 0:
                     continue
-                _, iscan = pkg.tables.scan_tables(ts, 0)
+                tt = (tx_types or {}).get(side, 0)
+                _, iscan = pkg.tables.scan_tables(ts, tt)
                 nc = min(side, 32) ** 2
                 pred = planes_pred[name]
                 recon = pred.clone()              # samples outside the full tiles keep the prediction, as in-place reconstruction would
-                g = {"name": name, "luma_size": S, "tx_size": ts, "tx_type": 0, "src": src, "src_stride": pw, "pred": pred, "pred_stride": pw,
+                g = {"name": name, "luma_size": S, "tx_size": ts, "tx_type": tt, "src": src, "src_stride": pw, "pred": pred, "pred_stride": pw,
                      "recon": recon, "recon_stride": pw, "xy": torch.from_numpy(xy.view(np.int32)).to(dev),
                      "offsets": torch.from_numpy(offs.view(np.int32)).to(dev) if ts == 0 else None,
                      "iscan": torch.from_numpy(iscan).to(dev), "qcoeff": torch.empty((n, nc), dtype=torch.int32, device=dev),
@@ -82,7 +84,7 @@ class FramePass:
         bd = 10 if self.is_16bit else 8
         for g in self.groups:
             d.encode_recon_planes(g["src"], g["src_stride"], g["pred"], g["pred_stride"], g["recon"], g["recon_stride"], g["xy"],
-                                  g["tx_size"], 0, qrow, g["iscan"], bd=bd)
+                                  g["tx_size"], g["tx_type"], qrow, g["iscan"], bd=bd)
 
     def digest(self):
         """int64 [blocks, sum eob, sum |qcoeff| weighted checksum, sum recon samples] of the pass, computed on the device"""

@@ -193,10 +193,11 @@ def test_frame_single_launch_equals_per_size_launches(dsp, pkg, bd):
     src = {k: torch.randint(0, hi, s, dtype=torch.int32, device=dev_, generator=g).to(dt) for k, s in shapes.items()}
     pred = {k: (src[k].to(torch.int32) + torch.randint(-40, 41, src[k].shape, dtype=torch.int32, device=dev_, generator=g)).clamp_(0, hi - 1).to(dt) for k in shapes}
     outs = []
+    types = {64: 0, 32: 9, 16: 3, 8: 11, 4: 6} if bd == 8 else None      # DCT_DCT, IDTX, ADST_ADST, H_DCT, FLIPADST_FLIPADST
     try:
         for knob in (0, 1):
             assert dsp.lib.svt_hip_tune(b"frame_single_launch", knob) == 0
-            fp = frames.FramePass(dsp, pkg, src, pred, is_16bit=bd > 8)
+            fp = frames.FramePass(dsp, pkg, src, pred, is_16bit=bd > 8, tx_types=types)
             fp.run(qrow)
             torch.cuda.synchronize()
             outs.append(fp)
