@@ -4,7 +4,7 @@
 //
 // One WAVE per block, four blocks per workgroup.  Both edges of a block live in LDS as 16-bit samples (at most
 // 16 + 2*64 + 16 each) and go through the reference's stages in place; every stage is a read phase into registers, a
-// barrier and a write phase, so the result is what the reference's sequential loops produce.  The stage sequence (and so
+// wave-level LDS fence (a wave's edges are its own: no workgroup barrier) and a write phase, so the result is what the reference's sequential loops produce.  The stage sequence (and so
 // the number of barriers) is the same for every wave whatever its block's mode; stages a block does not need are
 // predicated off.  Output: 4 samples per lane per step (one 4- or 8-byte store when the address allows).
 //
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
             A[-1] = (uint16_t)c; L[-1] = (uint16_t)c;
         }
     }
-    __syncthreads();
+    wave_lds_fence();
     const bool filt = is_dr && !d.disable_edge_filter && !const_fill;
     const bool angled = filt && p_angle != 90 && p_angle != 180;
     // ---- stage 2: corner filter (filter_intra_edge_corner, :3383) ----------------------------------------------------
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
         const int s = ((int)L[0] * 5 + (int)A[-1] * 6 + (int)A[0] * 5 + 8) >> 4;
         A[-1] = (uint16_t)s; L[-1] = (uint16_t)s;
     }
-    __syncthreads();
+    wave_lds_fence();
     // ---- stage 3: edge smoothing (av1_filter_intra_edge, :3539): sample 0 of the run is kept ---------------------------
     {
         const int ab_le = need_above_left ? 1 : 0;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
             va[t] = (sa && i >= 1 && i < na) ? taps(A - ab_le, i, na, sa) : -1;
             vl[t] = (sl && i >= 1 && i < nl) ? taps(L - ab_le, i, nl, sl) : -1;
         }
-        __syncthreads();
+        wave_lds_fence();
 #pragma unroll
         for (int t = 0; t < 3; t++) {
             const int i = lane + 64 * t;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
             if (vl[t] >= 0) L[i - ab_le] = (uint16_t)vl[t];
         }
     }
-    __syncthreads();
+    wave_lds_fence();
     // ---- stage 4: 2x up-sampling (av1_upsample_intra_edge, :3597): p[-2 .. 2 sz - 2] from p[-1 .. sz - 1] ---------------
     const int up_a = (filt && need_above) ? bip_use_upsample(w, h, p_angle - 90, ft) : 0;
     const int up_l = (filt && need_left) ? bip_use_upsample(h, w, p_angle - 180, ft) : 0;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
         if (up_l && lane < szl)
 #pragma unroll
             for (int k = 0; k < 4; k++) il[k] = in_at(L, lane + k, szl);
-        __syncthreads();
+        wave_lds_fence();
         if (up_a && lane < sza) {
             if (lane == 0) A[-2] = (uint16_t)ia[0];
             A[2 * lane - 1] = (uint16_t)min(max((-ia[0] + 9 * ia[1] + 9 * ia[2] - ia[3] + 8) >> 4, 0), maxv);
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
             L[2 * lane] = (uint16_t)il[2];
         }
     }
-    __syncthreads();
+    wave_lds_fence();
     // ---- stage 5: prediction ---------------------------------------------------------------------------------------------
     // resolve to one of the predictor kinds
     int kind, dx = 1, dy = 1;
