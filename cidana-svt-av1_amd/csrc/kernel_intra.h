@@ -340,8 +340,6 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
     }
     auto emit = [&](const int dx, const int dy, PixT* __restrict__ dst, const int kslot) {
         uint32_t px[PXL];
-#pragma unroll
-        for (int k = 0; k < PXL; k++) px[k] = 0;          // (entries past ppl stay 0: narrow blocks)
         if (MODE == IM_Z1) {
             const int x = dx * (r + 1);
             const uint32_t sh = (uint32_t)(((x << up_above) & 0x3f) >> 1), w = (32u - sh) | (sh << 16);
@@ -349,16 +347,15 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
             const uint32_t* q = A + min((x >> (6 - up_above)) + (c0 << up_above), lim_a - NB_ORIGIN);
             if (up_above == 0) {
 #pragma unroll
-                for (int k = 0; k < PXL; k++) if (k < ppl) px[k] = dir_lerp2(q[k], w);
+                for (int k = 0; k < PXL; k++) px[k] = dir_lerp2(q[k], w);
             } else {
 #pragma unroll
-                for (int k = 0; k < PXL; k++) if (k < ppl) px[k] = dir_lerp2(q[2 * k], w);
+                for (int k = 0; k < PXL; k++) px[k] = dir_lerp2(q[2 * k], w);
             }
         } else if (MODE == IM_Z3) {
             int y = dy * (c0 + 1);
 #pragma unroll
             for (int k = 0; k < PXL; k++) {
-                if (k >= ppl) break;                       // narrow blocks: the lane's row has ppl < 16 pixels (uniform)
                 const uint32_t sh = (uint32_t)(((y << up_left) & 0x3f) >> 1);
                 px[k] = dir_lerp2(L[min((y >> (6 - up_left)) + (r << up_left), lim_l - NB_ORIGIN)], (32u - sh) | (sh << 16));
                 y += dy;
@@ -378,7 +375,6 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
                 const char* smb = reinterpret_cast<const char*>(sm);
 #pragma unroll
                 for (int k = 0; k < PXL; k++) {
-                    if (k >= ppl) break;
                     const bool ab = b0 >= -1 - k;
                     const uint32_t s2 = ((uint32_t)y >> 1) & 31u;              // (y & 0x3f) >> 1
                     const uint32_t w2 = s2 * 0xffffu + 32u;                    // (32 - s2) | s2 << 16
@@ -390,7 +386,6 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
             } else
 #pragma unroll
             for (int k = 0; k < PXL; k++) {
-                if (k >= ppl) break;
                 const int base1 = (x >> (6 - up_above)) + ((c0 + k) << up_above);
                 const bool ab = base1 >= lim;
                 const uint32_t s2 = (uint32_t)(((y * (1 << up_left)) & 0x3f) >> 1);
