@@ -34,6 +34,14 @@ elif name == "me_sb":
     n = 510
     src = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 127, 128), dtype=torch.uint8, device=dev)
     fn = lambda: dsp.me_sb_search(src, ref, 64, 64)
+elif name.startswith("ois"):          # ois8 / ois16: the open-loop intra search of one 1080p picture at that block size
+    import numpy as np
+    bsize = int(name[3:]); W, H, pad = 1920, 1080, 64
+    plane = torch.randint(0, 256, (H + 2 * pad, W + 2 * pad), dtype=torch.uint8, device=dev); pic = plane[pad:, pad:]
+    blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
+    xy = torch.from_numpy(np.array([(y << 16) | x for x, y in blocks], np.uint32).view(np.int32)).to(dev)
+    modes, deltas = dsp.ois_candidates(bsize)
+    fn = lambda: dsp.ois_search(pic, W + 2 * pad, W, H, xy, bsize, modes, deltas)
 elif name.startswith("enc"):          # enc32 / enc64 / enc16 / enc8: fused encode_recon (qcoeff + recon), as tools/bench_kernels.py
     S = int(name[3:]); s_ = {8: 1, 16: 2, 32: 3, 64: 4}[S]
     n = (1 << 20) * 1024 // (S * S) if S <= 32 else 1 << 18
