@@ -264,7 +264,9 @@ struct DirMulti {
     uint32_t sad_ncand;
 };
 
-template <typename PixT, int MODE>
+// NPX = samples per lane = min(bw, 16 B worth): a compile-time constant so that narrow blocks (bw 4 / 8) do not compute
+// a full 16-B segment per lane and throw most of it away (the open-loop search's 8x8 pass spent half its VALU there).
+template <typename PixT, int MODE, int NPX>
 __global__ __launch_bounds__(256) void intra_dir_kernel(
     PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
     const PixT* __restrict__ above_all, const PixT* __restrict__ left_all, int32_t nb_pitch, int bw, int bh,
@@ -274,9 +276,11 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
     const uint32_t maxv = (1u << bd) - 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t dir_smem[];
     uint32_t* sm = reinterpret_cast<uint32_t*>(dir_smem);
-    constexpr int PXL = 16 / (int)sizeof(PixT);
+    constexpr int PXL = NPX;
     constexpr int PPW = 4 / (int)sizeof(PixT);                             // pixels per output dword
-    const int ppl = bw < PXL ? bw : PXL;
+    constexpr int NW = NPX / PPW;                                          // output dwords per lane
+    static_assert(NPX * (int)sizeof(PixT) <= 16 && NW >= 1, "a lane writes 4 .. 16 bytes");
+    constexpr int ppl = NPX;                                               // host: NPX == min(bw, 16 / sizeof(PixT))
     const int lanes_per_row = bw >> __builtin_ctz((uint32_t)ppl);
     const uint32_t per_block = (uint32_t)(lanes_per_row * bh);             // power of two, 4 .. 512
     const int pb_shift = __builtin_ctz(per_block);
@@ -400,9 +404,9 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
 #pragma unroll
                 for (int k = 0; k < PXL; k++) px[k] = min(px[k], maxv);
             }
-            uint32_t w[4];
+            uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NW; q++) {
                 uint32_t v = px[q * PPW];
 #pragma unroll
                 for (int t = 1; t < PPW; t++) v |= px[q * PPW + t] << (8 * (int)sizeof(PixT) * t);

@@ -173,6 +173,13 @@ __global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__
     const uint32_t row = l >> cpr_sh, col = (l & ((1u << cpr_sh) - 1)) * CS;
     const uint8_t* sblk = pic + (size_t)y * stride + x;
     const bool has_a = y != 0, has_l = x != 0;
+    // ---- the sums the directional kernels left in dist (kind OIS_K_FOLDED): the workgroup's contiguous run of rows in one coalesced
+    // pass, issued before everything else.  (Fetching them one candidate at a time inside the loop below was a chain of up to 38
+    // dependent global loads per wave - two thirds of this kernel's time on the 8x8 list.)  The loop overwrites the other entries.
+    const uint32_t first = blockIdx.x * slots;
+    const uint32_t nb_here = first < nblocks ? (nblocks - first < slots ? nblocks - first : slots) : 0;
+    if (kinds.k[OIS_MAX_CAND + 2])                         // host: set when the list has a folded candidate
+        for (uint32_t i = threadIdx.x; i < nb_here * ncand; i += 256) s_dist[i] = dist[(size_t)first * ncand + i];
     // ---- this lane's samples: source chunk, the above segment over it, its row's left sample, the three corners --------------
     uint32_t sv[4] = {0, 0, 0, 0}, av[4];
     __builtin_memcpy(sv, sblk + (size_t)row * stride + col, CS);
@@ -204,13 +211,11 @@ __global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__
     const uint32_t lg = __builtin_ctz(bsize);
     const int dcv = (has_a && has_l) ? (dsum + (int)bsize) >> (lg + 1) : ((has_a || has_l) ? (dsum + (int)(bsize >> 1)) >> lg : 128);
     const int wh = kOisSmWeights[bsize + row];
+    if (lpb <= 64) __syncthreads();                        // the copy above before this loop's stores (64x64: the barrier above)
     // ---- candidates -------------------------------------------------------------------------------------------------------------
     for (uint32_t c = 0; c < ncand; c++) {
         const uint32_t kind = kinds.k[c];                  // uniform (kernel argument)
-        if (kind == OIS_K_FOLDED) {
-            if (valid && l == 0) row_out[c] = dist[(size_t)blk * ncand + c];
-            continue;
-        }
+        if (kind == OIS_K_FOLDED) continue;
         uint32_t pv[4] = {0, 0, 0, 0};
         if (kind == OIS_K_DC) { pv[0] = pv[1] = pv[2] = pv[3] = (uint32_t)dcv * 0x01010101u; }
         else if (kind == OIS_K_V) { pv[0] = av[0]; pv[1] = av[1]; pv[2] = av[2]; pv[3] = av[3]; }
@@ -245,8 +250,6 @@ __global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__
             if (kinds.k[c] != OIS_K_FOLDED) row_out[c] = wave_part[c] + wave_part[ncand + c] + wave_part[2 * ncand + c] + wave_part[3 * ncand + c];
         __syncthreads();
     }
-    const uint32_t first = blockIdx.x * slots;
-    const uint32_t nb_here = first < nblocks ? (nblocks - first < slots ? nblocks - first : slots) : 0;
     for (uint32_t i = threadIdx.x; i < nb_here * ncand; i += 256) dist[(size_t)first * ncand + i] = s_dist[i];
     if (threadIdx.x < nb_here) {
         const uint32_t* r = s_dist + (size_t)threadIdx.x * ncand;

@@ -183,15 +183,17 @@ static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pit
             dm.chunk = (int)((dm.n + parts - 1) / parts);
             gy = (uint32_t)((dm.n + dm.chunk - 1) / dm.chunk);
         }
-#define IDL(T, M)                                                                                                     \
-    hipLaunchKernelGGL((intra_dir_kernel<T, M>), dim3((uint32_t)grid, gy), dim3(256), shmem, s, (T*)d_dst, dst_stride, \
-                       dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh,            \
+#define IDL(T, M, P)                                                                                                     \
+    hipLaunchKernelGGL((intra_dir_kernel<T, M, P>), dim3((uint32_t)grid, gy), dim3(256), shmem, s, (T*)d_dst, dst_stride, \
+                       dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh,               \
                        upsample_above, upsample_left, dx, dy, lim_a, lim_l, n_pad, bd, (uint32_t)nblocks, dm)
-#define IDM(T)                                                                                                        \
-    switch (mode) {                                                                                                   \
-    case SVT_INTRA_Z1: IDL(T, IM_Z1); break; case SVT_INTRA_Z2: IDL(T, IM_Z2); break; default: IDL(T, IM_Z3); break;  \
+#define IDM(T, P)                                                                                                             \
+    switch (mode) {                                                                                                           \
+    case SVT_INTRA_Z1: IDL(T, IM_Z1, P); break; case SVT_INTRA_Z2: IDL(T, IM_Z2, P); break; default: IDL(T, IM_Z3, P); break; \
     }
-        if (is_16bit) { IDM(uint16_t) } else { IDM(uint8_t) }
+        // samples per lane (ppl) is a template parameter: 4 / 8 / 16 for bytes, 4 / 8 for 16-bit samples
+        if (is_16bit) { if (ppl == 8) { IDM(uint16_t, 8) } else { IDM(uint16_t, 4) } }
+        else if (ppl == 16) { IDM(uint8_t, 16) } else if (ppl == 8) { IDM(uint8_t, 8) } else { IDM(uint8_t, 4) }
 #undef IDM
 #undef IDL
         return launch_status("intra_dir");
@@ -349,6 +351,7 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
             } else k = m == 9 ? OIS_K_SMOOTH : (m == 10 ? OIS_K_SMOOTH_V : (m == 11 ? OIS_K_SMOOTH_H : OIS_K_PAETH));
             kinds.k[c] = (uint8_t)k;
         }
+        kinds.k[OIS_MAX_CAND + 2] = any_dir ? 1 : 0;              // ois_nd_kernel: rows of dist hold folded sums to pick up
         const bool can_fold = bsize <= 16 && !g_tune_ois_no_fold;
         if (!g_tune_ois_no_nd && (!any_dir || can_fold)) {
             if (any_dir) {
