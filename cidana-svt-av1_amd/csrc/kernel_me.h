@@ -491,21 +491,111 @@ __host__ __device__ inline void me_pu_rect(int pu, int& x, int& y, int& w, int& 
 // shape as soon as its parts exist:   band: 8x8, 16x8, 32x8 | two bands: 8x16, 16x16, 32x16, 64x16 | 32-row half: 8x32,
 // 16x32, 32x32, 64x32 | SB: 16x64, 32x64, 64x64.  Sums that fit 16 bits on every other row (up to 32x16 / 16x32: 65 280) stay
 // packed; larger ones are widened per point.  Each PU's four keys (sad << 16 | point, or 2 * sad << 12 | point for the wide
-// ones) are min-reduced over the wave on the DPP path and lane 63 folds them into the workgroup's table, indexed in the
-// reference's EbMeTierZeroPu order.  With four points per lane the reference window costs one dword read per v_qsad, so the
-// LDS pipe and the 209 reductions per pass - not v_qsad - set the pace: measured 20x+ over the exact kernel.
+// ones) are min-reduced over the wave sixteen PUs at a time (me_wave_min16 below) into the wave's table; the last step maps the
+// table back to the reference's EbMeTierZeroPu order (kNsqLoc).  With four points per lane the reference window costs one dword
+// read per v_qsad.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned me_key4_min(unsigned long long a, unsigned idb) {
+// ---- batched wave minimum -------------------------------------------------------------------------------------------------
+// A PU's result is the minimum of its key over every lane.  One DPP reduction per PU (six dependent v_min_u32_dpp + a lane-63
+// table update, 209 times per pass) cost more than the v_qsad work itself.  Sixteen keys are reduced TOGETHER instead, halving
+// the number of live registers at every step (a transposing reduction): gfx950's v_permlane32_swap / v_permlane16_swap exchange
+// half-waves / odd-even rows between two registers, so  min(swap(a, b))  leaves a's result in one half of the lanes and b's in
+// the other; the last two register-halving steps select between two mirrored-DPP minima.  35 VALU instructions per 16 keys
+// instead of 96 + 16 table updates; afterwards lane L holds the wave minimum of key (L >> 2) & 15 and lanes L % 4 == 0 fold
+// the batch into the wave's table with ONE ds_min_u32.
+__device__ __forceinline__ unsigned me_min_swap32(unsigned a, unsigned b) {     // lanes 0..31: min over halves of a; 32..63: of b
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    return min((unsigned)r[0], (unsigned)r[1]);
+}
+__device__ __forceinline__ unsigned me_min_swap16(unsigned a, unsigned b) {     // even rows of 16 lanes: a; odd rows: b
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    return min((unsigned)r[0], (unsigned)r[1]);
+}
+__device__ __forceinline__ unsigned me_wave_min16(unsigned (&k)[16], bool bit3, bool bit2) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = me_min_swap32(k[i], k[i + 8]);           // lane bit 5 picks k[i] / k[i + 8]
+#pragma unroll
+    for (int i = 0; i < 4; i++) k[i] = me_min_swap16(k[i], k[i + 4]);           // lane bit 4 picks k[i] / k[i + 4]
+#pragma unroll
+    for (int i = 0; i < 2; i++) {                                                // lane bit 3 picks k[i] / k[i + 2] (row_mirror: i <-> 15 - i)
+        const unsigned a = min(k[i], (unsigned)__builtin_amdgcn_update_dpp((int)k[i], (int)k[i], 0x140, 0xF, 0xF, false));
+        const unsigned b = min(k[i + 2], (unsigned)__builtin_amdgcn_update_dpp((int)k[i + 2], (int)k[i + 2], 0x140, 0xF, 0xF, false));
+        k[i] = bit3 ? b : a;
+    }
+    {                                                                            // lane bit 2 picks k[0] / k[1] (row_half_mirror)
+        const unsigned a = min(k[0], (unsigned)__builtin_amdgcn_update_dpp((int)k[0], (int)k[0], 0x141, 0xF, 0xF, false));
+        const unsigned b = min(k[1], (unsigned)__builtin_amdgcn_update_dpp((int)k[1], (int)k[1], 0x141, 0xF, 0xF, false));
+        k[0] = bit2 ? b : a;
+    }
+    unsigned v = k[0];
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    return v;
+}
+
+// Batches of me_nsq4_kernel (15 per pass x 16 slots; -1 = unused slot) and where each PU's minimum lands in the wave's table.
+// z16: z-order index of the 16x16 at column c16 of 16-row band h16 of half h32 (EbMeTierZeroPu numbering).
+constexpr int nsq_z16(int h32, int h16, int c16) { return 8 * h32 + 4 * (c16 >> 1) + 2 * h16 + (c16 & 1); }
+constexpr int nsq_band_pu(int h32, int h16, int kb, int s) {          // 8-row band: 8x8 [0..7], 16x8 [8..11], 32x8 [12..13]
+    if (s < 8) return 21 + 4 * nsq_z16(h32, h16, s >> 1) + 2 * kb + (s & 1);
+    if (s < 12) return 95 + 2 * nsq_z16(h32, h16, s - 8) + kb;
+    if (s < 14) return 169 + 4 * (2 * h32 + (s - 12)) + 2 * h16 + kb;
+    return -1;
+}
+constexpr int nsq_row16_pu(int h32, int h16, int s) {                  // 16-row band: 8x16 [0..7], 16x16 [8..11], 32x16 [12..13], 64x16 [14]
+    if (s < 8) return 137 + 2 * nsq_z16(h32, h16, s >> 1) + (s & 1);
+    if (s < 12) return 5 + nsq_z16(h32, h16, s - 8);
+    if (s < 14) return 87 + 2 * (2 * h32 + (s - 12)) + h16;
+    if (s == 14) return 201 + 2 * h32 + h16;
+    return -1;
+}
+constexpr int nsq_half_pu(int h32, int s) {                            // 32-row half: 8x32 [0..7], 16x32 [8..11], 32x32 [12..13], 64x32 [14]
+    if (s < 8) return 185 + 4 * (2 * h32 + (s >> 2)) + (s & 3);
+    if (s < 12) return 129 + 2 * (2 * h32 + ((s - 8) >> 1)) + ((s - 8) & 1);
+    if (s < 14) return 1 + 2 * h32 + (s - 12);
+    if (s == 14) return 85 + h32;
+    return -1;
+}
+constexpr int nsq_sb_pu(int s) { return s < 4 ? 205 + s : (s < 6 ? 127 + (s - 4) : (s == 6 ? 0 : -1)); }   // 16x64, 32x64, 64x64
+constexpr int NSQ_BATCHES = 15;                                        // per half: band (h16, kb) -> 3 * h16 + kb, row16 -> 3 * h16 + 2, half -> 6; SB -> 14
+struct NsqLoc { uint8_t v[ME_PUS_ALL]; int filled; };
+constexpr NsqLoc make_nsq_loc() {
+    NsqLoc t{};
+    for (int h32 = 0; h32 < 2; h32++)
+        for (int s = 0; s < 16; s++) {
+            for (int h16 = 0; h16 < 2; h16++) {
+                for (int kb = 0; kb < 2; kb++)
+                    if (const int pu = nsq_band_pu(h32, h16, kb, s); pu >= 0) { t.v[pu] = (uint8_t)((7 * h32 + 3 * h16 + kb) * 16 + s); t.filled++; }
+                if (const int pu = nsq_row16_pu(h32, h16, s); pu >= 0) { t.v[pu] = (uint8_t)((7 * h32 + 3 * h16 + 2) * 16 + s); t.filled++; }
+            }
+            if (const int pu = nsq_half_pu(h32, s); pu >= 0) { t.v[pu] = (uint8_t)((7 * h32 + 6) * 16 + s); t.filled++; }
+        }
+    for (int s = 0; s < 16; s++)
+        if (const int pu = nsq_sb_pu(s); pu >= 0) { t.v[pu] = (uint8_t)(14 * 16 + s); t.filled++; }
+    return t;
+}
+constexpr bool nsq_loc_is_a_bijection() {
+    const NsqLoc t = make_nsq_loc();
+    if (t.filled != ME_PUS_ALL) return false;
+    bool seen[NSQ_BATCHES * 16] = {};
+    for (int p = 0; p < ME_PUS_ALL; p++) { if (seen[t.v[p]]) return false; seen[t.v[p]] = true; }
+    return true;
+}
+static_assert(nsq_loc_is_a_bijection(), "every PU must own exactly one (batch, slot)");
+__device__ constexpr NsqLoc kNsqLoc = make_nsq_loc();
+
+// keys of a lane's four points: sad << 16 | point (packed u16 sums, SAD still to be doubled) or (2 * sad) << 12 | point (wide
+// sums); c[j] = point index of the lane's j-th point, or 0xffffffff in a lane without work (the key is then all ones)
+__device__ __forceinline__ unsigned me_key4_min(unsigned long long a, const unsigned (&c)[4]) {
     const unsigned lo = (unsigned)a, hi = (unsigned)(a >> 32);
-    const unsigned k0 = ((lo << 16) | idb) + 0u, k1 = ((lo & 0xffff0000u) | idb) + 1u;
-    const unsigned k2 = ((hi << 16) | idb) + 2u, k3 = ((hi & 0xffff0000u) | idb) + 3u;
+    const unsigned k0 = (lo << 16) | c[0], k1 = (lo & 0xffff0000u) | c[1], k2 = (hi << 16) | c[2], k3 = (hi & 0xffff0000u) | c[3];
     return min(min(k0, k1), min(k2, k3));
 }
 __device__ __forceinline__ void me_unpack4(unsigned long long a, unsigned (&o)[4]) {
     o[0] = (unsigned)a & 0xffffu; o[1] = ((unsigned)a) >> 16; o[2] = (unsigned)(a >> 32) & 0xffffu; o[3] = (unsigned)(a >> 48);
 }
-__device__ __forceinline__ unsigned me_bigkey4_min(const unsigned (&s2)[4], unsigned idb) {      // s2 = doubled SADs (< 2^20)
-    return min(min((s2[0] << 12) | (idb + 0u), (s2[1] << 12) | (idb + 1u)), min((s2[2] << 12) | (idb + 2u), (s2[3] << 12) | (idb + 3u)));
+__device__ __forceinline__ unsigned me_bigkey4_min(const unsigned (&s2)[4], const unsigned (&c)[4]) {      // s2 = doubled SADs (< 2^20)
+    return min(min((s2[0] << 12) | c[0], (s2[1] << 12) | c[1]), min((s2[2] << 12) | c[2], (s2[3] << 12) | c[3]));
 }
 
 __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void me_nsq4_kernel(
@@ -517,7 +607,7 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_src = reinterpret_cast<uint32_t*>(smem);            // [32 even rows][16 dwords]
     uint8_t* s_ref = smem + 32 * 64;                                // [(64+sh-1)][wpitch], wpitch % 16 == 0
-    __shared__ unsigned s_red[4][ME_PUS_ALL];
+    __shared__ unsigned s_red[4][NSQ_BATCHES * 16];                 // [wave][batch][slot]
     const uint32_t blk = blockIdx.x;
     if (blk >= nblocks) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -529,7 +619,7 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         __builtin_memcpy(&v, gs + (size_t)(2 * r) * src_stride + c * 16, 16);
         reinterpret_cast<uint4*>(s_src)[tid] = v;
     }
-    for (int i = tid; i < 4 * ME_PUS_ALL; i += ME_THREADS) (&s_red[0][0])[i] = 0xffffffffu;
+    for (int i = tid; i < 4 * NSQ_BATCHES * 16; i += ME_THREADS) (&s_red[0][0])[i] = 0xffffffffu;
     const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
     {
         const uint32_t cpr = (win_w + 15) >> 4;
@@ -551,9 +641,11 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     __syncthreads();
 
-    auto put = [&](int pu, unsigned key) {                 // wave minimum of a PU's key -> this wave's row of the table
-        const unsigned k = wave_min_u32_to_lane63(key);
-        if (lane == 63) s_red[wave][pu] = min(s_red[wave][pu], k);
+    const bool bit3 = (lane & 8) != 0, bit2 = (lane & 4) != 0, writer = (lane & 3) == 0;
+    unsigned* my_red = &s_red[wave][(lane >> 2) & 15];
+    auto put16 = [&](int batch, unsigned (&k)[16]) {       // wave minima of 16 keys -> this wave's row of the table
+        const unsigned v = me_wave_min16(k, bit3, bit2);
+        if (writer) __hip_atomic_fetch_min(my_red + batch * 16, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
     const int xq = search_w >> 2;
     const int ntasks = xq * search_h;
@@ -562,8 +654,8 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const bool act = t < ntasks;
         const int tc = act ? t : 0;
         const int ys = tc / xq, xs0 = (tc - ys * xq) * 4;
-        const unsigned idb = (unsigned)(ys * search_w + xs0);
-        const unsigned dead = act ? 0u : 0xffffffffu;
+        const unsigned idb = (unsigned)(ys * search_w + xs0);          // a multiple of 4: idb + j == idb | j
+        const unsigned cj[4] = {act ? idb : 0xffffffffu, act ? idb | 1u : 0xffffffffu, act ? idb | 2u : 0xffffffffu, act ? idb | 3u : 0xffffffffu};
         const uint8_t* rbase = s_ref + (size_t)ys * wpitch + xs0;
         unsigned s64[4] = {0, 0, 0, 0};
         unsigned s32top[2][4];
@@ -571,9 +663,11 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll 1
         for (int h32 = 0; h32 < 2; h32++) {
             unsigned long long s16h0[4], v8x16h0[8], PA[2], PB[2], v16x32[4];
+            unsigned khalf[16];
 #pragma unroll
             for (int h16 = 0; h16 < 2; h16++) {
                 unsigned long long acc0[8], s16[4], v8x16[8];
+                unsigned krow[16];
 #pragma unroll
                 for (int kb = 0; kb < 2; kb++) {
                     unsigned long long acc[8];
@@ -593,22 +687,20 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         for (int q = 0; q < 16; q++)
                             acc[q >> 1] = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)rw[q + 1] << 32) | rw[q], sw[q], acc[q >> 1]);
                     }
-                    // ---- this 8-row band: 8x8, 16x8, 32x8 ----
+                    // ---- this 8-row band: 8x8, 16x8, 32x8 (slots as nsq_band_pu) ----
                     unsigned long long p16x8[4];
+                    unsigned kband[16];
 #pragma unroll
-                    for (int bx = 0; bx < 8; bx++) {
-                        const int c16 = bx >> 1, z16 = 8 * h32 + 4 * (c16 >> 1) + 2 * h16 + (c16 & 1);
-                        put(21 + 4 * z16 + 2 * kb + (bx & 1), me_key4_min(acc[bx], idb) | dead);
-                    }
+                    for (int bx = 0; bx < 8; bx++) kband[bx] = me_key4_min(acc[bx], cj);
 #pragma unroll
                     for (int c16 = 0; c16 < 4; c16++) {
-                        const int z16 = 8 * h32 + 4 * (c16 >> 1) + 2 * h16 + (c16 & 1);
                         p16x8[c16] = me_pk_add(acc[2 * c16], acc[2 * c16 + 1]);
-                        put(95 + 2 * z16 + kb, me_key4_min(p16x8[c16], idb) | dead);
+                        kband[8 + c16] = me_key4_min(p16x8[c16], cj);
                     }
 #pragma unroll
-                    for (int c32 = 0; c32 < 2; c32++)
-                        put(169 + 4 * (2 * h32 + c32) + 2 * h16 + kb, me_key4_min(me_pk_add(p16x8[2 * c32], p16x8[2 * c32 + 1]), idb) | dead);
+                    for (int c32 = 0; c32 < 2; c32++) kband[12 + c32] = me_key4_min(me_pk_add(p16x8[2 * c32], p16x8[2 * c32 + 1]), cj);
+                    kband[14] = kband[15] = 0xffffffffu;
+                    put16(7 * h32 + 3 * h16 + kb, kband);
                     if (kb == 0) {
 #pragma unroll
                         for (int bx = 0; bx < 8; bx++) acc0[bx] = acc[bx];
@@ -617,31 +709,31 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     } else {
 #pragma unroll
                         for (int bx = 0; bx < 8; bx++) {                              // 8x16
-                            const int c16 = bx >> 1, z16 = 8 * h32 + 4 * (c16 >> 1) + 2 * h16 + (c16 & 1);
                             v8x16[bx] = me_pk_add(acc0[bx], acc[bx]);
-                            put(137 + 2 * z16 + (bx & 1), me_key4_min(v8x16[bx], idb) | dead);
+                            krow[bx] = me_key4_min(v8x16[bx], cj);
                         }
 #pragma unroll
                         for (int c16 = 0; c16 < 4; c16++) s16[c16] = me_pk_add(s16[c16], p16x8[c16]);
                     }
                 }
-                // ---- this 16-row band: 16x16, 32x16, 64x16 ----
+                // ---- this 16-row band: 8x16 (above), 16x16, 32x16, 64x16 (slots as nsq_row16_pu) ----
                 unsigned long long p32x16[2];
 #pragma unroll
-                for (int c16 = 0; c16 < 4; c16++)
-                    put(5 + 8 * h32 + 4 * (c16 >> 1) + 2 * h16 + (c16 & 1), me_key4_min(s16[c16], idb) | dead);
+                for (int c16 = 0; c16 < 4; c16++) krow[8 + c16] = me_key4_min(s16[c16], cj);
 #pragma unroll
                 for (int c32 = 0; c32 < 2; c32++) {
                     p32x16[c32] = me_pk_add(s16[2 * c32], s16[2 * c32 + 1]);         // <= 65 280 per lane
-                    put(87 + 2 * (2 * h32 + c32) + h16, me_key4_min(p32x16[c32], idb) | dead);
+                    krow[12 + c32] = me_key4_min(p32x16[c32], cj);
                 }
                 {
                     unsigned a[4], b[4], s2[4];
                     me_unpack4(p32x16[0], a); me_unpack4(p32x16[1], b);
 #pragma unroll
                     for (int j = 0; j < 4; j++) s2[j] = (a[j] + b[j]) << 1;
-                    put(201 + 2 * h32 + h16, me_bigkey4_min(s2, idb) | dead);
+                    krow[14] = me_bigkey4_min(s2, cj);
                 }
+                krow[15] = 0xffffffffu;
+                put16(7 * h32 + 3 * h16 + 2, krow);
                 if (h16 == 0) {
 #pragma unroll
                     for (int c16 = 0; c16 < 4; c16++) s16h0[c16] = s16[c16];
@@ -650,17 +742,16 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     PA[0] = p32x16[0]; PA[1] = p32x16[1];
                 } else {
 #pragma unroll
+                    for (int bx = 0; bx < 8; bx++) khalf[bx] = me_key4_min(me_pk_add(v8x16h0[bx], v8x16[bx]), cj);   // 8x32
+#pragma unroll
                     for (int c16 = 0; c16 < 4; c16++) {                               // 16x32 (<= 65 280)
                         v16x32[c16] = me_pk_add(s16h0[c16], s16[c16]);
-                        put(129 + 2 * (2 * h32 + (c16 >> 1)) + (c16 & 1), me_key4_min(v16x32[c16], idb) | dead);
+                        khalf[8 + c16] = me_key4_min(v16x32[c16], cj);
                     }
-#pragma unroll
-                    for (int bx = 0; bx < 8; bx++)                                    // 8x32
-                        put(185 + 4 * (2 * h32 + (bx >> 2)) + (bx & 3), me_key4_min(me_pk_add(v8x16h0[bx], v8x16[bx]), idb) | dead);
                     PB[0] = p32x16[0]; PB[1] = p32x16[1];
                 }
             }
-            // ---- this 32-row half: 32x32, 64x32; parts of 32x64, 16x64, 64x64 ----
+            // ---- this 32-row half: 8x32, 16x32 (above), 32x32, 64x32 (slots as nsq_half_pu); parts of 32x64, 16x64, 64x64 ----
             unsigned s32[2][4];
 #pragma unroll
             for (int c32 = 0; c32 < 2; c32++) {
@@ -668,14 +759,16 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 me_unpack4(PA[c32], a); me_unpack4(PB[c32], b);
 #pragma unroll
                 for (int j = 0; j < 4; j++) { s32[c32][j] = (a[j] + b[j]) << 1; s64[j] += s32[c32][j]; }
-                put(1 + 2 * h32 + c32, me_bigkey4_min(s32[c32], idb) | dead);
+                khalf[12 + c32] = me_bigkey4_min(s32[c32], cj);
             }
             {
                 unsigned w[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) w[j] = s32[0][j] + s32[1][j];
-                put(85 + h32, me_bigkey4_min(w, idb) | dead);
+                khalf[14] = me_bigkey4_min(w, cj);
             }
+            khalf[15] = 0xffffffffu;
+            put16(7 * h32 + 6, khalf);
             if (h32 == 0) {
 #pragma unroll
                 for (int c32 = 0; c32 < 2; c32++)
@@ -684,28 +777,33 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                 for (int c16 = 0; c16 < 4; c16++) v16x32top[c16] = v16x32[c16];
             } else {
-#pragma unroll
-                for (int c32 = 0; c32 < 2; c32++) {                                   // 32x64
-                    unsigned w[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) w[j] = s32top[c32][j] + s32[c32][j];
-                    put(127 + c32, me_bigkey4_min(w, idb) | dead);
-                }
+                unsigned ksb[16];                                                     // slots as nsq_sb_pu
 #pragma unroll
                 for (int c16 = 0; c16 < 4; c16++) {                                   // 16x64
                     unsigned a[4], b[4], w[4];
                     me_unpack4(v16x32top[c16], a); me_unpack4(v16x32[c16], b);
 #pragma unroll
                     for (int j = 0; j < 4; j++) w[j] = (a[j] + b[j]) << 1;
-                    put(205 + c16, me_bigkey4_min(w, idb) | dead);
+                    ksb[c16] = me_bigkey4_min(w, cj);
                 }
+#pragma unroll
+                for (int c32 = 0; c32 < 2; c32++) {                                   // 32x64
+                    unsigned w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) w[j] = s32top[c32][j] + s32[c32][j];
+                    ksb[4 + c32] = me_bigkey4_min(w, cj);
+                }
+                ksb[6] = me_bigkey4_min(s64, cj);                                     // 64x64
+#pragma unroll
+                for (int i = 7; i < 16; i++) ksb[i] = 0xffffffffu;
+                put16(14, ksb);
             }
         }
-        put(0, me_bigkey4_min(s64, idb) | dead);
     }
     __syncthreads();
     if (tid < ME_PUS_ALL) {
-        const unsigned key = min(min(s_red[0][tid], s_red[1][tid]), min(s_red[2][tid], s_red[3][tid]));
+        const int loc = kNsqLoc.v[tid];
+        const unsigned key = min(min(s_red[0][loc], s_red[1][loc]), min(s_red[2][loc], s_red[3][loc]));
         // wide PUs carry (2 * sad) << 12 | point; the others sad16 << 16 | point with the SAD still to be doubled
         const bool wide = tid < 5 || tid == 85 || tid == 86 || tid == 127 || tid == 128 || tid >= 201;
         const unsigned sad = wide ? key >> 12 : (key >> 16) << 1;
