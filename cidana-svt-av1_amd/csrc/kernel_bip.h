@@ -2,11 +2,14 @@
 // batch of prediction blocks of one transform size, fused into one launch: edge selection and extension, corner, the
 // directional modes' smoothing filters and 2x up-sampling, DC by availability, and the prediction.
 //
-// One WAVE per block, four blocks per workgroup.  Both edges of a block live in LDS as 16-bit samples (at most
-// 16 + 2*64 + 16 each) and go through the reference's stages in place; every stage is a read phase into registers, a
-// wave-level LDS fence (a wave's edges are its own: no workgroup barrier) and a write phase, so the result is what the reference's sequential loops produce.  The stage sequence (and so
-// the number of barriers) is the same for every wave whatever its block's mode; stages a block does not need are
-// predicated off.  Output: 4 samples per lane per step (one 4- or 8-byte store when the address allows).
+// A group of LPB = 4 .. 64 lanes per block (the smallest power of two that covers a block's w + h + 1 edge samples in three
+// rounds), 64 / LPB blocks per wave, four waves per workgroup: a wave's life is a chain of dependent loads (descriptor -> edge
+// samples -> LDS stages -> stores) whatever the block size, so small blocks share it (one 16x16 block per wave: 1.3 G blocks/s;
+// four: see DESIGN 4.15).  Both edges of a block live in LDS as 16-bit samples and go through the reference's stages in place;
+// every stage is a read phase into registers, a wave-level LDS fence (a wave's edges are its own: no workgroup barrier) and a
+// write phase, so the result is what the reference's sequential loops produce.  The stage sequence (and so the number of
+// fences) is the same for every block whatever its mode; stages a block does not need are predicated off.  Output: 4 samples
+// per lane per step (one 4- or 8-byte store when the address allows).
 //
 // Write-bound like the other predictors (1-2 B out per pixel, ~2(W+H) samples in per block) but with per-block modes the
 // kernel cannot be specialised per mode the way intra_pred_kernel is; it is the encode-pass glue, not the search loop.
@@ -57,24 +60,34 @@ __device__ __forceinline__ int bip_use_upsample(int bs0, int bs1, int delta, int
     return type ? (wh <= 8) : (wh <= 16);
 }
 
-constexpr int BIP_EDGE = 16 + 160;          // staged samples per edge: positions [-16, 160)
 constexpr int BIP_WAVES = 4;
+// staged samples per edge: positions [-16, n): n covers w + h samples, twice that where the edge can be up-sampled (w + h <= 16)
+__host__ __device__ constexpr int bip_edge_len(int w, int h) { return (16 + (w + h <= 16 ? 2 * (w + h) : w + h) + 8 + 7) & ~7; }
+// lanes per block: w + h + 1 edge samples in at most three rounds (the smoothing stage keeps three values per lane)
+__host__ __device__ constexpr int bip_lanes_per_block(int w, int h) {
+    const int need = (w + h + 1 + 2) / 3;
+    int l = 4;
+    while (l < need) l <<= 1;
+    return l > 64 ? 64 : l;
+}
 
 template <typename PixT>
 __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
     PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
     const PixT* __restrict__ top_all, const PixT* __restrict__ left_all, int32_t neigh_pitch, const BipBlk* __restrict__ blks,
     int w, int h, int bd, uint32_t nblocks) {
-    __shared__ uint16_t s_edge[BIP_WAVES][2][BIP_EDGE];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t blk_id = blockIdx.x * BIP_WAVES + (uint32_t)wv;
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_edge[];          // [BIP_WAVES * blocks per wave][2][bip_edge_len]
+    const int LPB = bip_lanes_per_block(w, h), lsh = __builtin_ctz((uint32_t)LPB), bpw = 64 >> lsh, EL = bip_edge_len(w, h);
+    const int wv = threadIdx.x >> 6, sub = (threadIdx.x & 63) >> lsh;
+    const int lane = threadIdx.x & (LPB - 1);                 // lane inside the block's group
+    const uint32_t blk_id = (blockIdx.x * BIP_WAVES + (uint32_t)wv) * (uint32_t)bpw + (uint32_t)sub;
     const bool live = blk_id < nblocks;
-    const uint32_t b = live ? blk_id : 0u;                    // a spare wave replays block 0 without storing
+    const uint32_t b = live ? blk_id : 0u;                    // a spare group replays block 0 without storing
     const BipBlk d = blks[b];
     const PixT* __restrict__ top = top_all + (size_t)b * neigh_pitch + 1;       // element 0 is the corner: top[-1]
     const PixT* __restrict__ left = left_all + (size_t)b * neigh_pitch + 1;
-    uint16_t* A = s_edge[wv][0] + 16;
-    uint16_t* L = s_edge[wv][1] + 16;
+    uint16_t* A = s_edge + (size_t)((wv * bpw + sub) * 2) * EL + 16;
+    uint16_t* L = A + EL;
     const int maxv = (1 << bd) - 1, base = 128 << (bd - 8);
 
     const int mode = d.mode > 12 ? 12 : d.mode;
@@ -108,11 +121,11 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
         const int need_l = need_left ? h + (need_bottom ? w : 0) : 0;
         const int avail_l = (need_bottom && n_bl > 0) ? h + n_bl : n_left;
         const int def_l = n_top > 0 ? (int)top[0] : base + 1;
-        for (int i = lane; i < need_l; i += 64) L[i] = (uint16_t)(n_left > 0 ? (int)left[min(i, avail_l - 1)] : def_l);
+        for (int i = lane; i < need_l; i += LPB) L[i] = (uint16_t)(n_left > 0 ? (int)left[min(i, avail_l - 1)] : def_l);
         const int need_a = need_above ? w + (need_right ? h : 0) : 0;
         const int avail_a = (need_right && n_tr > 0) ? n_top + n_tr : n_top;
         const int def_a = n_left > 0 ? (int)left[0] : base - 1;
-        for (int i = lane; i < need_a; i += 64) A[i] = (uint16_t)(n_top > 0 ? (int)top[min(i, avail_a - 1)] : def_a);
+        for (int i = lane; i < need_a; i += LPB) A[i] = (uint16_t)(n_top > 0 ? (int)top[min(i, avail_a - 1)] : def_a);
         if (lane == 0 && need_above_left) {
             const int c = (n_top > 0 && n_left > 0) ? (int)top[-1] : (n_top > 0 ? (int)top[0] : (n_left > 0 ? (int)left[0] : base));
             A[-1] = (uint16_t)c; L[-1] = (uint16_t)c;
@@ -141,14 +154,14 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
         };
 #pragma unroll
         for (int t = 0; t < 3; t++) {
-            const int i = lane + 64 * t;
+            const int i = lane + LPB * t;
             va[t] = (sa && i >= 1 && i < na) ? taps(A - ab_le, i, na, sa) : -1;
             vl[t] = (sl && i >= 1 && i < nl) ? taps(L - ab_le, i, nl, sl) : -1;
         }
         wave_lds_fence();
 #pragma unroll
         for (int t = 0; t < 3; t++) {
-            const int i = lane + 64 * t;
+            const int i = lane + LPB * t;
             if (va[t] >= 0) A[i - ab_le] = (uint16_t)va[t];
             if (vl[t] >= 0) L[i - ab_le] = (uint16_t)vl[t];
         }
@@ -159,24 +172,31 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
     const int up_l = (filt && need_left) ? bip_use_upsample(h, w, p_angle - 180, ft) : 0;
     {
         const int sza = w + (need_right ? h : 0), szl = h + (need_bottom ? w : 0);                 // <= 16 when up-sampling
-        int ia[4] = {0, 0, 0, 0}, il[4] = {0, 0, 0, 0};
+        int ia[2][4], il[2][4];                                 // two rounds of LPB lanes: sz <= 16 <= 2 * LPB wherever the edge is up-sampled
         auto in_at = [](const uint16_t* p, int k, int sz) { return (int)p[k < 2 ? -1 : (k < sz + 2 ? k - 2 : sz - 1)]; };
-        if (up_a && lane < sza)
 #pragma unroll
-            for (int k = 0; k < 4; k++) ia[k] = in_at(A, lane + k, sza);
-        if (up_l && lane < szl)
+        for (int t = 0; t < 2; t++) {
+            const int i = lane + LPB * t;
 #pragma unroll
-            for (int k = 0; k < 4; k++) il[k] = in_at(L, lane + k, szl);
-        wave_lds_fence();
-        if (up_a && lane < sza) {
-            if (lane == 0) A[-2] = (uint16_t)ia[0];
-            A[2 * lane - 1] = (uint16_t)min(max((-ia[0] + 9 * ia[1] + 9 * ia[2] - ia[3] + 8) >> 4, 0), maxv);
-            A[2 * lane] = (uint16_t)ia[2];
+            for (int k = 0; k < 4; k++) {
+                ia[t][k] = (up_a && i < sza) ? in_at(A, i + k, sza) : 0;
+                il[t][k] = (up_l && i < szl) ? in_at(L, i + k, szl) : 0;
+            }
         }
-        if (up_l && lane < szl) {
-            if (lane == 0) L[-2] = (uint16_t)il[0];
-            L[2 * lane - 1] = (uint16_t)min(max((-il[0] + 9 * il[1] + 9 * il[2] - il[3] + 8) >> 4, 0), maxv);
-            L[2 * lane] = (uint16_t)il[2];
+        wave_lds_fence();
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int i = lane + LPB * t;
+            if (up_a && i < sza) {
+                if (i == 0) A[-2] = (uint16_t)ia[t][0];
+                A[2 * i - 1] = (uint16_t)min(max((-ia[t][0] + 9 * ia[t][1] + 9 * ia[t][2] - ia[t][3] + 8) >> 4, 0), maxv);
+                A[2 * i] = (uint16_t)ia[t][2];
+            }
+            if (up_l && i < szl) {
+                if (i == 0) L[-2] = (uint16_t)il[t][0];
+                L[2 * i - 1] = (uint16_t)min(max((-il[t][0] + 9 * il[t][1] + 9 * il[t][2] - il[t][3] + 8) >> 4, 0), maxv);
+                L[2 * i] = (uint16_t)il[t][2];
+            }
         }
     }
     wave_lds_fence();
@@ -196,8 +216,8 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
     if (kind == IM_DC || kind == IM_DC_TOP || kind == IM_DC_LEFT) {
         const int na = kind != IM_DC_LEFT ? w : 0, nl = kind != IM_DC_TOP ? h : 0;
         int sum = 0;
-        for (int i = lane; i < na + nl; i += 64) sum += i < na ? (int)A[i] : (int)L[i - na];
-        for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+        for (int i = lane; i < na + nl; i += LPB) sum += i < na ? (int)A[i] : (int)L[i - na];
+        for (int m = LPB >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
         dc = (sum + ((na + nl) >> 1)) / (na + nl);
     }
     const size_t boff = dst_offsets ? (size_t)dst_offsets[b] : (size_t)b * dst_block_pitch;
@@ -205,7 +225,7 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
     const int wq = w >> 2, items = wq * h;
     const int wq_shift = __builtin_ctz((uint32_t)wq);
     const int bl_s = (int)L[h - 1], tr_s = (int)A[w - 1], tl_s = (int)A[-1];
-    for (int q = lane; q < items; q += 64) {
+    for (int q = lane; q < items; q += LPB) {
         const int r = q >> wq_shift, c0 = (q & (wq - 1)) << 2;
         int px[4];
 #pragma unroll

@@ -271,15 +271,17 @@ extern "C" int svt_hip_build_intra_predictors_batch(void* d_dst, int32_t dst_str
     if (neigh_pitch < 1 + 2 * (w > h ? w : h)) return set_err(SVT_HIP_ERR_INVALID, "neigh_pitch %d < %d", neigh_pitch, 1 + 2 * (w > h ? w : h));
     if (dst_stride < w) return set_err(SVT_HIP_ERR_INVALID, "dst_stride %d < width %d", dst_stride, w);
     if (!d_dst_offsets && dst_block_pitch == 0) return set_err(SVT_HIP_ERR_INVALID, "dst_block_pitch 0 without offsets");
-    const size_t grid = (nblocks + BIP_WAVES - 1) / BIP_WAVES;
+    const size_t per_wg = (size_t)BIP_WAVES * (64 / bip_lanes_per_block(w, h));       // blocks per workgroup
+    const size_t grid = (nblocks + per_wg - 1) / per_wg;
     if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
+    const size_t lds = per_wg * 2 * (size_t)bip_edge_len(w, h) * sizeof(uint16_t);
     hipStream_t s = (hipStream_t)stream;
     if (is_16bit)
-        hipLaunchKernelGGL(bip_kernel<uint16_t>, dim3((uint32_t)grid), dim3(64 * BIP_WAVES), 0, s, (uint16_t*)d_dst, dst_stride, dst_block_pitch,
+        hipLaunchKernelGGL(bip_kernel<uint16_t>, dim3((uint32_t)grid), dim3(64 * BIP_WAVES), lds, s, (uint16_t*)d_dst, dst_stride, dst_block_pitch,
                            d_dst_offsets, (const uint16_t*)d_top_neigh, (const uint16_t*)d_left_neigh, neigh_pitch, (const BipBlk*)d_blocks, w, h,
                            bd, (uint32_t)nblocks);
     else
-        hipLaunchKernelGGL(bip_kernel<uint8_t>, dim3((uint32_t)grid), dim3(64 * BIP_WAVES), 0, s, (uint8_t*)d_dst, dst_stride, dst_block_pitch,
+        hipLaunchKernelGGL(bip_kernel<uint8_t>, dim3((uint32_t)grid), dim3(64 * BIP_WAVES), lds, s, (uint8_t*)d_dst, dst_stride, dst_block_pitch,
                            d_dst_offsets, (const uint8_t*)d_top_neigh, (const uint8_t*)d_left_neigh, neigh_pitch, (const BipBlk*)d_blocks, w, h,
                            bd, (uint32_t)nblocks);
     return launch_status("build_intra_predictors");

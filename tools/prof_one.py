@@ -49,6 +49,15 @@ elif name.startswith("enc"):          # enc32 / enc64 / enc16 / enc8: fused enco
     pred = (src.to(torch.int16) + torch.randint(-20, 21, (n, S, S), dtype=torch.int16, device=dev)).clamp(0, 255).to(torch.uint8)
     iscan = torch.from_numpy(pkg.tables.scan_tables(s_, 0)[1]).to(dev)
     fn = lambda: dsp.encode_recon(src, pred, s_, 0, qrow, iscan, keep_coeff=False)
+elif name == "bip":                  # build_intra_predictors glue, 16x16, mixed modes (as tools/bench_kernels.py)
+    n = 1 << 20
+    top = torch.randint(0, 256, (n, 48), dtype=torch.uint8, device=dev); left = torch.randint(0, 256, (n, 48), dtype=torch.uint8, device=dev)
+    blk = torch.zeros((n, 8), dtype=torch.uint8, device=dev)
+    blk[:, 0] = torch.arange(n, device=dev) % 13
+    blk[:, 1] = ((torch.arange(n, device=dev) // 13) % 7 - 3).to(torch.int8).view(torch.uint8) * ((blk[:, 0] >= 1) & (blk[:, 0] <= 8)).to(torch.uint8)
+    blk[:, 4] = 16; blk[:, 5] = 16; blk[:, 6] = 16; blk[:, 7] = 16
+    out = torch.empty((n, 16, 16), dtype=torch.uint8, device=dev)
+    fn = lambda: dsp.build_intra_predictors(top, left, blk, 2, dst=out, dst_stride=16)
 else:
     raise SystemExit("unknown " + name)
 for _ in range(5): fn()
