@@ -126,7 +126,69 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_intra_neighbor_px.argtypes = [c_void_p, c_void_p]
     L.svt_hip_intra_has_top_right.argtypes = [c_int] * 12
     L.svt_hip_intra_has_bottom_left.argtypes = [c_int] * 12
+    L.svt_hip_y4m_parse_header.argtypes = [ctypes.c_char_p, c_void_p]
+    L.svt_hip_y4m_frame_bytes.argtypes = [c_void_p]
+    L.svt_hip_y4m_frame_bytes.restype = c_size_t
+    L.svt_hip_y4m_open.argtypes = [ctypes.c_char_p, c_void_p, c_void_p]
+    L.svt_hip_y4m_read_frame.argtypes = [c_void_p, c_void_p, c_size_t]
+    L.svt_hip_y4m_close.argtypes = [c_void_p]
+    L.svt_hip_picture_import.argtypes = [c_void_p, c_uint32, c_uint32, c_int, c_int, c_int, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p,
+                                         c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]
+    L.svt_hip_picture_pad.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_void_p]
+    L.svt_hip_picture_decimate.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_uint32,
+                                           c_uint32, c_uint32, c_void_p]
     return L
+
+
+class Y4mInfo(ctypes.Structure):
+    """svt_hip_y4m_info: what read_y4m_header (Source/App/EncApp/EbAppInputy4m.c:35) takes from the header line"""
+    _fields_ = [("width", c_uint32), ("height", c_uint32), ("fr_n", c_uint32), ("fr_d", c_uint32), ("bit_depth", c_uint32),
+                ("interlaced", c_uint32), ("chroma", ctypes.c_char * 8), ("scan_type", ctypes.c_char)]
+
+
+def y4m_parse_header(lib, line):
+    """HOST: the header line that follows the "YUV4MPEG2" signature -> Y4mInfo, or SvtHipError where the reference's application
+    rejects the file (svt_hip_y4m_parse_header; needs no device)"""
+    info = Y4mInfo()
+    rc = lib.svt_hip_y4m_parse_header(line if isinstance(line, bytes) else line.encode(), ctypes.addressof(info))
+    if rc != 0:
+        raise SvtHipError(f"svt_hip_y4m_parse_header: {lib.svt_hip_last_error().decode()}")
+    return info
+
+
+class Y4mReader:
+    """HOST: a y4m file through svt_hip_y4m_open / _read_frame / _close (check_if_y4m, read_y4m_header, read_y4m_frame_delimiter).
+    read_into(buffer) fills any writable buffer object (numpy array, pinned torch tensor via .numpy()) with the next frame's planes
+    as the file holds them (Y, Cb, Cr back to back) and returns False at the end of the file."""
+
+    def __init__(self, lib, path):
+        self.lib = lib
+        self.info = Y4mInfo()
+        h = c_void_p()
+        rc = lib.svt_hip_y4m_open(os.fsencode(path), ctypes.byref(h), ctypes.addressof(self.info))
+        if rc != 0:
+            raise SvtHipError(f"svt_hip_y4m_open: {lib.svt_hip_last_error().decode()}")
+        self.h = h
+        self.frame_bytes = lib.svt_hip_y4m_frame_bytes(ctypes.addressof(self.info))
+
+    def read_into(self, arr):
+        import numpy as np
+        a = np.asarray(arr)
+        rc = self.lib.svt_hip_y4m_read_frame(self.h, a.ctypes.data, a.nbytes)
+        if rc < 0:
+            raise SvtHipError(f"svt_hip_y4m_read_frame: {self.lib.svt_hip_last_error().decode()}")
+        return rc == 1
+
+    def close(self):
+        if self.h:
+            self.lib.svt_hip_y4m_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def _np16(a):
@@ -593,6 +655,34 @@ class SvtHipDsp:
                                                      ctypes.byref(params), self._p(best), self._p(mv), n, self._stream()),
                     "svt_hip_hme_level_batch")
         return best, mv
+
+    # ---- picture input ----
+    def picture_import(self, frame, width, height, planes, origin_x, origin_y, pad_right=0, pad_bottom=0, ss_x=1, ss_y=1):
+        """frame: 1-D uint8 / int16 (uint16 values) device tensor holding Y, Cb, Cr back to back as a y4m frame does; planes: the three
+        padded plane buffers (2-D tensors [rows, stride]; chroma may be None).  One launch: copy + right / bottom extension + borders
+        (svt_hip_picture_import)."""
+        t = self.torch
+        is16 = frame.dtype != t.uint8
+        y, cb, cr = planes
+        self._check(self.lib.svt_hip_picture_import(self._p(frame), width, height, ss_x, ss_y, int(is16), self._p(y), y.stride(0),
+                                                    self._p(cb) if cb is not None else None, cb.stride(0) if cb is not None else 0,
+                                                    self._p(cr) if cr is not None else None, cr.stride(0) if cr is not None else 0,
+                                                    origin_x, origin_y, pad_right, pad_bottom, self._stream()), "svt_hip_picture_import")
+
+    def picture_pad(self, buf, width, height, pad_w, pad_h):
+        """generate_padding{,16_bit} in place on a 2-D buffer tensor [height + 2 pad_h, stride] (svt_hip_picture_pad)"""
+        self._check(self.lib.svt_hip_picture_pad(self._p(buf), buf.stride(0), width, height, pad_w, pad_h, int(buf.dtype != self.torch.uint8),
+                                                 self._stream()), "svt_hip_picture_pad")
+
+    def picture_decimate(self, luma_origin, luma_stride, width, height, quarter=None, q_origin=(0, 0), sixteenth=None, s_origin=(0, 0)):
+        """DecimateInputPicture: luma_origin = tensor view whose data_ptr() is the luma picture's origin sample; quarter / sixteenth:
+        2-D padded buffers or None (svt_hip_picture_decimate)"""
+        self._check(self.lib.svt_hip_picture_decimate(self._p(luma_origin), luma_stride, width, height,
+                                                      self._p(quarter) if quarter is not None else None,
+                                                      quarter.stride(0) if quarter is not None else 0, q_origin[0], q_origin[1],
+                                                      self._p(sixteenth) if sixteenth is not None else None,
+                                                      sixteenth.stride(0) if sixteenth is not None else 0, s_origin[0], s_origin[1],
+                                                      self._stream()), "svt_hip_picture_decimate")
 
     class IntraPos(ctypes.Structure):
         """svt_hip_intra_pos: where one prediction block sits (the arguments of av1_predict_intra_block, EbIntraPrediction.c:4078)"""

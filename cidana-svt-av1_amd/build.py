@@ -13,7 +13,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libsvt_hip_dsp.so")
-SOURCES = ["csrc/svt_hip_core.hip", "csrc/svt_hip_txfm.hip", "csrc/svt_hip_pixel.hip", "csrc/svt_hip_intra.hip", "csrc/host_tables.cpp"]
+SOURCES = ["csrc/svt_hip_core.hip", "csrc/svt_hip_txfm.hip", "csrc/svt_hip_pixel.hip", "csrc/svt_hip_intra.hip", "csrc/svt_hip_picture.hip", "csrc/host_tables.cpp"]
 OBJ_DIR = os.path.join(PKG, "build_obj")            # git-ignored; objects do not travel, the linked .so does
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fwrapv", "-Wall", "-Wno-unused-function"]
 HOST_FLAGS = ["-x", "c++", "-O2", "-fPIC", "-std=c++17", "-Wall"]        # host-only units: no device pass

@@ -1,0 +1,221 @@
+// svt_hip_picture.hip — picture input: y4m header / frame reader (host) and the device-side layout of a frame in
+// the encoder's padded picture buffers, border generation and the HME decimations (kernel_picture.h).
+#include "host_common.h"
+#include "kernel_picture.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace svtdev;
+using namespace svthost;
+
+// ---- y4m (Source/App/EncApp/EbAppInputy4m.c) -------------------------------------------------------------------------
+namespace {
+// copyUntilCharacterOrNewLine (:13-33) as the application's build behaves: EB_STRNCPY(dst, src, count) bounds the copy with
+// sizeof(dst) of a char POINTER, so a token of 8 or more characters (or an empty one) is cleared by strncpy_ss
+// (EbAppFifo.c:160-283) and compares equal to nothing.  Kept, so that this reader accepts and rejects exactly the files the
+// reference's application does ("C420mpeg2" / "C420paldv" are rejected there).
+const char* y4m_token(const char* src, char* dst, size_t cap, char chr) {
+    const char* s0 = src;
+    size_t n = 0;
+    while (*src != chr && *src != '\n' && *src != '\0') { src++; n++; }
+    if (n == 0 || n >= 8 || n + 1 > cap) dst[0] = '\0';
+    else { memcpy(dst, s0, n); dst[n] = '\0'; }
+    return src;
+}
+struct Y4mFmt { const char* name; const char* chroma; uint32_t bd; };
+const Y4mFmt kY4mFmt[] = {      // the 'C' tokens of read_y4m_header (:93-190)
+    {"420mpeg2", "420", 8}, {"420paldv", "420", 8}, {"420jpeg", "420", 8}, {"420p16", "420", 16}, {"422p16", "422", 16}, {"444p16", "444", 16},
+    {"420p14", "420", 14}, {"422p14", "422", 14}, {"444p14", "444", 14}, {"420p12", "420", 12}, {"422p12", "422", 12}, {"444p12", "444", 12},
+    {"420p10", "420", 10}, {"422p10", "422", 10}, {"444p10", "444", 10}, {"420p9", "420", 9}, {"422p9", "422", 9}, {"444p9", "444", 9},
+    {"420", "420", 8}, {"411", "411", 8}, {"422", "422", 8}, {"444", "444", 8},
+    {"mono16", "400", 16}, {"mono12", "400", 12}, {"mono10", "400", 10}, {"mono9", "400", 9}, {"mono", "400", 8}};
+}  // namespace
+
+struct svt_hip_y4m {
+    FILE* f;
+    svt_hip_y4m_info info;
+    size_t frame_bytes;
+};
+
+extern "C" int svt_hip_y4m_parse_header(const char* line, svt_hip_y4m_info* out) {
+    if (!line || !out) return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    uint32_t bitdepth = 8, width = 0, height = 0, fr_n = 0, fr_d = 0;
+    char chroma[8] = "420", scan = 'p', tok[96];
+    uint32_t interlaced = 1;                              // read_y4m_header starts from interlaced = EB_TRUE (:43)
+    for (const char* p = line; *p != '\0'; p++) {
+        if (*p == 0x20) continue;
+        switch (*p++) {
+        case 'W': { char* e; width = (uint32_t)strtol(p, &e, 10); p = e; } break;
+        case 'H': { char* e; height = (uint32_t)strtol(p, &e, 10); p = e; } break;
+        case 'I':
+            switch (*p++) {
+            case 'p': interlaced = 0; scan = 'p'; break;
+            case 't': interlaced = 1; scan = 't'; break;
+            case 'b': interlaced = 1; scan = 'b'; break;
+            default: return set_err(SVT_HIP_ERR_INVALID, "interlace type not supported");
+            }
+            break;
+        case 'C': {
+            p = y4m_token(p, tok, sizeof(tok), 0x20);
+            const Y4mFmt* f = nullptr;
+            for (const Y4mFmt& c : kY4mFmt)
+                if (strcmp(c.name, tok) == 0) { f = &c; break; }
+            if (!f) return set_err(SVT_HIP_ERR_INVALID, "chroma format not supported");
+            strcpy(chroma, f->chroma);
+            bitdepth = f->bd;
+        } break;
+        case 'F':
+            p = y4m_token(p, tok, sizeof(tok), ':');
+            fr_n = (uint32_t)strtol(tok, nullptr, 10);
+            if (*p != '\0') p++;
+            p = y4m_token(p, tok, sizeof(tok), 0x20);
+            fr_d = (uint32_t)strtol(tok, nullptr, 10);
+            break;
+        case 'A':
+            p = y4m_token(p, tok, sizeof(tok), ':');
+            if (*p != '\0') p++;
+            p = y4m_token(p, tok, sizeof(tok), 0x20);
+            break;
+        default: break;
+        }
+        if (*p == '\0') break;
+    }
+    if (width == 0) return set_err(SVT_HIP_ERR_INVALID, "width not found in y4m header");
+    if (height == 0) return set_err(SVT_HIP_ERR_INVALID, "height not found in y4m header");
+    if (fr_n == 0 || fr_d == 0) return set_err(SVT_HIP_ERR_INVALID, "frame rate not found in y4m header");
+    memset(out, 0, sizeof(*out));
+    out->width = width; out->height = height; out->fr_n = fr_n; out->fr_d = fr_d;
+    out->bit_depth = bitdepth; out->interlaced = interlaced; out->scan_type = scan;
+    strcpy(out->chroma, chroma);
+    return SVT_HIP_OK;
+}
+
+// bytes of one frame's planes in the file: 8-bit samples are bytes, deeper ones 16-bit little endian
+extern "C" size_t svt_hip_y4m_frame_bytes(const svt_hip_y4m_info* info) {
+    if (!info) return 0;
+    const size_t es = info->bit_depth > 8 ? 2 : 1, luma = (size_t)info->width * info->height;
+    size_t chroma = 0;
+    if (!strcmp(info->chroma, "420")) chroma = 2 * ((size_t)((info->width + 1) >> 1) * ((info->height + 1) >> 1));
+    else if (!strcmp(info->chroma, "422")) chroma = 2 * ((size_t)((info->width + 1) >> 1) * info->height);
+    else if (!strcmp(info->chroma, "444")) chroma = 2 * luma;
+    else if (!strcmp(info->chroma, "411")) chroma = 2 * ((size_t)((info->width + 3) >> 2) * info->height);
+    return (luma + chroma) * es;
+}
+
+// check_if_y4m (:269-290) + read_y4m_header: SVT_HIP_ERR_INVALID for a file that does not start with "YUV4MPEG2" or whose
+// header the reference rejects
+extern "C" int svt_hip_y4m_open(const char* path, svt_hip_y4m** out, svt_hip_y4m_info* info) {
+    if (!path || !out) return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) return set_err(SVT_HIP_ERR_INVALID, "cannot open %s", path);
+    char sig[10] = {0}, line[80];                        // YFM_HEADER_MAX = 80 (:7): the header line is at most 79 characters
+    if (fread(sig, 9, 1, f) != 1 || strcmp(sig, "YUV4MPEG2") != 0) { fclose(f); return set_err(SVT_HIP_ERR_INVALID, "%s is not a YUV4MPEG2 file", path); }
+    if (!fgets(line, sizeof(line), f)) { fclose(f); return set_err(SVT_HIP_ERR_INVALID, "%s: no header line", path); }
+    svt_hip_y4m_info inf;
+    if (int rc = svt_hip_y4m_parse_header(line, &inf)) { fclose(f); return rc; }
+    svt_hip_y4m* h = new svt_hip_y4m{f, inf, svt_hip_y4m_frame_bytes(&inf)};
+    if (info) *info = inf;
+    *out = h;
+    return SVT_HIP_OK;
+}
+
+// read_y4m_frame_delimiter (:247-266) + the frame's planes.  1 = a frame was read, 0 = end of file, < 0 = error
+extern "C" int svt_hip_y4m_read_frame(svt_hip_y4m* h, void* host_dst, size_t capacity) {
+    if (!h || !host_dst) return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    if (capacity < h->frame_bytes) return set_err(SVT_HIP_ERR_INVALID, "buffer of %zu bytes for a frame of %zu", capacity, h->frame_bytes);
+    char d[10];
+    if (!fgets(d, sizeof(d), h->f)) return 0;
+    if (strcmp(d, "FRAME\n") != 0) return set_err(SVT_HIP_ERR_INVALID, "Failed to read proper y4m frame delimeter. Read broken.");
+    const size_t got = fread(host_dst, 1, h->frame_bytes, h->f);
+    if (got != h->frame_bytes) return got == 0 ? 0 : set_err(SVT_HIP_ERR_INVALID, "truncated frame: %zu of %zu bytes", got, h->frame_bytes);
+    return 1;
+}
+extern "C" void svt_hip_y4m_close(svt_hip_y4m* h) {
+    if (!h) return;
+    if (h->f) fclose(h->f);
+    delete h;
+}
+
+// ---- device side ---------------------------------------------------------------------------------------------------
+extern "C" int svt_hip_picture_import(const void* d_frame, uint32_t width, uint32_t height, int ss_x, int ss_y, int is_16bit,
+                                      void* d_y, uint32_t stride_y, void* d_cb, uint32_t stride_cb, void* d_cr, uint32_t stride_cr,
+                                      uint32_t origin_x, uint32_t origin_y, uint32_t pad_right, uint32_t pad_bottom, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (!d_frame || !d_y) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (width == 0 || height == 0 || width > 16384 || height > 16384) return set_err(SVT_HIP_ERR_INVALID, "picture %ux%u", width, height);
+    if ((ss_x | ss_y) & ~1) return set_err(SVT_HIP_ERR_INVALID, "subsampling %d,%d", ss_x, ss_y);
+    if ((d_cb == nullptr) != (d_cr == nullptr)) return set_err(SVT_HIP_ERR_INVALID, "one chroma buffer without the other");
+    PicImport d;
+    memset(&d, 0, sizeof(d));
+    d.nplanes = d_cb ? 3 : 1;
+    const uint32_t cw = (width + (uint32_t)ss_x) >> ss_x, ch = (height + (uint32_t)ss_y) >> ss_y;
+    uint32_t row = 0, max_w = 0;
+    for (uint32_t i = 0; i < d.nplanes; i++) {
+        PicPlane& p = d.p[i];
+        const int sx = i ? ss_x : 0, sy = i ? ss_y : 0;
+        p.buf = i == 0 ? d_y : (i == 1 ? d_cb : d_cr);
+        p.stride = i == 0 ? stride_y : (i == 1 ? stride_cb : stride_cr);
+        p.w = i ? cw : width; p.h = i ? ch : height;
+        p.ox = origin_x >> sx; p.oy = origin_y >> sy;
+        // PadPictureToMultipleOfMinCuSizeDimensions (EbPictureAnalysisProcess.c:4818): pad_right >> subsampling_x for chroma
+        p.full_w = p.w + (pad_right >> sx) + 2 * p.ox;
+        p.full_h = p.h + (pad_bottom >> sy) + 2 * p.oy;
+        if (p.stride < p.full_w) return set_err(SVT_HIP_ERR_INVALID, "plane %u: stride %u < %u", i, p.stride, p.full_w);
+        p.src_off = i == 0 ? 0 : width * height + (i - 1) * cw * ch;
+        p.row0 = row;
+        row += p.full_h;
+        if (p.full_w > max_w) max_w = p.full_w;
+    }
+    d.rows_total = row;
+    if (row > 65535) return set_err(SVT_HIP_ERR_INVALID, "%u buffer rows in one launch", row);
+    const uint32_t npl = is_16bit ? 8 : 16, gx = ((max_w + npl - 1) / npl + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    if (is_16bit) hipLaunchKernelGGL(picture_import_kernel<uint16_t>, dim3(gx, row), dim3(256), 0, s, (const uint16_t*)d_frame, d);
+    else hipLaunchKernelGGL(picture_import_kernel<uint8_t>, dim3(gx, row), dim3(256), 0, s, (const uint8_t*)d_frame, d);
+    return launch_status("picture_import");
+}
+
+extern "C" int svt_hip_picture_pad(void* d_buf, uint32_t stride, uint32_t width, uint32_t height, uint32_t pad_w, uint32_t pad_h,
+                                   int is_16bit, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (!d_buf) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (width == 0 || height == 0) return set_err(SVT_HIP_ERR_INVALID, "picture %ux%u", width, height);
+    if (stride < width + 2 * pad_w) return set_err(SVT_HIP_ERR_INVALID, "stride %u < %u", stride, width + 2 * pad_w);
+    const uint32_t rows = height + 2 * pad_h;
+    if (rows > 65535) return set_err(SVT_HIP_ERR_INVALID, "%u buffer rows in one launch", rows);
+    if (pad_w == 0 && pad_h == 0) return SVT_HIP_OK;
+    const uint32_t npl = is_16bit ? 8 : 16, gx = ((width + 2 * pad_w + npl - 1) / npl + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    if (is_16bit) hipLaunchKernelGGL(picture_pad_kernel<uint16_t>, dim3(gx, rows), dim3(256), 0, s, (uint16_t*)d_buf, stride, (int)width, (int)height, (int)pad_w, (int)pad_h);
+    else hipLaunchKernelGGL(picture_pad_kernel<uint8_t>, dim3(gx, rows), dim3(256), 0, s, (uint8_t*)d_buf, stride, (int)width, (int)height, (int)pad_w, (int)pad_h);
+    return launch_status("picture_pad");
+}
+
+extern "C" int svt_hip_picture_decimate(const uint8_t* d_luma, uint32_t luma_stride, uint32_t width, uint32_t height,
+                                        uint8_t* d_quarter, uint32_t q_stride, uint32_t q_origin_x, uint32_t q_origin_y,
+                                        uint8_t* d_sixteenth, uint32_t s_stride, uint32_t s_origin_x, uint32_t s_origin_y, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (!d_luma || (!d_quarter && !d_sixteenth)) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (width == 0 || height == 0) return set_err(SVT_HIP_ERR_INVALID, "picture %ux%u", width, height);
+    PicDecim q, x;
+    memset(&q, 0, sizeof(q)); memset(&x, 0, sizeof(x));
+    uint32_t row = 0, max_w = 0;
+    if (d_quarter) {
+        q = PicDecim{d_quarter, q_stride, (width + 1) / 2, (height + 1) / 2, q_origin_x, q_origin_y, 0};
+        if (q_stride < q.w + 2 * q.ox) return set_err(SVT_HIP_ERR_INVALID, "quarter stride %u < %u", q_stride, q.w + 2 * q.ox);
+        row += q.h + 2 * q.oy; max_w = q.w + 2 * q.ox;
+    }
+    if (d_sixteenth) {
+        x = PicDecim{d_sixteenth, s_stride, (width + 3) / 4, (height + 3) / 4, s_origin_x, s_origin_y, row};
+        if (s_stride < x.w + 2 * x.ox) return set_err(SVT_HIP_ERR_INVALID, "sixteenth stride %u < %u", s_stride, x.w + 2 * x.ox);
+        row += x.h + 2 * x.oy;
+        if (x.w + 2 * x.ox > max_w) max_w = x.w + 2 * x.ox;
+    }
+    if (row > 65535) return set_err(SVT_HIP_ERR_INVALID, "%u buffer rows in one launch", row);
+    // without a quarter picture the sixteenth's rows start at 0 and the kernel's "row >= s.row0" picks it for every row
+    hipLaunchKernelGGL(picture_decimate_kernel, dim3(((max_w + 15) / 16 + 255) / 256, row), dim3(256), 0, (hipStream_t)stream, d_luma, luma_stride,
+                       (int)width, q, x);
+    return launch_status("picture_decimate");
+}

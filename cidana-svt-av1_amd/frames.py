@@ -99,3 +99,82 @@ class FramePass:
             d[3] += (g["recon"].to(t.int64) & 0xffff).sum()
         d[2] %= DIGEST_MOD
         return d
+
+
+class PictureInput:
+    """The picture-input side: frames of a y4m file -> the encoder's padded plane buffers in HBM, plus the 1/4 and
+    1/16 luma pictures the hierarchical motion estimation searches.  Reference flow: ReadInputFrames (EbAppProcessCmd.c:765-900) ->
+    CopyApiFromApp into the input EbPictureBufferDesc -> PadPictureToMultipleOfMinCuSizeDimensions / ...OfLcuDimensions and
+    DecimateInputPicture (EbPictureAnalysisProcess.c:4818-4958).
+
+    MI355X form: two pinned host staging buffers and two device staging buffers; frame k + 1 is read from the file and copied to
+    the device on a copy stream while frame k's import / decimation kernels (and whatever the caller enqueues after them) run on
+    the compute stream.  A 10-bit picture is kept as 16-bit samples (what the reference's own 16-bit DSP functions take after it
+    packs its 8-bit + 2-bit planes), not as the split planes.  geometry: origin = border on every side (the reference's
+    left / top padding), pad_right / pad_bottom = extension to a multiple of the minimum CU size (8)."""
+
+    def __init__(self, dsp, pkg, path, origin=(64 + 4, 64 + 4), min_cu=8, with_decimation=True, device="cuda:0"):
+        import torch
+        self.dsp, self.t = dsp, torch
+        self.rd = pkg.Y4mReader(dsp.lib, path)
+        i = self.rd.info
+        if i.chroma != b"420" or i.bit_depth not in (8, 10):
+            self.rd.close()
+            raise pkg.SvtHipError(f"PictureInput handles 4:2:0 at 8 or 10 bits (file: {i.chroma.decode()} / {i.bit_depth})")
+        self.w, self.h, self.is16 = i.width, i.height, i.bit_depth > 8
+        self.pad_right = (-self.w) % min_cu
+        self.pad_bottom = (-self.h) % min_cu
+        self.ox, self.oy = origin
+        self.W, self.H = self.w + self.pad_right, self.h + self.pad_bottom
+        dt = torch.int16 if self.is16 else torch.uint8
+        nsamp = self.rd.frame_bytes // (2 if self.is16 else 1)
+        self.host = [torch.empty(nsamp, dtype=dt).pin_memory() for _ in range(2)]
+        self.stage = [torch.empty(nsamp, dtype=dt, device=device) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.copied = [torch.cuda.Event() for _ in range(2)]
+        self.consumed = [torch.cuda.Event() for _ in range(2)]
+
+        def plane(w, h, ox, oy):
+            stride = (w + 2 * ox + 63) & ~63
+            return torch.empty((h + 2 * oy, stride), dtype=dt, device=device)
+        self.planes = (plane(self.W, self.H, self.ox, self.oy), plane(self.W >> 1, self.H >> 1, self.ox >> 1, self.oy >> 1),
+                       plane(self.W >> 1, self.H >> 1, self.ox >> 1, self.oy >> 1))
+        self.quarter = self.sixteenth = None
+        if with_decimation and not self.is16:
+            self.q_origin = (self.ox >> 1, self.oy >> 1)
+            self.s_origin = (self.ox >> 2, self.oy >> 2)
+            qw, qh, sw, sh = (self.W + 1) // 2, (self.H + 1) // 2, (self.W + 3) // 4, (self.H + 3) // 4
+            self.quarter = torch.empty((qh + 2 * self.q_origin[1], (qw + 2 * self.q_origin[0] + 63) & ~63), dtype=torch.uint8, device=device)
+            self.sixteenth = torch.empty((sh + 2 * self.s_origin[1], (sw + 2 * self.s_origin[0] + 63) & ~63), dtype=torch.uint8, device=device)
+        self.slot = 0
+        self.pending = self._fetch(0)
+
+    def _fetch(self, slot):
+        """read the next frame into pinned buffer `slot` and start its copy to the device; False at the end of the file"""
+        self.consumed[slot].synchronize()                 # the import kernel that read this device buffer has finished
+        if not self.rd.read_into(self.host[slot].numpy()):
+            return False
+        with self.t.cuda.stream(self.copy_stream):
+            self.stage[slot].copy_(self.host[slot], non_blocking=True)
+            self.copied[slot].record(self.copy_stream)
+        return True
+
+    def next(self):
+        """-> (y, cb, cr) padded planes of the next frame (enqueued on the current stream), or None at the end of the file.  The
+        planes are overwritten by the following call."""
+        if not self.pending:
+            return None
+        slot = self.slot
+        cur = self.t.cuda.current_stream()
+        cur.wait_event(self.copied[slot])
+        self.dsp.picture_import(self.stage[slot], self.w, self.h, self.planes, self.ox, self.oy, self.pad_right, self.pad_bottom)
+        self.consumed[slot].record(cur)
+        if self.quarter is not None:
+            y = self.planes[0]
+            self.dsp.picture_decimate(y[self.oy:, self.ox:], y.stride(0), self.W, self.H, self.quarter, self.q_origin, self.sixteenth, self.s_origin)
+        self.slot ^= 1
+        self.pending = self._fetch(self.slot)             # overlaps with the kernels just enqueued
+        return self.planes
+
+    def close(self):
+        self.rd.close()

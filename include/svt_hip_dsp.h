@@ -741,6 +741,41 @@ void svt_hip_cfl_predict_hbd(const int16_t *pred_buf_q3, uint16_t *pred, int32_t
 void svt_hip_av1_txb_init_levels(const svt_tran_low_t *const coeff, const int32_t width, const int32_t height,
                                  uint8_t *const levels);
 
+/* ---- picture input ("the y4m -> plane upload path") --------------------------------------------------
+ * Host: the reference application's y4m reader (Source/App/EncApp/EbAppInputy4m.c) - the same header tokens, the same
+ * accepted / rejected files (including its 7-character bound on the 'C' and 'F' tokens), "FRAME\n" delimiters. */
+typedef struct svt_hip_y4m_info {
+    uint32_t width, height, fr_n, fr_d, bit_depth, interlaced;
+    char chroma[8];                /* "420" "422" "444" "411" "400" */
+    char scan_type;                /* 'p' 't' 'b' */
+} svt_hip_y4m_info;
+typedef struct svt_hip_y4m svt_hip_y4m;
+/* read_y4m_header (:35-243) on the line that follows the "YUV4MPEG2" signature */
+int svt_hip_y4m_parse_header(const char *line, svt_hip_y4m_info *out);
+size_t svt_hip_y4m_frame_bytes(const svt_hip_y4m_info *info);
+/* check_if_y4m (:269) + read_y4m_header; read_y4m_frame_delimiter (:247) + the planes: 1 = frame read, 0 = end of file */
+int svt_hip_y4m_open(const char *path, svt_hip_y4m **out, svt_hip_y4m_info *info);
+int svt_hip_y4m_read_frame(svt_hip_y4m *h, void *host_dst, size_t capacity);
+void svt_hip_y4m_close(svt_hip_y4m *h);
+/* Device: a frame as the file holds it (d_frame: Y, Cb, Cr back to back, u8 or u16 samples, already in HBM) laid out in the
+ * encoder's padded plane buffers in ONE launch: the copy, pad_input_picture (EbMcp.c:273; right / bottom extension to the
+ * minimum CU size, PadPictureToMultipleOfMinCuSizeDimensions, EbPictureAnalysisProcess.c:4818) and generate_padding{,16_bit}
+ * (EbMcp.c:176-267; the borders of origin_x / origin_y samples).  d_y / d_cb / d_cr = first sample of each BUFFER (the picture
+ * origin is at (origin_x >> ss, origin_y >> ss)); strides in samples; d_cb = d_cr = NULL for luma only. */
+int svt_hip_picture_import(const void *d_frame, uint32_t width, uint32_t height, int ss_x, int ss_y, int is_16bit, void *d_y,
+                           uint32_t stride_y, void *d_cb, uint32_t stride_cb, void *d_cr, uint32_t stride_cr,
+                           uint32_t origin_x, uint32_t origin_y, uint32_t pad_right, uint32_t pad_bottom, void *stream);
+/* generate_padding / generate_padding16_bit in place (the reference also pads reconstructed reference pictures with it,
+ * EbEncDecProcess.c:1040-1100): d_buf = first sample of the buffer, picture at (pad_w, pad_h) */
+int svt_hip_picture_pad(void *d_buf, uint32_t stride, uint32_t width, uint32_t height, uint32_t pad_w, uint32_t pad_h,
+                        int is_16bit, void *stream);
+/* DecimateInputPicture (EbPictureAnalysisProcess.c:4907-4958): Decimation2D (:170) at step 2 (quarter) and 4 (sixteenth) of
+ * the luma picture at d_luma (its ORIGIN sample), each followed by generate_padding of the decimated buffer; either output may
+ * be NULL.  d_quarter / d_sixteenth = first sample of the buffer. */
+int svt_hip_picture_decimate(const uint8_t *d_luma, uint32_t luma_stride, uint32_t width, uint32_t height, uint8_t *d_quarter,
+                             uint32_t q_stride, uint32_t q_origin_x, uint32_t q_origin_y, uint8_t *d_sixteenth,
+                             uint32_t s_stride, uint32_t s_origin_x, uint32_t s_origin_y, void *stream);
+
 /* ---- dispatch registration ---------------------------------------------------------------------------------------
  * The library keeps a registry {reference slot name -> drop-in of the same signature} for every RTCD global of
  * aom_dsp_rtcd.h it implements (svt_hip_rtcd_slot_count() entries: the 19 av1_fwd_txfm2d_WxH, the 19

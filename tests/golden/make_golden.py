@@ -620,6 +620,65 @@ def gen_bip():
     np.savez_compressed(os.path.join(HERE, "bip.npz"), **d)
 
 
+def gen_picture():
+    """picture input (n4): the reference application's read_y4m_header on files, and the reference library's pad_input_picture ->
+    generate_padding{,16_bit} sequence and Decimation2D + generate_padding on small frames"""
+    import tempfile
+    from svtlibs import Y4M_HEADERS, write_y4m
+    rng = np.random.default_rng(4907)
+    d = {}
+    R.ref_y4m_header.restype = ctypes.c_long
+    hdr = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, (line, _) in enumerate(Y4M_HEADERS):
+            path = os.path.join(tmp, f"h{i}.y4m")
+            write_y4m(path, line, [(np.zeros(4, np.uint8),) * 3])
+            out = np.zeros(8, np.int32)
+            R.ref_y4m_header(path.encode(), ptr(out))
+            hdr.append(out.copy())
+    d["y4m_lines"] = np.array([l for l, _ in Y4M_HEADERS])
+    d["y4m_out"] = np.array(hdr)
+    cases = []
+    for k, (w, h, ox, oy, pr, pb, is16) in enumerate([(17, 9, 4, 3, 7, 7, 0), (40, 24, 16, 8, 0, 0, 0), (33, 31, 5, 5, 7, 1, 0), (64, 48, 68, 68, 0, 0, 0),
+                                                      (20, 12, 6, 2, 4, 4, 1), (35, 17, 8, 8, 5, 7, 1)]):
+        dt = np.uint16 if is16 else np.uint8
+        frame = rng.integers(0, 1 << (10 if is16 else 8), (h, w)).astype(dt)
+        W, H = w + pr, h + pb
+        stride = W + 2 * ox + 3
+        buf = np.full((H + 2 * oy, stride), 0x55, dt)
+        buf[oy:oy + h, ox:ox + w] = frame
+        if is16:
+            # the reference holds a 10-bit input picture as an 8-bit plane + a bit-increment plane (2 bits at the top of a byte) and
+            # runs pad_input_picture on each (EbPictureAnalysisProcess.c:4830-4876): done so here, then recombined into 16-bit samples
+            hi = np.ascontiguousarray((buf >> 2).astype(np.uint8)); lo = np.ascontiguousarray(((buf & 3) << 6).astype(np.uint8))
+            for pl in (hi, lo):
+                R.ref_pad_input_picture(ctypes.c_void_p(pl.ctypes.data + (oy * stride + ox)), stride, w, h, pr, pb)
+            buf[:] = (hi.astype(np.uint16) << 2) | (lo.astype(np.uint16) >> 6)
+        else:
+            R.ref_pad_input_picture(ctypes.c_void_p(buf.ctypes.data + (oy * stride + ox)), stride, w, h, pr, pb)
+        R.ref_generate_padding(ptr(buf), stride, W, H, ox, oy, is16)
+        d[f"pad{k}_prm"] = np.array([w, h, ox, oy, pr, pb, is16, stride], np.int32)
+        d[f"pad{k}_frame"] = frame
+        d[f"pad{k}_out"] = buf
+        cases.append(k)
+    d["pad_cases"] = np.array(cases, np.int32)
+    for k, (w, h, qo, so) in enumerate([(64, 32, 8, 4), (50, 22, 6, 3), (33, 19, 4, 4)]):
+        stride = w + 5
+        luma = rng.integers(0, 256, (h, stride)).astype(np.uint8)
+        outs = []
+        for step, o in ((2, qo), (4, so)):
+            dw, dh = (w + step - 1) // step, (h + step - 1) // step
+            ds = dw + 2 * o + 1
+            buf = np.full((dh + 2 * o, ds), 0x33, np.uint8)
+            R.ref_decimation_2d(ptr(luma), stride, w, h, ctypes.c_void_p(buf.ctypes.data + o * ds + o), ds, step)
+            R.ref_generate_padding(ptr(buf), ds, dw, dh, o, o, 0)
+            outs.append(buf)
+        d[f"dec{k}_prm"] = np.array([w, h, stride, qo, so], np.int32)
+        d[f"dec{k}_luma"] = luma; d[f"dec{k}_q"] = outs[0]; d[f"dec{k}_s"] = outs[1]
+    d["dec_cases"] = np.arange(3, dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "picture.npz"), **d)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                    # one family only: python make_golden.py cfl_levels
         globals()["gen_" + sys.argv[1]]()
@@ -635,6 +694,7 @@ if __name__ == "__main__":
     gen_pins()
     gen_hme()
     gen_bip()
+    gen_picture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

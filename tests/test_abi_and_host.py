@@ -279,3 +279,52 @@ def test_c_frame_host_compiles_and_fails_loudly_without_a_device(tmp_path):
         pytest.skip("a GPU is present: tests/test_gpu_frame_api.py runs it")
     pr = subprocess.run([exe, "128", "64", "100", "7"], capture_output=True, text=True)
     assert pr.returncode == 3, (pr.returncode, pr.stdout, pr.stderr)
+
+
+def test_y4m_reader_host_side_equals_oracle_and_reference_fixture(pkg, tmp_path):
+    """n4 host side (no device): svt_hip_y4m_parse_header accepts / rejects and parses as the oracle does (itself pinned to the
+    reference application, picture.npz), and svt_hip_y4m_open / _read_frame / _close return a written file's frames"""
+    import numpy as np
+    import svtlibs
+    lib = pkg.load_library()
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "picture.npz"))
+    for line, exp in zip(g["y4m_lines"].tolist(), g["y4m_out"].tolist()):
+        oi = svtlibs.Y4mInfo()
+        orc = O.svt_oracle_y4m_parse_header(line.encode(), ctypes.byref(oi))
+        if orc != 0:
+            with pytest.raises(pkg.SvtHipError):
+                pkg.y4m_parse_header(lib, line)
+            assert exp[1] != 0
+            continue
+        pi = pkg.y4m_parse_header(lib, line)
+        for f in ("width", "height", "fr_n", "fr_d", "bit_depth", "interlaced", "chroma", "scan_type"):
+            assert getattr(pi, f) == getattr(oi, f), (line, f)
+        assert [pi.width, pi.height, pi.fr_n, pi.fr_d, pi.bit_depth, pi.interlaced] == exp[2:8]
+    rng = np.random.default_rng(5)
+    for bd, token in ((8, "C420jpeg"), (10, "C420p10")):
+        w, h = 22, 10
+        dt = np.uint8 if bd == 8 else np.dtype("<u2")
+        frames = [(rng.integers(0, 1 << bd, (h, w)).astype(dt), rng.integers(0, 1 << bd, (h // 2, w // 2)).astype(dt),
+                   rng.integers(0, 1 << bd, (h // 2, w // 2)).astype(dt)) for _ in range(3)]
+        path = str(tmp_path / f"t{bd}.y4m")
+        svtlibs.write_y4m(path, f" W{w} H{h} F30:1 Ip {token}\n", frames)
+        with pkg.Y4mReader(lib, path) as rd:
+            assert (rd.info.width, rd.info.height, rd.info.bit_depth) == (w, h, bd)
+            assert rd.frame_bytes == (w * h + 2 * (w // 2) * (h // 2)) * dt.itemsize if bd > 8 else rd.frame_bytes == w * h * 3 // 2
+            buf = np.zeros(rd.frame_bytes, np.uint8)
+            for fr in frames:
+                assert rd.read_into(buf)
+                assert buf.tobytes() == b"".join(np.ascontiguousarray(p).tobytes() for p in fr)
+            assert not rd.read_into(buf)                 # end of file
+            with pytest.raises(pkg.SvtHipError):
+                rd.read_into(np.zeros(4, np.uint8))      # too small a buffer is an error, not a short read
+    bad = str(tmp_path / "raw.yuv")
+    open(bad, "wb").write(b"\x10" * 100)
+    with pytest.raises(pkg.SvtHipError):
+        pkg.Y4mReader(lib, bad)
+    broken = str(tmp_path / "broken.y4m")
+    open(broken, "wb").write(b"YUV4MPEG2 W4 H2 F1:1\nFRAMX\n" + b"\x00" * 12)
+    with pkg.Y4mReader(lib, broken) as rd:
+        with pytest.raises(pkg.SvtHipError):
+            rd.read_into(np.zeros(rd.frame_bytes, np.uint8))

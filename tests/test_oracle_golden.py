@@ -409,3 +409,36 @@ def test_predict_intra_block_golden():
         assert np.array_equal(got, exp), ({k: v for k, v in c.items() if np.isscalar(v)}, out5)
         n += 1
     assert n == 300
+
+
+def test_picture_input_golden():
+    """n4: y4m header parsing == the reference application's read_y4m_header on files; pad_input_picture + generate_padding and
+    Decimation2D + generate_padding == the reference library's (tests/golden/picture.npz)"""
+    O = svtlibs.oracle()
+    g = np.load(os.path.join(G, "picture.npz"))
+    for line, exp in zip(g["y4m_lines"].tolist(), g["y4m_out"].tolist()):
+        info = svtlibs.Y4mInfo()
+        rc = O.svt_oracle_y4m_parse_header(line.encode(), ctypes.byref(info))
+        assert exp[0] == 1 and (rc == 0) == (exp[1] == 0), line
+        if rc == 0:
+            assert [info.width, info.height, info.fr_n, info.fr_d, info.bit_depth, info.interlaced] == exp[2:8], line
+    for k in g["pad_cases"].tolist():
+        w, h, ox, oy, pr, pb, is16, stride = (int(v) for v in g[f"pad{k}_prm"])
+        exp = g[f"pad{k}_out"]
+        buf = np.full_like(exp, 0x55)
+        buf[oy:oy + h, ox:ox + w] = g[f"pad{k}_frame"]
+        es = 2 if is16 else 1
+        O.svt_oracle_pad_input_picture(ctypes.c_void_p(buf.ctypes.data + (oy * stride + ox) * es), stride, w, h, pr, pb, es)
+        O.svt_oracle_generate_padding(ptr(buf), stride, w + pr, h + pb, ox, oy, es)
+        assert np.array_equal(buf, exp), k
+    for k in g["dec_cases"].tolist():
+        w, h, stride, qo, so = (int(v) for v in g[f"dec{k}_prm"])
+        luma = np.ascontiguousarray(g[f"dec{k}_luma"])
+        for step, o, key in ((2, qo, "q"), (4, so, "s")):
+            exp = g[f"dec{k}_{key}"]
+            dw, dh = (w + step - 1) // step, (h + step - 1) // step
+            buf = np.full_like(exp, 0x33)
+            ds = exp.shape[1]
+            O.svt_oracle_decimation_2d(ptr(luma), stride, w, h, ctypes.c_void_p(buf.ctypes.data + o * ds + o), ds, step)
+            O.svt_oracle_generate_padding(ptr(buf), ds, dw, dh, o, o, 1)
+            assert np.array_equal(buf, exp), (k, key)

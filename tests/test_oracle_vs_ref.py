@@ -505,3 +505,67 @@ def test_predict_intra_block_vs_reference_randomized():
         assert np.array_equal(got, exp), ({k: v for k, v in c.items() if np.isscalar(v)}, out5)
         n += 1
     assert n > 3500
+
+
+# ---- picture input: y4m header, padding, decimation ---------------------------------------------------
+def test_y4m_header_vs_reference_application(tmp_path):
+    """read_y4m_header / check_if_y4m / read_y4m_frame_delimiter of the reference's application on real files"""
+    O = svtlibs.oracle()
+    R.ref_y4m_header.restype = ctypes.c_long
+    for i, (line, good) in enumerate(svtlibs.Y4M_HEADERS):
+        path = str(tmp_path / f"h{i}.y4m")
+        svtlibs.write_y4m(path, line, [(np.zeros(4, np.uint8),) * 3])
+        out = np.zeros(8, np.int32)
+        pos = R.ref_y4m_header(path.encode(), ptr(out))
+        info = svtlibs.Y4mInfo()
+        rc = O.svt_oracle_y4m_parse_header(line.encode(), ctypes.byref(info))
+        assert out[0] == 1
+        assert (rc == 0) == good == (out[1] == 0), (line, rc, out)
+        if good:
+            assert [info.width, info.height, info.fr_n, info.fr_d, info.bit_depth, info.interlaced] == out[2:8].tolist(), line
+            assert pos == 9 + len(line) + 6        # signature + header line + "FRAME\n"
+    # not a y4m file
+    p = str(tmp_path / "raw.yuv")
+    open(p, "wb").write(b"\x10" * 64)
+    out = np.zeros(8, np.int32)
+    R.ref_y4m_header(p.encode(), ptr(out))
+    assert out[0] == 0
+
+
+@pytest.mark.parametrize("is16", [0, 1])
+def test_padding_and_decimation_vs_reference(is16):
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(77 + is16)
+    dt = np.uint16 if is16 else np.uint8
+    for trial in range(40):
+        w, h = int(rng.integers(1, 70)), int(rng.integers(1, 50))
+        pw, ph = int(rng.integers(0, 20)), int(rng.integers(0, 12))
+        stride = w + 2 * pw + int(rng.integers(0, 9))
+        a = rng.integers(0, 1 << (10 if is16 else 8), (h + 2 * ph, stride)).astype(dt)
+        b = a.copy()
+        R.ref_generate_padding(ptr(a), stride, w, h, pw, ph, is16)
+        O.svt_oracle_generate_padding(ptr(b), stride, w, h, pw, ph, 2 if is16 else 1)
+        assert np.array_equal(a, b), (trial, w, h, pw, ph)
+        # closed form the device kernel uses: every sample of the padded area = the nearest picture sample
+        yy = np.clip(np.arange(h + 2 * ph) - ph, 0, h - 1)
+        xx = np.clip(np.arange(w + 2 * pw) - pw, 0, w - 1)
+        assert np.array_equal(a[:, :w + 2 * pw], a[ph:ph + h, pw:pw + w][np.ix_(yy, xx)])
+    if is16:
+        return
+    for trial in range(40):
+        w, h = int(rng.integers(1, 70)), int(rng.integers(1, 50))
+        pr, pb = int(rng.integers(0, 8)), int(rng.integers(0, 8))
+        stride = w + pr + int(rng.integers(0, 5))
+        a = rng.integers(0, 256, (h + pb, stride)).astype(np.uint8)
+        b = a.copy()
+        R.ref_pad_input_picture(ptr(a), stride, w, h, pr, pb)
+        O.svt_oracle_pad_input_picture(ptr(b), stride, w, h, pr, pb, 1)
+        assert np.array_equal(a, b)
+        for step in (2, 4):
+            ow, oh = (w + step - 1) // step, (h + step - 1) // step
+            src = rng.integers(0, 256, (h, w + 3)).astype(np.uint8)
+            d0 = np.full((oh, ow + 2), 7, np.uint8); d1 = d0.copy()
+            R.ref_decimation_2d(ptr(src), w + 3, w, h, ptr(d0), ow + 2, step)
+            O.svt_oracle_decimation_2d(ptr(src), w + 3, w, h, ptr(d1), ow + 2, step)
+            assert np.array_equal(d0, d1)
+            assert np.array_equal(d0[:, :ow], src[::step, :w:step])
