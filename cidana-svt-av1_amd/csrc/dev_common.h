@@ -108,6 +108,28 @@ __device__ __forceinline__ unsigned group_sum(unsigned v) {
     for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
+// sum / minimum over an aligned group of `lanes` lanes (a wave-uniform power of two, 4 .. 64), valid in every lane of the group.
+// The steps inside a row of 16 lanes are DPP operands of the add itself (quad permutes, then the mirrors: lane i <-> 7 - i and
+// i <-> 15 - i pair up what the previous steps left equal); only the two steps across rows go through ds_bpermute.  A runtime
+// loop of __shfl_xor is one LDS round trip per step.
+__device__ __forceinline__ uint32_t group_sum_rt(uint32_t v, uint32_t lanes) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+    if (lanes >= 8) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);      // row_half_mirror
+    if (lanes >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);     // row_mirror
+    if (lanes >= 32) v += (uint32_t)__shfl_xor((int)v, 16, 64);
+    if (lanes >= 64) v += (uint32_t)__shfl_xor((int)v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t group_min_rt(uint32_t v, uint32_t lanes) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
+    if (lanes >= 8) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));
+    if (lanes >= 16) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));
+    if (lanes >= 32) v = min(v, (uint32_t)__shfl_xor((int)v, 16, 64));
+    if (lanes >= 64) v = min(v, (uint32_t)__shfl_xor((int)v, 32, 64));
+    return v;
+}
 template <int G>
 __device__ __forceinline__ unsigned long long group_sum64(unsigned long long v) {
 #pragma unroll

@@ -35,7 +35,7 @@ extern int g_tune_no_q16;
 extern int g_tune_q2_su4;
 extern int g_tune_ois_no_fold;
 extern int g_tune_ois_no_nd;
-extern int g_tune_dir_no_split;
+extern int g_tune_dir_no_split, g_tune_dir_split_target;
 extern int g_tune_no_me16;
 extern int g_tune_me_exact;
 extern int g_tune_no_f32p;

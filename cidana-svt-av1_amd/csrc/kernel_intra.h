@@ -416,11 +416,11 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
                 const size_t base_off = has_offs ? (size_t)off_word : (size_t)blk * dst_block_pitch;
                 intra_store<PixT>(dst + base_off + (size_t)r * dst_stride + c0, make_uint4(w[0], w[1], w[2], w[3]), ppl);
             } else {
-                // lanes of a block are per_block (<= 64) consecutive lanes of one wave: butterfly sum, lane 0 writes
+                // lanes of a block are per_block (4 .. 64) consecutive lanes of one wave: group sum (DPP inside a row), lane 0 writes
                 uint32_t sad = __builtin_amdgcn_sad_u8(srcw[0], w[0], 0u);
                 if (ppl >= 8) sad = __builtin_amdgcn_sad_u8(srcw[1], w[1], sad);
                 if (ppl == 16) { sad = __builtin_amdgcn_sad_u8(srcw[2], w[2], sad); sad = __builtin_amdgcn_sad_u8(srcw[3], w[3], sad); }
-                for (uint32_t m = per_block >> 1; m >= 1; m >>= 1) sad += __shfl_xor(sad, (int)m, 64);
+                sad = group_sum_rt(sad, per_block);
                 if (j == 0) multi.sad_dist[(size_t)blk * multi.sad_ncand + (uint32_t)kslot] = sad;
             }
         }

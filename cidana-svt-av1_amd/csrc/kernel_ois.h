@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void ois_sad_kernel(const uint8_t* __restrict_
         sad = __builtin_amdgcn_sad_u8(sv[0], pv[0], sad);
         sad = __builtin_amdgcn_sad_u8(sv[1], pv[1], sad);
         if (cs == 16) { sad = __builtin_amdgcn_sad_u8(sv[2], pv[2], sad); sad = __builtin_amdgcn_sad_u8(sv[3], pv[3], sad); }
-        for (uint32_t m = span >> 1; m >= 1; m >>= 1) sad += __shfl_xor(sad, (int)m, 64);
+        sad = group_sum_rt(sad, span);
         if (lpb <= 64) { if (l == 0) row_out[c] = sad; }
         else if ((threadIdx.x & 63) == 0) wave_part[(threadIdx.x >> 6) * ncand + c] = sad;
     }
@@ -144,7 +144,10 @@ __global__ __launch_bounds__(256) void ois_sad_kernel(const uint8_t* __restrict_
 // this is the whole open-loop search in ONE launch - no neighbour arrays, no prediction scratch.
 // ---------------------------------------------------------------------------
 enum { OIS_K_DC = 0, OIS_K_V, OIS_K_H, OIS_K_SMOOTH, OIS_K_SMOOTH_V, OIS_K_SMOOTH_H, OIS_K_PAETH, OIS_K_FOLDED };
-struct OisKinds { uint8_t k[OIS_MAX_CAND + 3]; };
+struct OisKinds {
+    uint8_t k[OIS_MAX_CAND + 3];             // kind of candidate c; [OIS_MAX_CAND + 2] = the list has folded candidates
+    uint8_t n_nd, nd_c[15], nd_kind[15];     // the candidates ois_nd_kernel computes itself, in list order (host-built: the kernel's loop
+};                                           // then runs 7 times, not 45 with a scalar load and a branch per folded candidate)
 
 __device__ constexpr uint8_t kOisSmWeights[128] = {          // sm_weight_arrays (ASM_AVX2/EbIntraPrediction_AVX2.h:19-38), index [bs + i]
     0, 0, 255, 128, 255, 149, 85, 64, 255, 197, 146, 105, 73, 50, 37, 32,
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__
     int dsum = 0;
     for (uint32_t i = l; i < 2 * bsize; i += lpb) dsum += i < bsize ? (has_a ? above_at(i) : 0) : (has_l ? left_at(i - bsize) : 0);
     const uint32_t span = lpb < 64 ? lpb : 64;
-    for (uint32_t m = span >> 1; m >= 1; m >>= 1) dsum += __shfl_xor(dsum, (int)m, 64);
+    dsum = (int)group_sum_rt((uint32_t)dsum, span);
     uint32_t* row_out = s_dist + (size_t)slot * ncand;
     uint32_t* wave_part = s_dist + (size_t)slots * ncand;            // 64x64 only: [wave][cand], then 4 DC partials
     if (lpb > 64) {
@@ -211,11 +214,12 @@ __global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__
     const uint32_t lg = __builtin_ctz(bsize);
     const int dcv = (has_a && has_l) ? (dsum + (int)bsize) >> (lg + 1) : ((has_a || has_l) ? (dsum + (int)(bsize >> 1)) >> lg : 128);
     const int wh = kOisSmWeights[bsize + row];
+    uint32_t wwv[4] = {0, 0, 0, 0};                        // this lane's column weights, one byte each: one load instead of one per pixel and kind
+    __builtin_memcpy(wwv, kOisSmWeights + bsize + col, CS);
     if (lpb <= 64) __syncthreads();                        // the copy above before this loop's stores (64x64: the barrier above)
     // ---- candidates -------------------------------------------------------------------------------------------------------------
-    for (uint32_t c = 0; c < ncand; c++) {
-        const uint32_t kind = kinds.k[c];                  // uniform (kernel argument)
-        if (kind == OIS_K_FOLDED) continue;
+    for (uint32_t i = 0; i < kinds.n_nd; i++) {
+        const uint32_t kind = kinds.nd_kind[i], c = kinds.nd_c[i];       // uniform (kernel arguments)
         uint32_t pv[4] = {0, 0, 0, 0};
         if (kind == OIS_K_DC) { pv[0] = pv[1] = pv[2] = pv[3] = (uint32_t)dcv * 0x01010101u; }
         else if (kind == OIS_K_V) { pv[0] = av[0]; pv[1] = av[1]; pv[2] = av[2]; pv[3] = av[3]; }
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__
 #pragma unroll
             for (int k = 0; k < CS; k++) {
                 const int t = (int)((av[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                const int ww = kOisSmWeights[bsize + col + k];
+                const int ww = (int)((wwv[k >> 2] >> (8 * (k & 3))) & 0xffu);
                 int v;
                 if (kind == OIS_K_SMOOTH) v = (wh * t + (256 - wh) * bl + ww * lf + (256 - ww) * tr + 256) >> 9;
                 else if (kind == OIS_K_SMOOTH_V) v = (wh * t + (256 - wh) * bl + 128) >> 8;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__
         sad = __builtin_amdgcn_sad_u8(sv[0], pv[0], sad);
         sad = __builtin_amdgcn_sad_u8(sv[1], pv[1], sad);
         if (CS == 16) { sad = __builtin_amdgcn_sad_u8(sv[2], pv[2], sad); sad = __builtin_amdgcn_sad_u8(sv[3], pv[3], sad); }
-        for (uint32_t m = span >> 1; m >= 1; m >>= 1) sad += __shfl_xor(sad, (int)m, 64);
+        sad = group_sum_rt(sad, span);
         if (lpb <= 64) { if (l == 0) row_out[c] = sad; }
         else if ((threadIdx.x & 63) == 0) wave_part[(threadIdx.x >> 6) * ncand + c] = sad;
     }
@@ -251,7 +255,14 @@ __global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__
         __syncthreads();
     }
     for (uint32_t i = threadIdx.x; i < nb_here * ncand; i += 256) dist[(size_t)first * ncand + i] = s_dist[i];
-    if (threadIdx.x < nb_here) {
+    if (lpb <= 64) {
+        // best index = first strict minimum: the block's lanes each scan every lpb-th candidate, key = sum << 6 | index (sums
+        // < 2^20, at most 61 candidates), minimum over the group
+        uint32_t key = 0xffffffffu;
+        for (uint32_t c = l; c < ncand; c += lpb) key = min(key, (row_out[c] << 6) | c);
+        key = group_min_rt(key, span);
+        if (valid && l == 0) best_index[blk] = (int8_t)(key & 63u);
+    } else if (threadIdx.x < nb_here) {
         const uint32_t* r = s_dist + (size_t)threadIdx.x * ncand;
         uint32_t best = 64u * 64u * 255u;
         int bi = 0;

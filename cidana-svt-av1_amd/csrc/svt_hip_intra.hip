@@ -173,11 +173,11 @@ static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pit
         const size_t shmem = slots * 2 * (size_t)((n_pad + 7) & ~7) * 4;            // pair dwords (see the kernel)
         DirMulti dm;
         if (multi) dm = *multi; else dm.n = 0;
-        // angles per workgroup: all of them when the batch alone fills the GPU (>= 16 workgroups per CU), else split over grid.y
+        // angles per workgroup: all of them when the batch alone gives every CU a few workgroups, else split over grid.y (each part re-stages the edges)
         uint32_t gy = 1;
         dm.chunk = dm.n > 0 ? dm.n : 1;
         if (dm.n > 1 && !g_tune_dir_no_split) {
-            const size_t want = (size_t)16 * (size_t)g_num_cu;
+            const size_t want = (size_t)g_tune_dir_split_target * (size_t)g_num_cu;
             size_t parts = grid >= want ? 1 : (want + grid - 1) / grid;
             if (parts > (size_t)dm.n) parts = (size_t)dm.n;
             dm.chunk = (int)((dm.n + parts - 1) / parts);
@@ -341,7 +341,7 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
     {
         OisKinds kinds;
         memset(&kinds, 0, sizeof(kinds));
-        bool any_dir = false;
+        bool any_dir = false, nd_fits = true;             // nd_fits: the kernel's own list (7 distinct kinds; a list may repeat them)
         for (int c = 0; c < ncand; c++) {
             const int m = modes[c];
             int k;
@@ -352,10 +352,14 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
                 any_dir = any_dir || k == OIS_K_FOLDED;
             } else k = m == 9 ? OIS_K_SMOOTH : (m == 10 ? OIS_K_SMOOTH_V : (m == 11 ? OIS_K_SMOOTH_H : OIS_K_PAETH));
             kinds.k[c] = (uint8_t)k;
+            if (k != OIS_K_FOLDED) {
+                if (kinds.n_nd >= sizeof(kinds.nd_c)) nd_fits = false;
+                else { kinds.nd_c[kinds.n_nd] = (uint8_t)c; kinds.nd_kind[kinds.n_nd] = (uint8_t)k; kinds.n_nd++; }
+            }
         }
         kinds.k[OIS_MAX_CAND + 2] = any_dir ? 1 : 0;              // ois_nd_kernel: rows of dist hold folded sums to pick up
         const bool can_fold = bsize <= 16 && !g_tune_ois_no_fold;
-        if (!g_tune_ois_no_nd && (!any_dir || can_fold)) {
+        if (!g_tune_ois_no_nd && nd_fits && (!any_dir || can_fold)) {
             if (any_dir) {
                 uint8_t* d_above = (uint8_t*)w;
                 uint8_t* d_left = d_above + ois_align(nblocks * pitch);
