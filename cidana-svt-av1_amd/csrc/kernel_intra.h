@@ -262,6 +262,13 @@ struct DirMulti {
     const uint32_t* sad_xy;
     uint32_t* sad_dist;
     uint32_t sad_ncand;
+    // zone 2, one lane per row (bw == samples per lane: the open-loop search's 8x8 and 16x16), no up-sampling: the LEFT-edge terms
+    // of pixel k depend on (dy, k) only, so the host tabulates them per angle - the kernel fetches a row of each with one scalar
+    // load and the per-pixel work drops to an add, two selects, the dot and the shift.
+    //   z2_w2[a][k] = (32 - s) | s << 16,  s = ((-dy (k + 1)) & 63) >> 1;   z2_ol[a][k] = 4 * ((-dy (k + 1)) >> 6)
+    int z2_tab;                  // tables valid (host: zone 2, lanes per row == 1, no up-sampling)
+    uint32_t z2_w2[20][16];
+    int32_t z2_ol[20][16];
 };
 
 // NPX = samples per lane = min(bw, 16 B worth): a compile-time constant so that narrow blocks (bw 4 / 8) do not compute
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
         const uint8_t* sp = multi.sad_pic + (size_t)((q >> 16) + (uint32_t)r) * multi.sad_stride + (q & 0xffffu) + (uint32_t)c0;
         if (ppl == 16) __builtin_memcpy(srcw, sp, 16); else if (ppl == 8) __builtin_memcpy(srcw, sp, 8); else __builtin_memcpy(srcw, sp, 4);
     }
-    auto emit = [&](const int dx, const int dy, PixT* __restrict__ dst, const int kslot) {
+    auto emit = [&](const int dx, const int dy, PixT* __restrict__ dst, const int kslot, const int kslot_tab) {
         uint32_t px[PXL];
         if (MODE == IM_Z1) {
             const int x = dx * (r + 1);
@@ -358,6 +365,15 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
             }
         } else if (MODE == IM_Z3) {
             int y = dy * (c0 + 1);
+            if (lanes_per_row == 1 && up_left == 0) {
+                // one lane per row: y, its fraction and the weight pair of pixel k are the same in every lane (SGPRs)
+#pragma unroll
+                for (int k = 0; k < PXL; k++) {
+                    const int ys = dy * (k + 1);
+                    const uint32_t sh = (uint32_t)((ys & 0x3f) >> 1);
+                    px[k] = dir_lerp2(L[min((ys >> 6) + r, lim_l - NB_ORIGIN)], (32u - sh) | (sh << 16));
+                }
+            } else
 #pragma unroll
             for (int k = 0; k < PXL; k++) {
                 const uint32_t sh = (uint32_t)(((y << up_left) & 0x3f) >> 1);
@@ -373,20 +389,42 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
             if ((up_above | up_left) == 0) {
                 // no upsampling (every block larger than 8x8, and the whole open-loop search): constant shifts, LDS byte
                 // addresses and the weight pair as one multiply-add - the kernel is VALU-bound on this per-pixel selection
-                const int b0 = (x >> 6) + c0;                                  // base1 of pixel k = b0 + k; above edge when >= -1
                 const uint32_t w1 = (32u - s1) | (s1 << 16);
                 const int aoffB = aoff * 4, loffB = loff * 4;
                 const char* smb = reinterpret_cast<const char*>(sm);
+                auto row_px = [&](const int c0v) {
+                    const int b0 = (x >> 6) + c0v;                             // base1 of pixel k = b0 + k; above edge when >= -1
+                    int y = (r << 6) - dy * (c0v + 1);
 #pragma unroll
-                for (int k = 0; k < PXL; k++) {
-                    const bool ab = b0 >= -1 - k;
-                    const uint32_t s2 = ((uint32_t)y >> 1) & 31u;              // (y & 0x3f) >> 1
-                    const uint32_t w2 = s2 * 0xffffu + 32u;                    // (32 - s2) | s2 << 16
-                    const int offL = loffB + ((y >> 4) & ~3);                  // 4 * (loff + (y >> 6))
-                    const int off = ab ? aoffB + 4 * k : offL;
-                    px[k] = dir_lerp2(*reinterpret_cast<const uint32_t*>(smb + off), ab ? w1 : w2);
-                    y -= dy;
-                }
+                    for (int k = 0; k < PXL; k++) {
+                        const bool ab = b0 >= -1 - k;
+                        const uint32_t s2 = ((uint32_t)y >> 1) & 31u;          // (y & 0x3f) >> 1
+                        const uint32_t w2 = s2 * 0xffffu + 32u;                // (32 - s2) | s2 << 16
+                        const int offL = loffB + ((y >> 4) & ~3);              // 4 * (loff + (y >> 6))
+                        const int off = ab ? aoffB + 4 * k : offL;
+                        px[k] = dir_lerp2(*reinterpret_cast<const uint32_t*>(smb + off), ab ? w1 : w2);
+                        y -= dy;
+                    }
+                };
+                if (multi.z2_tab && multi.n != 0) {
+                    // LDS byte addresses as integers (the pointer form costs an add of the LDS base per read)
+                    typedef const __attribute__((address_space(3))) uint32_t* LdsWord;
+                    const uint32_t ldsb = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smb);
+                    const uint32_t aB = ldsb + (uint32_t)aoffB, lB = ldsb + (uint32_t)(loffB + (r << 2));
+                    const int xb = x >> 6;
+                    // the angle's two table rows, fetched unconditionally into SGPRs (left to itself the compiler sinks each
+                    // element's scalar load into a branch on `ab`: two exec-mask branches and two waits per pixel)
+                    uint32_t tw[PXL], tol[PXL];
+#pragma unroll
+                    for (int k = 0; k < PXL; k++) { tw[k] = multi.z2_w2[kslot_tab][k]; tol[k] = (uint32_t)multi.z2_ol[kslot_tab][k]; }
+#pragma unroll
+                    for (int k = 0; k < PXL; k++) asm volatile("" : "+s"(tw[k]), "+s"(tol[k]));
+                    uint32_t ev[PXL];
+#pragma unroll
+                    for (int k = 0; k < PXL; k++) ev[k] = *(LdsWord)(uintptr_t)(xb >= -1 - k ? aB + 4u * (uint32_t)k : lB + tol[k]);
+#pragma unroll
+                    for (int k = 0; k < PXL; k++) px[k] = dir_lerp2(ev[k], xb >= -1 - k ? w1 : tw[k]);
+                } else row_px(c0);
             } else
 #pragma unroll
             for (int k = 0; k < PXL; k++) {
@@ -425,10 +463,10 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
             }
         }
     };
-    if (multi.n == 0) emit(dx, dy, dst, 0);
+    if (multi.n == 0) emit(dx, dy, dst, 0, 0);
     else {
         const int k0 = (int)blockIdx.y * multi.chunk, k1 = min(multi.n, k0 + multi.chunk);
-        for (int k = k0; k < k1; k++) emit(multi.dx[k], multi.dy[k], dst + (size_t)multi.slot[k] * multi.batch_pitch, (int)multi.slot[k]);
+        for (int k = k0; k < k1; k++) emit(multi.dx[k], multi.dy[k], dst + (size_t)multi.slot[k] * multi.batch_pitch, (int)multi.slot[k], k);
     }
 }
 

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void ois_gather_kernel(const uint8_t* __restri
         if (l == 0) {
             const uint8_t tl = (x != 0 && y != 0) ? src[-(ptrdiff_t)stride - 1] : (uint8_t)128;
             ab[-1] = tl; lb[-1] = tl;
+            ab[-2] = 0; lb[-2] = 0;          // position -2 is staged with the rest (it only matters with up-sampling, which the open loop never has)
         }
         // DC sum over the first bsize samples of each available edge (a block's lanes may span two waves: LDS)
         if (l < bsize) atomicAdd(&s_sum[slot], (y != 0 ? (int)av : 0) + (x != 0 ? (int)lv : 0));

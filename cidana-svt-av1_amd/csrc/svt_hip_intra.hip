@@ -173,6 +173,17 @@ static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pit
         const size_t shmem = slots * 2 * (size_t)((n_pad + 7) & ~7) * 4;            // pair dwords (see the kernel)
         DirMulti dm;
         if (multi) dm = *multi; else dm.n = 0;
+        dm.z2_tab = 0;
+        if (dm.n > 0 && mode == SVT_INTRA_Z2 && bw == ppl && (upsample_above | upsample_left) == 0) {     // see DirMulti
+            dm.z2_tab = 1;
+            for (int a = 0; a < dm.n; a++)
+                for (int k = 0; k < 16; k++) {
+                    const int ys = -(int)dm.dy[a] * (k + 1);
+                    const uint32_t sh = ((uint32_t)ys & 63u) >> 1;
+                    dm.z2_w2[a][k] = (32u - sh) | (sh << 16);
+                    dm.z2_ol[a][k] = 4 * (ys >> 6);
+                }
+        }
         // angles per workgroup: all of them when the batch alone gives every CU a few workgroups, else split over grid.y (each part re-stages the edges)
         uint32_t gy = 1;
         dm.chunk = dm.n > 0 ? dm.n : 1;
@@ -364,7 +375,7 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
                 uint8_t* d_above = (uint8_t*)w;
                 uint8_t* d_left = d_above + ois_align(nblocks * pitch);
                 uint8_t* d_dc = d_left + ois_align(nblocks * pitch);
-                if (hipMemsetAsync(d_above, 0, 2 * ois_align(nblocks * pitch), st) != hipSuccess) return set_err(SVT_HIP_ERR_RUNTIME, "hipMemsetAsync");
+                // (no clearing of the neighbour arrays: the directional kernels stage positions [-2, 2 * bsize) only, all written by the gather)
                 const uint32_t slots = 256 / (2 * bsize);
                 hipLaunchKernelGGL(ois_gather_kernel, dim3((uint32_t)((nblocks + slots - 1) / slots)), dim3(256), 0, st, d_pic, stride, width,
                                    height, d_xy, bsize, d_above, d_left, (uint32_t)pitch, d_dc, (uint32_t)nblocks);
