@@ -273,7 +273,9 @@ struct DirMulti {
 
 // NPX = samples per lane = min(bw, 16 B worth): a compile-time constant so that narrow blocks (bw 4 / 8) do not compute
 // a full 16-B segment per lane and throw most of it away (the open-loop search's 8x8 pass spent half its VALU there).
-template <typename PixT, int MODE, int NPX>
+// TAB: zone 2 with the host's per-angle tables (DirMulti::z2_w2 / z2_ol); a separate instantiation so that the dense-output kernels
+// keep their own code (with both paths in one kernel the 32x32 single-angle form ran 15 % slower).
+template <typename PixT, int MODE, int NPX, bool TAB = false>
 __global__ __launch_bounds__(256) void intra_dir_kernel(
     PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
     const PixT* __restrict__ above_all, const PixT* __restrict__ left_all, int32_t nb_pitch, int bw, int bh,
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
                         y -= dy;
                     }
                 };
-                if (multi.z2_tab && multi.n != 0) {
+                if constexpr (TAB) {
                     // LDS byte addresses as integers (the pointer form costs an add of the LDS base per read)
                     typedef const __attribute__((address_space(3))) uint32_t* LdsWord;
                     const uint32_t ldsb = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smb);

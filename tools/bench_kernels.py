@@ -19,6 +19,22 @@ def timeit(fn, iters=8):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
+def timeit_graph(fn, iters=40):
+    """the same call captured once into a HIP graph and replayed: GPU time without the host's per-launch cost (a call of a few
+    launches of ~10 us each is host-bound from Python); None when the call cannot be captured"""
+    try:
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            fn(); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                fn()
+        torch.cuda.synchronize()
+        return timeit(g.replay, iters=iters)
+    except Exception as e:                                   # noqa: BLE001
+        print(json.dumps({"graph_capture_failed": str(e)[:200]}), flush=True)
+        torch.cuda.synchronize()
+        return None
 rows = []
 def rec(name, n, bytes_per, ms, extra=None):
     r = {"kernel": name, "units": n, "bytes_per_unit": bytes_per, "ms": round(ms, 4), "Munits_per_s": round(n / ms / 1e3, 2),
@@ -96,9 +112,13 @@ if want("bd10"):
         w, h = TW[s], TH[s]
         src = torch.randint(0, 1024, (n, h, w), dtype=torch.int16, device=dev); pred = torch.randint(0, 1024, (n, h, w), dtype=torch.int16, device=dev)
         _, isc = pkg.tables.scan_tables(s, 0); iscan = torch.from_numpy(isc).to(dev)
-        xy = None
-        ms = timeit(lambda: dsp.fwd_quant_planes(src.view(n * h, w), w, pred.view(n * h, w), w,
-                                                 torch.arange(n, dtype=torch.int32, device=dev) * (h << 16), s, 0, qrow10, iscan, bd=10), iters=4)
+        # the batch as ONE plane 16 384 samples wide (origins are 16-bit x | y << 16: a single column of blocks would wrap y and
+        # measure a cache-resident handful of blocks - the first version of this row did, and read 1.1 of the HBM peak)
+        PWD = 16384
+        bi = np.arange(n, dtype=np.uint32)
+        assert int(bi[-1] // (PWD // w)) * h + h <= 65536
+        xy = torch.from_numpy((((bi // (PWD // w)) * h << 16) | ((bi % (PWD // w)) * w)).astype(np.uint32).view(np.int32)).to(dev)
+        ms = timeit(lambda: dsp.fwd_quant_planes(src.view(-1, PWD), PWD, pred.view(-1, PWD), PWD, xy, s, 0, qrow10, iscan, bd=10), iters=4)
         rec(f"fused_generic_bd10_{w}x{h}", n, 4 * w * h + 12 * w * h + 2, ms)
         co = torch.randint(-2000, 2001, (n, w * h), dtype=torch.int32, device=dev)
         d = torch.randint(0, 1024, (n, h, w), dtype=torch.int16, device=dev)
@@ -190,17 +210,21 @@ if want("ois"):
         blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
         xy = torch.from_numpy(np.array([(y << 16) | x for x, y in blocks], np.uint32).view(np.int32)).to(dev)
         modes, deltas = dsp.ois_candidates(bsize)
-        ms = timeit(lambda: dsp.ois_search(pic, W + 2 * pad, W, H, xy, bsize, modes, deltas), iters=4)
+        call = lambda: dsp.ois_search(pic, W + 2 * pad, W, H, xy, bsize, modes, deltas)
+        ms_call = timeit(call, iters=20)
+        ms_g = timeit_graph(call)
+        ms = min(ms_call, ms_g) if ms_g is not None else ms_call
         tot += ms
         rec(f"ois_search_1080p_{bsize}x{bsize}_{len(modes)}cand", len(blocks), bsize * bsize * (1 + 2 * len(modes)), ms,
-            {"candidate_predictions_per_s_M": round(len(blocks) * len(modes) / ms / 1e3, 1)})
+            {"candidate_predictions_per_s_M": round(len(blocks) * len(modes) / ms / 1e3, 1), "ms_per_call_from_python": round(ms_call, 4),
+             "ms_graph_replay": None if ms_g is None else round(ms_g, 4)})
     groups = []
     for bsize in (8, 16, 32, 64):
         blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
         xy = torch.from_numpy(np.array([(y << 16) | x for x, y in blocks], np.uint32).view(np.int32)).to(dev)
         modes, deltas = dsp.ois_candidates(bsize)
         groups.append((xy, bsize, modes, deltas))
-    ms_frame = timeit(lambda: dsp.ois_search_frame(pic, W + 2 * pad, W, H, groups), iters=4)
+    ms_frame = timeit(lambda: dsp.ois_search_frame(pic, W + 2 * pad, W, H, groups), iters=20)
     rows.append({"kernel": "ois_search_1080p_all_sizes_one_call", "ms": round(ms_frame, 4), "units": 1, "bytes_per_unit": 0, "Munits_per_s": 0, "GBps": 0, "frac_hbm_peak": 0})
     print(json.dumps({"ois_search_1080p_all_sizes_ms": round(tot, 3), "ois_search_1080p_all_sizes_one_call_ms": round(ms_frame, 4)}), flush=True)
 if want("me_sb"):
