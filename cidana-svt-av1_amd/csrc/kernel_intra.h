@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(
 // the blocks a workgroup works on are staged in LDS in PAIR form: dword i = edge[i] | edge[i+1] << 16,
 // padded with copies of the last valid sample edge[max_base] (the reference's "base >= max_base ->
 // edge[max_base]" case then falls out of the same interpolation: (32*e + 16) >> 5 == e, so the pixel
-// loop has no bounds test).  A pixel is then ONE aligned ds_read_b32 and ONE v_dot2_u32_u16:
+// loop has no bounds test).  Staging takes the samples in groups of four pairs per lane (one 8-byte load, four v_perm_b32, two
+// ds_write_b64).  A pixel is then ONE aligned ds_read_b32 and ONE v_dot2_u32_u16:
 //   (a*(32-sh) + b*sh + 16) >> 5  =  dot2((a, b), (32-sh, sh), 16) >> 5.
 // (The first LDS version kept samples as bytes: the compiler merged the per-sample reads into unaligned
 // ds_read_b128/b64 at ~23 LDS cycles each and the LDS was 86 % busy; one ds_read_u8 per sample was slower
@@ -301,44 +302,57 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
     const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t j = (uint32_t)(item & (per_block - 1));
     const int r = (int)(j >> lr_shift), c0 = (int)(j & (uint32_t)(lanes_per_row - 1)) * ppl;
-    const int estride = (n_pad + 7) & ~7;                                  // pair dwords per staged edge
+    const int estride = (n_pad + 10) & ~7;                                 // pair dwords per staged edge (+ 3: the last group of four may pass n_pad)
     uint32_t* sa = sm + (size_t)slot * 2 * estride;                        // above edge of this lane's block
     uint32_t* sl = sa + estride;
     const bool live = item < total;
     const uint32_t blk = live ? (uint32_t)(item >> pb_shift) : 0u;
     const bool has_offs = dst_offsets != nullptr;
     const uint32_t off_word = (has_offs ? dst_offsets : kZeroWord)[has_offs ? blk : 0u];
-    // ---- stage the block's two edges as pairs: array positions [NB_ORIGIN-2, lim] from memory (lim = NB_ORIGIN +
-    // max_base), everything after it = edge[max_base].  All loads of a lane are issued before the first LDS
-    // write (fixed trip count, clamped index: no branch, no wait between the loads).
+    // ---- stage the block's two edges as pairs: array positions [NB_ORIGIN-2, n_pad) - sample i from memory up to lim (= NB_ORIGIN +
+    // max_base), edge[lim] after it.  A lane takes GROUPS of four consecutive pair dwords: one (unaligned) 8- or 12-byte load
+    // gives the five samples they need, four v_perm / v_alignbit build the pairs, two ds_write_b64 store them - against two byte
+    // loads and ~7 VALU instructions per pair before (the staging cost as much as the prediction of a 32x32 z1 block).
     {
         const PixT* ga = above_all + (size_t)blk * nb_pitch;
         const PixT* gl = left_all + (size_t)blk * nb_pitch;
-        const int i0 = NB_ORIGIN - 2 + (int)jl, last = n_pad - 1;
-        auto stage = [&](auto itc) {
-            constexpr int IT = decltype(itc)::value;
-            uint32_t va[IT], vl[IT];
+        const int ng = (n_pad - (NB_ORIGIN - 2) + 3) >> 2;                 // groups per edge (estride is a multiple of 8: room for the last one)
+        for (int g = (int)jl; g < 2 * ng; g += (int)lpb) {
+            const bool left_edge = g >= ng;
+            const int gi = left_edge ? g - ng : g;
+            const PixT* ge = left_edge ? gl : ga;
+            const int lim = left_edge ? lim_l : lim_a;
+            const int idx = NB_ORIGIN - 2 + 4 * gi;
+            const uint32_t tail = (uint32_t)ge[lim] * 0x10001u;
+            uint32_t pr[4];
+            if (sizeof(PixT) == 1) {
+                // the 8-byte window never reaches past sample lim (the row of a block ends soon after it): groups near the tail read the
+                // window that ENDS at lim and shift their byte selectors by o; pairs at or past lim are replaced below
+                const int wb = min(idx, lim - 7), o = idx - wb;
+                uint32_t d[2];
+                __builtin_memcpy(d, ge + wb, 8);
+                const uint32_t so = (uint32_t)o * 0x00010001u;
 #pragma unroll
-            for (int t = 0; t < IT; t++) {
-                const int i = min(i0 + t * (int)lpb, last);
-                va[t] = (uint32_t)ga[min(i, lim_a)] | ((uint32_t)ga[min(i + 1, lim_a)] << 16);
-                vl[t] = (uint32_t)gl[min(i, lim_l)] | ((uint32_t)gl[min(i + 1, lim_l)] << 16);
+                for (int k = 0; k < 4; k++) pr[k] = __builtin_amdgcn_perm(d[1], d[0], (0x0c000c00u | ((uint32_t)(k + 1) << 16) | (uint32_t)k) + so);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) __builtin_memcpy(&pr[k], ge + min(idx + k, lim - 1), 4);      // samples (i, i + 1): one 4-byte load
             }
 #pragma unroll
-            for (int t = 0; t < IT; t++) {
-                const int i = min(i0 + t * (int)lpb, last);
-                sa[i] = va[t]; sl[i] = vl[t];
-            }
-        };
-        const int niter = (n_pad - (NB_ORIGIN - 2) + (int)lpb - 1) >> __builtin_ctz(lpb);
-        if (niter <= 1) stage(std::integral_constant<int, 1>{});
-        else if (niter <= 2) stage(std::integral_constant<int, 2>{});
-        else if (niter <= 4) stage(std::integral_constant<int, 4>{});
-        else if (niter <= 8) stage(std::integral_constant<int, 8>{});
-        else for (int i = i0; i < n_pad; i += (int)lpb) {
-            sa[i] = (uint32_t)ga[min(i, lim_a)] | ((uint32_t)ga[min(i + 1, lim_a)] << 16);
-            sl[i] = (uint32_t)gl[min(i, lim_l)] | ((uint32_t)gl[min(i + 1, lim_l)] << 16);
+            for (int k = 0; k < 4; k++) pr[k] = idx + k < lim ? pr[k] : tail;
+            uint2* o = reinterpret_cast<uint2*>((left_edge ? sl : sa) + idx);      // 8-byte aligned (NB_ORIGIN - 2 is even)
+            o[0] = make_uint2(pr[0], pr[1]); o[1] = make_uint2(pr[2], pr[3]);
         }
+    }
+    // zone 2, one angle per launch, no up-sampling: the left-edge terms of column c - weight pair and 4 * ((-dy (c + 1)) >> 6) - are
+    // the same in every row; 64 lanes tabulate them once per workgroup behind the staged edges (DirMulti documents the terms)
+    const bool z2_lds_tab = MODE == IM_Z2 && !TAB && multi.n == 0 && (up_above | up_left) == 0;
+    uint32_t* tabw = sm + (size_t)(256u >> __builtin_ctz(lpb)) * 2 * estride;
+    if (z2_lds_tab && threadIdx.x < 64) {
+        const int ys = -dy * ((int)threadIdx.x + 1);
+        const uint32_t sh = ((uint32_t)ys & 63u) >> 1;
+        tabw[threadIdx.x] = (32u - sh) | (sh << 16);
+        tabw[64 + threadIdx.x] = (uint32_t)(4 * (ys >> 6));
     }
     __syncthreads();
     const uint32_t* A = sa + NB_ORIGIN;
@@ -426,6 +440,23 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
                     for (int k = 0; k < PXL; k++) ev[k] = *(LdsWord)(uintptr_t)(xb >= -1 - k ? aB + 4u * (uint32_t)k : lB + tol[k]);
 #pragma unroll
                     for (int k = 0; k < PXL; k++) px[k] = dir_lerp2(ev[k], xb >= -1 - k ? w1 : tw[k]);
+                } else if (z2_lds_tab) {
+                    typedef const __attribute__((address_space(3))) uint32_t* LdsWord;
+                    const uint32_t ldsb = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smb);
+                    const uint32_t aB = ldsb + (uint32_t)aoffB, lB = ldsb + (uint32_t)(loffB + (r << 2));
+                    const int b0 = (x >> 6) + c0;
+                    uint32_t tw[PXL], tol[PXL];
+#pragma unroll
+                    for (int q = 0; q < PXL / 4; q++) {
+                        const uint4 a = *reinterpret_cast<const uint4*>(tabw + c0 + 4 * q), b = *reinterpret_cast<const uint4*>(tabw + 64 + c0 + 4 * q);
+                        tw[4 * q] = a.x; tw[4 * q + 1] = a.y; tw[4 * q + 2] = a.z; tw[4 * q + 3] = a.w;
+                        tol[4 * q] = b.x; tol[4 * q + 1] = b.y; tol[4 * q + 2] = b.z; tol[4 * q + 3] = b.w;
+                    }
+                    uint32_t ev[PXL];
+#pragma unroll
+                    for (int k = 0; k < PXL; k++) ev[k] = *(LdsWord)(uintptr_t)(b0 >= -1 - k ? aB + 4u * (uint32_t)k : lB + tol[k]);
+#pragma unroll
+                    for (int k = 0; k < PXL; k++) px[k] = dir_lerp2(ev[k], b0 >= -1 - k ? w1 : tw[k]);
                 } else row_px(c0);
             } else
 #pragma unroll

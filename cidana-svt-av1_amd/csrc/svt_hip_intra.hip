@@ -170,7 +170,7 @@ static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pit
         const int up = upsample_above > upsample_left ? upsample_above : upsample_left;
         const int n_pad = (lim_a > lim_l ? lim_a : lim_l) + ((16 / es) << up) + 3;
         const size_t slots = per_block >= 256 ? 1 : 256 / per_block;
-        const size_t shmem = slots * 2 * (size_t)((n_pad + 7) & ~7) * 4;            // pair dwords (see the kernel)
+        const size_t shmem = slots * 2 * (size_t)((n_pad + 10) & ~7) * 4 + 2 * 64 * 4;   // pair dwords + zone 2's column table (see the kernel)
         DirMulti dm;
         if (multi) dm = *multi; else dm.n = 0;
         dm.z2_tab = 0;
