@@ -314,3 +314,18 @@ def write_y4m(path, header_line, frames):
             f.write(b"FRAME\n")
             for p in planes:
                 f.write(np.ascontiguousarray(p).tobytes())
+
+
+def random_y4m_header(rng):
+    """a header line built from valid and damaged tokens in random order (always ends with a newline, at most 79 characters as the
+    reference's fgets buffer holds)"""
+    toks = []
+    pool = [lambda: f"W{rng.integers(0, 5000)}", lambda: f"H{rng.integers(0, 3000)}", lambda: f"F{rng.integers(0, 10 ** int(rng.integers(1, 10)))}:{rng.integers(0, 2000)}",
+            lambda: "I" + "ptb?x"[rng.integers(0, 5)], lambda: f"A{rng.integers(0, 300)}:{rng.integers(0, 300)}",
+            lambda: "C" + ["420", "420jpeg", "420mpeg2", "420paldv", "420p10", "422p10", "444p12", "mono", "mono16", "411", "420p9", "422", "444", "420p16", "420p14",
+                           "bogus", "", "420jpeg2", "4"][rng.integers(0, 19)],
+            lambda: "X" + "YSCSS=420JPEG"[: rng.integers(0, 13)], lambda: "", lambda: "Q7"]
+    for _ in range(int(rng.integers(1, 8))):
+        toks.append(pool[rng.integers(0, len(pool))]())
+    line = " " + " ".join(toks)
+    return line[:78] + "\n"

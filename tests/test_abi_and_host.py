@@ -301,6 +301,17 @@ def test_y4m_reader_host_side_equals_oracle_and_reference_fixture(pkg, tmp_path)
         for f in ("width", "height", "fr_n", "fr_d", "bit_depth", "interlaced", "chroma", "scan_type"):
             assert getattr(pi, f) == getattr(oi, f), (line, f)
         assert [pi.width, pi.height, pi.fr_n, pi.fr_d, pi.bit_depth, pi.interlaced] == exp[2:8]
+    rng = np.random.default_rng(248)
+    for trial in range(2000):                             # random headers: the product parser == the oracle's, field by field
+        line = svtlibs.random_y4m_header(rng)
+        oi = svtlibs.Y4mInfo()
+        orc = O.svt_oracle_y4m_parse_header(line.encode(), ctypes.byref(oi))
+        pi = pkg.Y4mInfo()
+        prc = lib.svt_hip_y4m_parse_header(line.encode(), ctypes.addressof(pi))
+        assert (orc == 0) == (prc == 0), line
+        if orc == 0:
+            for f in ("width", "height", "fr_n", "fr_d", "bit_depth", "interlaced", "chroma", "scan_type"):
+                assert getattr(pi, f) == getattr(oi, f), (line, f)
     rng = np.random.default_rng(5)
     for bd, token in ((8, "C420jpeg"), (10, "C420p10")):
         w, h = 22, 10

@@ -524,6 +524,19 @@ def test_y4m_header_vs_reference_application(tmp_path):
         if good:
             assert [info.width, info.height, info.fr_n, info.fr_d, info.bit_depth, info.interlaced] == out[2:8].tolist(), line
             assert pos == 9 + len(line) + 6        # signature + header line + "FRAME\n"
+    # random headers: valid and damaged tokens in any order
+    rng = np.random.default_rng(247)
+    path = str(tmp_path / "r.y4m")
+    for trial in range(300):
+        line = svtlibs.random_y4m_header(rng)
+        svtlibs.write_y4m(path, line, [(np.zeros(4, np.uint8),) * 3])
+        out = np.zeros(8, np.int32)
+        R.ref_y4m_header(path.encode(), ptr(out))
+        info = svtlibs.Y4mInfo()
+        rc = O.svt_oracle_y4m_parse_header(line.encode(), ctypes.byref(info))
+        assert (rc == 0) == (out[1] == 0), (line, rc, out)
+        if rc == 0:
+            assert [info.width, info.height, info.fr_n, info.fr_d, info.bit_depth, info.interlaced] == out[2:8].tolist(), line
     # not a y4m file
     p = str(tmp_path / "raw.yuv")
     open(p, "wb").write(b"\x10" * 64)
