@@ -59,7 +59,10 @@ class FramePass:
                 nc = min(side, 32) ** 2
                 pred = planes_pred[name]
                 recon = pred.clone()              # samples outside the full tiles keep the prediction, as in-place reconstruction would
-                g = {"name": name, "luma_size": S, "tx_size": ts, "tx_type": tt, "src": src, "src_stride": pw, "pred": pred, "pred_stride": pw,
+                # 2-D planes may be views into padded picture buffers (PictureInput): their own row strides; the stack form is dense
+                sst = src.stride(0) if src.dim() == 2 else pw
+                pst = pred.stride(0) if pred.dim() == 2 else pw
+                g = {"name": name, "luma_size": S, "tx_size": ts, "tx_type": tt, "src": src, "src_stride": sst, "pred": pred, "pred_stride": pst,
                      "recon": recon, "recon_stride": pw, "xy": torch.from_numpy(xy.view(np.int32)).to(dev),
                      "offsets": torch.from_numpy(offs.view(np.int32)).to(dev) if ts == 0 else None,
                      "iscan": torch.from_numpy(iscan).to(dev), "qcoeff": torch.empty((n, nc), dtype=torch.int32, device=dev),

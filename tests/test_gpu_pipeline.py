@@ -1,0 +1,55 @@
+"""GPU: the rows of SURVEY 8(f) chained on a y4m clip (tools/pipeline_y4m.py): picture input + decimation -> HME 0/1/2 -> full-pel ME
+(209 PUs) -> open-loop intra search -> encode pass, each stage reading the previous stage's device buffers.  The stages are pinned
+to the reference one by one elsewhere; this checks the GLUE - buffer geometry, strides, origins, vector units - with a clip whose
+motion is known: every picture is the previous one displaced by (4, 4) samples (a multiple of 4, so that the 1/4 and 1/16 pictures
+of consecutive frames are displaced copies as well), so interior SBs must find exactly that vector with SAD 0, at every PU shape."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_tool():
+    spec = importlib.util.spec_from_file_location("pipeline_y4m", os.path.join(ROOT, "tools", "pipeline_y4m.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_pipeline_finds_the_known_motion_and_is_deterministic(dsp, tmp_path):
+    tool = load_tool()
+    path = str(tmp_path / "pan.y4m")
+    w, h, nf = 448, 320, 4
+    tool.synthetic_clip(path, w, h, nf, pan=(4, 4))
+    digests = []
+    for rep in range(2):
+        p = tool.Pipeline(dsp, path)
+        outs = []
+        while True:
+            o = p.step()
+            if o is None:
+                break
+            outs.append(o)
+        assert len(outs) == nf and "me_mv" not in outs[0] and "me_mv" in outs[1]
+        for o in outs[1:]:
+            sad = o["me_sad"].cpu().numpy().view(np.uint32)
+            mv = o["me_mv"].cpu().numpy().view(np.uint32)
+            sbs = p.sb_xy.cpu().numpy()
+            # SBs whose 64x64 block and displaced match lie inside the picture (the borders are replicated samples, not the moving texture)
+            inner = [i for i, (x, y) in enumerate(sbs) if x + 64 + 4 <= w and y + 64 + 4 <= h]
+            assert len(inner) >= 12
+            for i in inner:
+                assert (sad[i] == 0).all(), (i, sad[i][:8])
+                assert ((mv[i] & 0xffff) == 4 * 4).all() and ((mv[i] >> 16) == 4 * 4).all(), (i, mv[i][:4])
+            # HME level 2 arrives at the same vector for those SBs
+            hm = o["hme_mv"].cpu().numpy()
+            assert all(tuple(hm[i]) == (4, 4) for i in inner), hm[inner[:6]]
+            assert o["enc_digest"][0] > 0
+        digests.append([tool.digest_of(o) for o in outs])
+        p.pi.close()
+    assert digests[0] == digests[1]

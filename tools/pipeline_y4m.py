@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""The hot path end to end on a y4m file (every row of SURVEY 8(f) working on the others' outputs), per frame:
+   picture input    file -> pinned -> HBM -> padded planes + 1/4 and 1/16 luma pictures   (frames.PictureInput, n4)
+   HME 0 / 1 / 2    every 64x64 SB against the previous picture's pyramid, vectors stay on the device   (svt_hip_hme_level_batch, n1)
+   full-pel ME      209 PUs per SB around the HME vector, 64x64 search area   (svt_hip_me_fullpel_search_batch, a11)
+   open-loop intra  every 8x8 ... 64x64 block, the reference's candidate lists   (svt_hip_ois_search_frame, n2)
+   encode pass      residual -> FwdTxfm2d -> quant / dequant -> InvTxfm2d -> recon, five CU sizes, luma + chroma   (svt_hip_encode_recon_frame, n3)
+The prediction of the encode pass is the previous source picture at zero motion (inter prediction itself is outside SURVEY 8).
+Prints frames/s of the whole chain (file reading and PCIe included) and a digest of every stage's outputs; with no file argument a
+synthetic moving-texture 1080p clip is written first.  usage: tools/pipeline_y4m.py [in.y4m] [--frames N]"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import __graft_entry__ as ge
+
+pkg = ge.load_package()
+from cidana_svt_av1_amd import frames
+
+
+def synthetic_clip(path, w, h, nf, seed=3, pan=(3, 1)):
+    """a textured picture panning by `pan` samples per frame: the motion search has something to find"""
+    rng = np.random.default_rng(seed)
+    dx, dy = pan
+    big = rng.integers(0, 256, (h + dy * nf + 64, w + dx * nf + 64)).astype(np.float32)
+    k = np.ones(5, np.float32) / 5
+    big = np.apply_along_axis(lambda r: np.convolve(r, k, "same"), 1, big)
+    big = np.apply_along_axis(lambda c: np.convolve(c, k, "same"), 0, big)
+    big = ((big - big.min()) / (big.max() - big.min()) * 255).astype(np.uint8)
+    with open(path, "wb") as f:
+        f.write(f"YUV4MPEG2 W{w} H{h} F30:1 Ip C420jpeg\n".encode())
+        for i in range(nf):
+            y = big[dy * i:dy * i + h, dx * i:dx * i + w]
+            f.write(b"FRAME\n")
+            f.write(np.ascontiguousarray(y).tobytes())
+            f.write(np.ascontiguousarray(y[::2, ::2]).tobytes())
+            f.write(np.ascontiguousarray(255 - y[::2, ::2]).tobytes())
+
+
+class Pipeline:
+    def __init__(self, dsp, path, qindex=100):
+        self.dsp = dsp
+        self.pi = frames.PictureInput(dsp, pkg, path, origin=(68, 68))
+        pi = self.pi
+        if pi.is16:
+            raise SystemExit("this tool runs the 8-bit chain")
+        dev = pi.planes[0].device
+        self.W, self.H, self.pad = pi.W, pi.H, pi.ox
+        W, H = self.W, self.H
+        sbs = [(x, y) for y in range(0, H, 64) for x in range(0, W, 64)]
+        self.nsb = len(sbs)
+        self.sb_xy = torch.tensor(sbs, dtype=torch.int32, device=dev)
+        # HME: per level the SB origins / sizes in that level's picture, and the level parameters (EbMotionEstimation.c:5689-6016)
+        # the search area of level 0 is split into 2 x 2 regions (EbMotionEstimation.c: number_hme_search_region_in_width / _height);
+        # each region's vector is refined by levels 1 and 2 and the best level-2 SAD wins, as MotionEstimateLcu does
+        self.hme = {}
+        hw = {0: (np.array([32, 32], np.uint16), np.array([16, 16], np.uint16)), 1: (np.array([16, 16], np.uint16), np.array([8, 8], np.uint16)),
+              2: (np.array([16, 16], np.uint16), np.array([8, 8], np.uint16))}
+        self.hme_geo = []
+        for level in (0, 1, 2):
+            sh = 2 - level
+            lw, lh, lpad = (W + (1 << sh) - 1) >> sh, (H + (1 << sh) - 1) >> sh, self.pad >> sh
+            org = torch.tensor([(x >> sh, y >> sh) for x, y in sbs], dtype=torch.int16, device=dev)
+            size = torch.tensor([(min(64, W - x) >> sh, min(64, H - y) >> sh) for x, y in sbs], dtype=torch.int16, device=dev)
+            self.hme_geo.append((org, size, lpad))
+            w_, h_ = hw[level]
+            for rw in (0, 1):
+                for rh in (0, 1):
+                    self.hme[(level, rw, rh)] = dsp.hme_level_params(level, w_, h_, rw, rh, int(w_.sum()), int(h_.sum()), 100, 100, lpad, lpad, lw, lh)
+        # full-pel ME: plane form, byte offsets of each SB's source block and of its search window's origin
+        self.stride = pi.planes[0].stride(0)
+        self.src_off = ((self.sb_xy[:, 1] + self.pad) * self.stride + self.sb_xy[:, 0] + self.pad).to(torch.int32)
+        self.SW = self.SH = 64
+        # open-loop intra search groups
+        self.ois_groups = []
+        for bsize in (8, 16, 32, 64):
+            blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
+            xy = torch.from_numpy(np.array([(y << 16) | x for x, y in blocks], np.uint32).view(np.int32)).to(dev)
+            modes, deltas = dsp.ois_candidates(bsize)
+            self.ois_groups.append((xy, bsize, modes, deltas))
+        qt = pkg.tables.quant_tables(8)
+        self.qrow = {k: v[qindex].copy() for k, v in qt.items()}
+        self.prev = None
+        self.fp = None
+
+    def interior(self, planes):
+        p = self.pad
+        return {"Y": planes[0][p:p + self.H, p:p + self.W], "U": planes[1][p // 2:p // 2 + self.H // 2, p // 2:p // 2 + self.W // 2],
+                "V": planes[2][p // 2:p // 2 + self.H // 2, p // 2:p // 2 + self.W // 2]}
+
+    def step(self):
+        dsp, pi, t = self.dsp, self.pi, torch
+        planes = pi.next()
+        if planes is None:
+            return None
+        out = {}
+        y = planes[0]
+        pic = y[self.pad:, self.pad:]
+        # open-loop intra search on the source picture
+        out["ois"] = dsp.ois_search_frame(pic, y.stride(0), self.W, self.H, self.ois_groups)
+        if self.prev is not None:
+            pyr_cur = {0: pi.sixteenth, 1: pi.quarter, 2: y}
+            best = mv = None
+            for rw in (0, 1):
+                for rh in (0, 1):
+                    centres = None
+                    for level in (0, 1, 2):
+                        org, size, lpad = self.hme_geo[level]
+                        cur, ref = pyr_cur[level], self.prev["pyr"][level]
+                        b, centres = dsp.hme_level(cur[lpad:, lpad:], cur.stride(0), ref[lpad:, lpad:], ref.stride(0), org, size, centres,
+                                                   1 if level == 1 else 0, self.hme[(level, rw, rh)])
+                    if best is None:
+                        best, mv = b, centres
+                    else:
+                        take = b < best                    # strict: the first region keeps ties
+                        best = t.where(take, b, best); mv = t.where(take[:, None], centres, mv)
+            out["hme_sad"], out["hme_mv"] = best, mv
+            # search-area origin per SB: centred on the HME vector, kept inside the padded reference picture
+            sx, sy = self.sb_xy[:, 0], self.sb_xy[:, 1]
+            ox = mv[:, 0].to(t.int32) - self.SW // 2
+            oy = mv[:, 1].to(t.int32) - self.SH // 2
+            ox = t.minimum(t.maximum(ox, -self.pad - sx), self.W + self.pad - (64 + self.SW - 1) - sx)
+            oy = t.minimum(t.maximum(oy, -self.pad - sy), self.H + self.pad - (64 + self.SH - 1) - sy)
+            origins = t.stack([ox, oy], dim=1).to(t.int16).contiguous()
+            ref_off = ((sy + oy + self.pad) * self.stride + sx + ox + self.pad).to(t.int32)
+            out["me_sad"], out["me_mv"] = dsp.me_fullpel_search(y, self.prev["planes"][0], self.SW, self.SH, origins=origins, nsq=True,
+                                                                src_stride=self.stride, src_offsets=self.src_off, ref_stride=self.stride,
+                                                                ref_offsets=ref_off, n=self.nsb)
+            # encode pass: source against the previous picture at zero motion (views into the padded buffers, no copies)
+            if self.fp is None:
+                self.fp = frames.FramePass(dsp, pkg, self.interior(planes), self.interior(self.prev["planes"]))
+            self.fp.run(self.qrow)
+            out["enc_digest"] = self.fp.digest()
+        # the buffers of this picture become the reference of the next (PictureInput overwrites its planes on the next call)
+        if self.prev is None:
+            self.prev = {"planes": tuple(p.clone() for p in planes), "pyr": {0: pi.sixteenth.clone(), 1: pi.quarter.clone(), 2: None}}
+            self.prev["pyr"][2] = self.prev["planes"][0]
+        else:
+            for d, s in zip(self.prev["planes"], planes):
+                d.copy_(s)
+            self.prev["pyr"][0].copy_(pi.sixteenth); self.prev["pyr"][1].copy_(pi.quarter)
+        return out
+
+
+def digest_of(out):
+    d = {}
+    for k, v in out.items():
+        if k == "ois":
+            d["ois_best_sum"] = int(sum(int(b.to(torch.int64).sum()) for _, b in v))
+            d["ois_dist_sum"] = int(sum(int(dd.to(torch.int64).sum()) for dd, _ in v))
+        elif k == "enc_digest":
+            d[k] = [int(x) for x in v.cpu().tolist()]
+        else:
+            d[k + "_sum"] = int((v.to(torch.int64) & 0xffffffff).sum())
+    return d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("file", nargs="?")
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--size", default="1920x1080")
+    a = ap.parse_args()
+    dsp = pkg.SvtHipDsp(0)
+    tmp = None
+    path = a.file
+    if path is None:
+        w, h = (int(v) for v in a.size.split("x"))
+        tmp = tempfile.mkdtemp(prefix="svt_pipe_")
+        path = os.path.join(tmp, "clip.y4m")
+        synthetic_clip(path, w, h, a.frames)
+    results = []
+    for rep in range(2):                                  # the second pass is timed (page cache, allocator, first-launch costs settled)
+        p = Pipeline(dsp, path)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n, last = 0, None
+        while True:
+            o = p.step()
+            if o is None:
+                break
+            last, n = o, n + 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        results.append((n, dt, digest_of(last)))
+        p.pi.close()
+    n, dt, dg = results[-1]
+    assert results[0][2] == dg, "the two passes disagree"
+    print(json.dumps({"file": os.path.basename(path), "picture": f"{p.W}x{p.H}", "frames": n, "seconds": round(dt, 4), "frames_per_s": round(n / dt, 1),
+                      "ms_per_frame": round(1e3 * dt / n, 3), "stages": "input + decimation, OIS (4 sizes), HME 0/1/2, ME 209 PUs 64x64 area, encode pass (5 sizes, YUV)",
+                      "last_frame_digest": dg, "device": dsp.device_name()}), flush=True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump({"frames": n, "seconds": dt, "frames_per_s": n / dt, "digest": dg}, open(os.path.join(ROOT, "gpurun_out", "pipeline.json"), "w"), indent=1)
+    if tmp:
+        os.remove(path); os.rmdir(tmp)
+
+
+if __name__ == "__main__":
+    main()
