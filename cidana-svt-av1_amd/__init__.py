@@ -115,6 +115,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
                                                           c_void_p, c_size_t, c_void_p]
     L.svt_hip_hme_level_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                           c_void_p, c_size_t, c_void_p]
+    L.svt_hip_hme_level_regions_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                                  c_void_p, c_void_p, c_size_t, c_void_p]
     L.svt_hip_hme_level_params.argtypes = [c_int, c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32,
                                            c_uint32, c_uint32, c_uint32, c_void_p]
     L.svt_hip_me_fullpel_search_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_void_p, c_uint32, c_size_t, c_void_p,
@@ -683,6 +685,20 @@ class SvtHipDsp:
                                                       self._p(sixteenth) if sixteenth is not None else None,
                                                       sixteenth.stride(0) if sixteenth is not None else 0, s_origin[0], s_origin[1],
                                                       self._stream()), "svt_hip_picture_decimate")
+
+    def hme_level_regions(self, src_pic, src_stride, ref_pic00, ref_stride, sb_origin, sb_size, centers, center_shift, params_list):
+        """hme_level for 1 .. 4 search regions in one launch (svt_hip_hme_level_regions_batch).  centers: int16 [regions, n, 2] or
+        None.  -> (best_sad int64 [regions, n], mv int16 [regions, n, 2])"""
+        t = self.torch
+        n, nr = sb_origin.shape[0], len(params_list)
+        arr = (self.HmeParams * nr)(*params_list)
+        best = t.zeros((nr, n), dtype=t.int64, device=sb_origin.device)
+        mv = t.zeros((nr, n, 2), dtype=t.int16, device=sb_origin.device)
+        self._check(self.lib.svt_hip_hme_level_regions_batch(self._p(src_pic), src_stride, self._p(ref_pic00), ref_stride, self._p(sb_origin),
+                                                             self._p(sb_size), self._p(centers) if centers is not None else None, center_shift,
+                                                             ctypes.addressof(arr), nr, self._p(best), self._p(mv), n, self._stream()),
+                    "svt_hip_hme_level_regions_batch")
+        return best, mv
 
     class IntraPos(ctypes.Structure):
         """svt_hip_intra_pos: where one prediction block sits (the arguments of av1_predict_intra_block, EbIntraPrediction.c:4078)"""

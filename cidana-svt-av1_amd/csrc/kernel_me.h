@@ -931,11 +931,20 @@ struct HmeParams {          // == svt_hip_hme_params (include/svt_hip_dsp.h)
         ref_height, round_down, mv_shift;
 };
 
+// Several search regions of one level in ONE launch (the reference splits a level's area into up to 2 x 2 regions and carries
+// each region's vector through the next levels): blockIdx.y = region, its parameter set from ps, its centres / results in
+// planes of ntasks entries ([region][task]).
+struct HmeParamSets { HmeParams p[4]; };
+
 __global__ __launch_bounds__(ME_THREADS) void hme_level_kernel(
     const uint8_t* __restrict__ src_pic, uint32_t src_stride, const uint8_t* __restrict__ ref_pic, uint32_t ref_stride,
     const int16_t* __restrict__ sb_origin /* [n][2] */, const uint16_t* __restrict__ sb_size /* [n][2] */,
-    const int16_t* __restrict__ centers /* [n][2] or NULL */, int center_shift, HmeParams p,
-    unsigned long long* __restrict__ best_sad, int16_t* __restrict__ mv /* [n][2] */, uint32_t wpitch, uint32_t ntasks) {
+    const int16_t* __restrict__ centers /* [regions][n][2] or NULL */, int center_shift, const HmeParamSets ps,
+    unsigned long long* __restrict__ best_sad /* [regions][n] */, int16_t* __restrict__ mv /* [regions][n][2] */, uint32_t wpitch, uint32_t ntasks) {
+    const HmeParams& p = ps.p[blockIdx.y];
+    if (centers) centers += (size_t)blockIdx.y * ntasks * 2;
+    best_sad += (size_t)blockIdx.y * ntasks;
+    mv += (size_t)blockIdx.y * ntasks * 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* s_src = reinterpret_cast<uint32_t*>(smem);            // [32 rows][16 dwords]: the block's even rows, zero-padded
     uint8_t* s_ref = smem + 32 * 64;

@@ -321,31 +321,50 @@ extern "C" int svt_hip_me_sb_search_planes_batch(const uint8_t* d_src_plane, uin
                              search_h, d_origins, x_origin, y_origin, d_best_sad, d_best_mv, nblocks, stream);
 }
 
-// one HME level for many SBs, search-area clipping on the device (include/svt_hip_dsp.h)
+// one HME level for many SBs, search-area clipping on the device; 1 .. 4 search regions per launch (include/svt_hip_dsp.h)
+extern "C" int svt_hip_hme_level_regions_batch(const uint8_t* d_src_pic, uint32_t src_stride, const uint8_t* d_ref_pic, uint32_t ref_stride,
+                                               const int16_t* d_sb_origin, const uint16_t* d_sb_size, const int16_t* d_centers,
+                                               int center_shift, const svt_hip_hme_params* params, int nregions, uint64_t* d_best_sad,
+                                               int16_t* d_mv, size_t ntasks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (ntasks == 0) return SVT_HIP_OK;
+    if (!d_src_pic || !d_ref_pic || !d_sb_origin || !d_sb_size || !params || !d_best_sad || !d_mv) return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    if (nregions < 1 || nregions > 4) return set_err(SVT_HIP_ERR_INVALID, "%d search regions (1..4)", nregions);
+    if (center_shift < 0 || center_shift > 2) return set_err(SVT_HIP_ERR_INVALID, "centre shift %d", center_shift);
+    if (ntasks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many tasks");
+    HmeParamSets hp;
+    static_assert(sizeof(HmeParams) == sizeof(svt_hip_hme_params), "layout");
+    memset(&hp, 0, sizeof(hp));
+    size_t lds = 0;
+    uint32_t wpitch = 0;
+    for (int r = 0; r < nregions; r++) {
+        const svt_hip_hme_params& P = params[r];
+        if (P.search_area_width < 1 || P.search_area_height < 1 || (P.round_down != 8 && P.round_down != 16) || P.mv_shift < 0 || P.mv_shift > 2 ||
+            P.ref_width < 1 || P.ref_height < 1)
+            return set_err(SVT_HIP_ERR_INVALID, "HME parameters: area %dx%d, round_down %d, mv_shift %d", P.search_area_width, P.search_area_height,
+                           P.round_down, P.mv_shift);
+        // the clipped area never exceeds the nominal one; blocks are at most 64 x 64 (32 compared rows)
+        const uint32_t win_w = 64 + (uint32_t)P.search_area_width - 1;
+        const uint32_t wp = ((win_w + 3) & ~3u) + 8;
+        if (wp > wpitch) wpitch = wp;
+        memcpy(&hp.p[r], &P, sizeof(HmeParams));
+    }
+    for (int r = 0; r < nregions; r++) {
+        const size_t need = 32 * 64 + (size_t)wpitch * ((uint32_t)params[r].search_area_height + 62);
+        if (need > lds) lds = need;
+    }
+    if (lds > 60 * 1024) return set_err(SVT_HIP_ERR_INVALID, "HME search window needs %zu B of LDS (> 60 KiB)", lds);
+    hipLaunchKernelGGL(hme_level_kernel, dim3((uint32_t)ntasks, (uint32_t)nregions), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src_pic, src_stride,
+                       d_ref_pic, ref_stride, d_sb_origin, d_sb_size, d_centers, center_shift, hp, (unsigned long long*)d_best_sad, d_mv, wpitch,
+                       (uint32_t)ntasks);
+    return launch_status("hme_level");
+}
 extern "C" int svt_hip_hme_level_batch(const uint8_t* d_src_pic, uint32_t src_stride, const uint8_t* d_ref_pic, uint32_t ref_stride,
                                        const int16_t* d_sb_origin, const uint16_t* d_sb_size, const int16_t* d_centers,
                                        int center_shift, const svt_hip_hme_params* params, uint64_t* d_best_sad, int16_t* d_mv,
                                        size_t ntasks, void* stream) {
-    if (int rc = require_init()) return rc;
-    if (ntasks == 0) return SVT_HIP_OK;
-    if (!d_src_pic || !d_ref_pic || !d_sb_origin || !d_sb_size || !params || !d_best_sad || !d_mv) return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
-    const svt_hip_hme_params& P = *params;
-    if (P.search_area_width < 1 || P.search_area_height < 1 || (P.round_down != 8 && P.round_down != 16) || P.mv_shift < 0 || P.mv_shift > 2 ||
-        center_shift < 0 || center_shift > 2 || P.ref_width < 1 || P.ref_height < 1)
-        return set_err(SVT_HIP_ERR_INVALID, "HME parameters: area %dx%d, round_down %d, mv_shift %d, centre shift %d", P.search_area_width,
-                       P.search_area_height, P.round_down, P.mv_shift, center_shift);
-    if (ntasks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many tasks");
-    // the clipped area never exceeds the nominal one; blocks are at most 64 x 64 (32 compared rows)
-    const uint32_t win_w = 64 + (uint32_t)P.search_area_width - 1, win_h = (uint32_t)P.search_area_height + 62;
-    const uint32_t wpitch = ((win_w + 3) & ~3u) + 8;
-    const size_t lds = 32 * 64 + (size_t)wpitch * win_h;
-    if (lds > 60 * 1024) return set_err(SVT_HIP_ERR_INVALID, "HME search window needs %zu B of LDS (> 60 KiB)", lds);
-    HmeParams hp;
-    static_assert(sizeof(HmeParams) == sizeof(svt_hip_hme_params), "layout");
-    memcpy(&hp, params, sizeof(hp));
-    hipLaunchKernelGGL(hme_level_kernel, dim3((uint32_t)ntasks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src_pic, src_stride, d_ref_pic, ref_stride,
-                       d_sb_origin, d_sb_size, d_centers, center_shift, hp, (unsigned long long*)d_best_sad, d_mv, wpitch, (uint32_t)ntasks);
-    return launch_status("hme_level");
+    return svt_hip_hme_level_regions_batch(d_src_pic, src_stride, d_ref_pic, ref_stride, d_sb_origin, d_sb_size, d_centers, center_shift, params, 1,
+                                           d_best_sad, d_mv, ntasks, stream);
 }
 
 // K6 in the reference's result layout, both result flavours, square or all 209 PUs (include/svt_hip_dsp.h)

@@ -372,6 +372,13 @@ int svt_hip_hme_level_batch(const uint8_t *d_src_pic, uint32_t src_stride, const
                             const int16_t *d_sb_origin, const uint16_t *d_sb_size, const int16_t *d_centers,
                             int center_shift, const svt_hip_hme_params *params, uint64_t *d_best_sad, int16_t *d_mv,
                             size_t ntasks, void *stream);
+/* The same for 1 .. 4 search regions of the level in ONE launch (the reference walks number_hme_search_region_in_width x
+ * _in_height regions per SB and carries each region's vector through the next levels, EbMotionEstimation.c:7700-7950):
+ * params[nregions]; d_centers / d_best_sad / d_mv are [region][task] planes (d_centers may be NULL at level 0). */
+int svt_hip_hme_level_regions_batch(const uint8_t *d_src_pic, uint32_t src_stride, const uint8_t *d_ref_pic,
+                                    uint32_t ref_stride, const int16_t *d_sb_origin, const uint16_t *d_sb_size,
+                                    const int16_t *d_centers, int center_shift, const svt_hip_hme_params *params, int nregions,
+                                    uint64_t *d_best_sad, int16_t *d_mv, size_t ntasks, void *stream);
 
 /* K6 with the encoder's own result rows: d_best_sad / d_best_mv hold, per SB, pu_pitch uint32 whose first 85 (nsq = 0)
  * or 209 (nsq != 0) entries are MeContext_t.p_sb_best_sad[list][ref][..] / p_sb_best_mv[..] in EbMeTierZeroPu order

@@ -85,6 +85,34 @@ def test_hme_three_levels_chained_on_device_vs_oracle(dsp):
             centers = mv
 
 
+def test_hme_regions_in_one_launch_equal_per_region_calls(dsp):
+    """svt_hip_hme_level_regions_batch: the 2 x 2 search regions of a level in ONE launch, chained through the three levels with
+    [region][task] centre planes, against one svt_hip_hme_level_batch call per region and level"""
+    rng = np.random.default_rng(5)
+    W2, H2 = 448, 256
+    pics = {}
+    for level, (W, H, pad) in {2: (W2, H2, 68), 1: (W2 // 2, H2 // 2, 34), 0: (W2 // 4, H2 // 4, 17)}.items():
+        stride = W + 2 * pad + 5
+        pics[level] = (dev(rng.integers(0, 256, (H, W), dtype=np.uint8)), dev(rng.integers(0, 256, (H + 2 * pad, stride), dtype=np.uint8)), W, H, pad, stride)
+    sbs = [(x, y, min(64, W2 - x), min(64, H2 - y)) for y in range(0, H2, 64) for x in range(0, W2, 64)]
+    hme = {0: (np.array([32, 32], np.uint16), np.array([16, 16], np.uint16)), 1: (np.array([16, 16], np.uint16), np.array([8, 8], np.uint16)),
+           2: (np.array([16, 16], np.uint16), np.array([8, 8], np.uint16))}
+    regions = [(rw, rh) for rw in (0, 1) for rh in (0, 1)]
+    c_all, c_each = None, [None] * 4
+    for level in (0, 1, 2):
+        src, ref, W, H, pad, stride = pics[level]
+        sh = 2 - level
+        org = dev(np.array([(x >> sh, y >> sh) for (x, y, w, h) in sbs], np.int16)); size = dev(np.array([(w >> sh, h >> sh) for (x, y, w, h) in sbs], np.int16))
+        hw, hh = hme[level]
+        prm = [dsp.hme_level_params(level, hw, hh, rw, rh, int(hw.sum()), int(hh.sum()), 100, 100, pad, pad, W, H) for rw, rh in regions]
+        ref00 = ref.view(-1)[pad * stride + pad:]
+        cs = 1 if level == 1 else 0
+        b_all, c_all = dsp.hme_level_regions(src, W, ref00, stride, org, size, c_all, cs, prm)
+        for r in range(4):
+            b, c_each[r] = dsp.hme_level(src, W, ref00, stride, org, size, c_each[r], cs, prm[r])
+            assert torch.equal(b, b_all[r]) and torch.equal(c_each[r], c_all[r]), (level, r)
+
+
 def test_hme_argument_errors(dsp, pkg):
     p = dsp.HmeParams()
     z = torch.zeros((1, 2), dtype=torch.int16, device="cuda")

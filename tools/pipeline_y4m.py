@@ -109,20 +109,18 @@ class Pipeline:
         out["ois"] = dsp.ois_search_frame(pic, y.stride(0), self.W, self.H, self.ois_groups)
         if self.prev is not None:
             pyr_cur = {0: pi.sixteenth, 1: pi.quarter, 2: y}
-            best = mv = None
-            for rw in (0, 1):
-                for rh in (0, 1):
-                    centres = None
-                    for level in (0, 1, 2):
-                        org, size, lpad = self.hme_geo[level]
-                        cur, ref = pyr_cur[level], self.prev["pyr"][level]
-                        b, centres = dsp.hme_level(cur[lpad:, lpad:], cur.stride(0), ref[lpad:, lpad:], ref.stride(0), org, size, centres,
-                                                   1 if level == 1 else 0, self.hme[(level, rw, rh)])
-                    if best is None:
-                        best, mv = b, centres
-                    else:
-                        take = b < best                    # strict: the first region keeps ties
-                        best = t.where(take, b, best); mv = t.where(take[:, None], centres, mv)
+            # the four regions of a level in one launch, three launches per picture; the best level-2 SAD wins (strict: the first
+            # region keeps ties, as the reference's region loop does)
+            centres = None
+            for level in (0, 1, 2):
+                org, size, lpad = self.hme_geo[level]
+                cur, ref = pyr_cur[level], self.prev["pyr"][level]
+                b4, centres = dsp.hme_level_regions(cur[lpad:, lpad:], cur.stride(0), ref[lpad:, lpad:], ref.stride(0), org, size, centres,
+                                                    1 if level == 1 else 0, [self.hme[(level, rw, rh)] for rw in (0, 1) for rh in (0, 1)])
+            best, mv = b4[0], centres[0]
+            for r in (1, 2, 3):
+                take = b4[r] < best
+                best = t.where(take, b4[r], best); mv = t.where(take[:, None], centres[r], mv)
             out["hme_sad"], out["hme_mv"] = best, mv
             # search-area origin per SB: centred on the HME vector, kept inside the padded reference picture
             sx, sy = self.sb_xy[:, 0], self.sb_xy[:, 1]
