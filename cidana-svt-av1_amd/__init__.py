@@ -137,6 +137,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_picture_import.argtypes = [c_void_p, c_uint32, c_uint32, c_int, c_int, c_int, c_void_p, c_uint32, c_void_p, c_uint32, c_void_p,
                                          c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]
     L.svt_hip_picture_pad.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_void_p]
+    L.svt_hip_picture_luma8.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, c_int, c_void_p]
     L.svt_hip_picture_decimate.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_uint32, c_uint32, c_uint32, c_void_p, c_uint32,
                                            c_uint32, c_uint32, c_void_p]
     return L
@@ -675,6 +676,11 @@ class SvtHipDsp:
         """generate_padding{,16_bit} in place on a 2-D buffer tensor [height + 2 pad_h, stride] (svt_hip_picture_pad)"""
         self._check(self.lib.svt_hip_picture_pad(self._p(buf), buf.stride(0), width, height, pad_w, pad_h, int(buf.dtype != self.torch.uint8),
                                                  self._stream()), "svt_hip_picture_pad")
+
+    def picture_luma8(self, plane16, out8, cols, rows, bd=10):
+        """the 8-bit plane (v >> (bd - 8)) of a 16-bit padded plane buffer, buffer to buffer (svt_hip_picture_luma8)"""
+        self._check(self.lib.svt_hip_picture_luma8(self._p(plane16), plane16.stride(0), self._p(out8), out8.stride(0), cols, rows, bd, self._stream()),
+                    "svt_hip_picture_luma8")
 
     def picture_decimate(self, luma_origin, luma_stride, width, height, quarter=None, q_origin=(0, 0), sixteenth=None, s_origin=(0, 0)):
         """DecimateInputPicture: luma_origin = tensor view whose data_ptr() is the luma picture's origin sample; quarter / sixteenth:

@@ -113,4 +113,28 @@ __global__ __launch_bounds__(256) void picture_decimate_kernel(const uint8_t* __
     else pic_decim_chunk<2>(out, luma + (size_t)cy * 2 * luma_stride, x0, (int)d.ox, (int)d.w, full_w, luma_w);
 }
 
+// The 8-bit picture the analysis stages (HME, ME, open-loop intra search) read when the input is deeper: the reference keeps a
+// 10-bit picture as an 8-bit plane (the samples' top 8 bits) + a 2-bit plane and searches on the former (EbPictureBufferDesc:
+// buffer_y / bufferBitIncY; unpack in EbPackUnPack_C.c).  Here the picture is 16-bit samples, so the 8-bit plane is v >> (bd - 8),
+// over the whole padded buffer (borders included: replication commutes with the shift).  16 samples per lane.
+__global__ __launch_bounds__(256) void picture_luma8_kernel(const uint16_t* __restrict__ in, uint32_t in_stride, uint8_t* __restrict__ out,
+                                                            uint32_t out_stride, int cols, int shift) {
+    const int y = (int)blockIdx.y, x0 = (int)(blockIdx.x * 256u + threadIdx.x) * 16;
+    if (x0 >= cols) return;
+    const uint16_t* src = in + (size_t)y * in_stride + x0;
+    uint8_t* dst = out + (size_t)y * out_stride + x0;
+    if (x0 + 16 <= cols) {
+        uint32_t v[8], o[4];
+        __builtin_memcpy(v, src, 32);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t a = v[2 * q], b = v[2 * q + 1];
+            o[q] = (((a & 0xffffu) >> shift) & 0xffu) | ((((a >> 16) >> shift) & 0xffu) << 8) | ((((b & 0xffffu) >> shift) & 0xffu) << 16) | (((b >> 16) >> shift) << 24);
+        }
+        __builtin_memcpy(dst, o, 16);
+    } else {
+        for (int k = 0; x0 + k < cols; k++) dst[k] = (uint8_t)(src[k] >> shift);
+    }
+}
+
 }  // namespace svtdev

@@ -193,6 +193,18 @@ extern "C" int svt_hip_picture_pad(void* d_buf, uint32_t stride, uint32_t width,
     return launch_status("picture_pad");
 }
 
+extern "C" int svt_hip_picture_luma8(const uint16_t* d_in, uint32_t in_stride, uint8_t* d_out, uint32_t out_stride, uint32_t cols, uint32_t rows,
+                                     int bd, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (!d_in || !d_out) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (bd < 9 || bd > 16) return set_err(SVT_HIP_ERR_INVALID, "bit depth %d", bd);
+    if (cols == 0 || rows == 0 || rows > 65535) return set_err(SVT_HIP_ERR_INVALID, "buffer %ux%u", cols, rows);
+    if (in_stride < cols || out_stride < cols) return set_err(SVT_HIP_ERR_INVALID, "stride below %u columns", cols);
+    hipLaunchKernelGGL(picture_luma8_kernel, dim3(((cols + 15) / 16 + 255) / 256, rows), dim3(256), 0, (hipStream_t)stream, d_in, in_stride, d_out,
+                       out_stride, (int)cols, bd - 8);
+    return launch_status("picture_luma8");
+}
+
 extern "C" int svt_hip_picture_decimate(const uint8_t* d_luma, uint32_t luma_stride, uint32_t width, uint32_t height,
                                         uint8_t* d_quarter, uint32_t q_stride, uint32_t q_origin_x, uint32_t q_origin_y,
                                         uint8_t* d_sixteenth, uint32_t s_stride, uint32_t s_origin_x, uint32_t s_origin_y, void* stream) {

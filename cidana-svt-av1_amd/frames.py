@@ -143,7 +143,10 @@ class PictureInput:
         self.planes = (plane(self.W, self.H, self.ox, self.oy), plane(self.W >> 1, self.H >> 1, self.ox >> 1, self.oy >> 1),
                        plane(self.W >> 1, self.H >> 1, self.ox >> 1, self.oy >> 1))
         self.quarter = self.sixteenth = None
-        if with_decimation and not self.is16:
+        # a deeper picture's analysis plane: its samples' top 8 bits (what the reference's HME / ME / intra search read), same geometry
+        self.luma8 = torch.empty(self.planes[0].shape, dtype=torch.uint8, device=device) if self.is16 else None
+        self.bd = i.bit_depth
+        if with_decimation:
             self.q_origin = (self.ox >> 1, self.oy >> 1)
             self.s_origin = (self.ox >> 2, self.oy >> 2)
             qw, qh, sw, sh = (self.W + 1) // 2, (self.H + 1) // 2, (self.W + 3) // 4, (self.H + 3) // 4
@@ -172,8 +175,10 @@ class PictureInput:
         cur.wait_event(self.copied[slot])
         self.dsp.picture_import(self.stage[slot], self.w, self.h, self.planes, self.ox, self.oy, self.pad_right, self.pad_bottom)
         self.consumed[slot].record(cur)
+        if self.luma8 is not None:
+            self.dsp.picture_luma8(self.planes[0], self.luma8, self.W + 2 * self.ox, self.H + 2 * self.oy, self.bd)
         if self.quarter is not None:
-            y = self.planes[0]
+            y = self.luma8 if self.luma8 is not None else self.planes[0]
             self.dsp.picture_decimate(y[self.oy:, self.ox:], y.stride(0), self.W, self.H, self.quarter, self.q_origin, self.sixteenth, self.s_origin)
         self.slot ^= 1
         self.pending = self._fetch(self.slot)             # overlaps with the kernels just enqueued

@@ -776,6 +776,11 @@ int svt_hip_picture_import(const void *d_frame, uint32_t width, uint32_t height,
  * EbEncDecProcess.c:1040-1100): d_buf = first sample of the buffer, picture at (pad_w, pad_h) */
 int svt_hip_picture_pad(void *d_buf, uint32_t stride, uint32_t width, uint32_t height, uint32_t pad_w, uint32_t pad_h,
                         int is_16bit, void *stream);
+/* The 8-bit plane of a deeper picture, v >> (bd - 8): what the reference keeps as buffer_y next to its bit-increment plane and
+ * what its HME / ME / open-loop intra search read; un_pack8_bit_data (C_DEFAULT/EbPackUnPack_C.c:152-175, bd = 10).  Whole padded buffer:
+ * cols x rows samples from d_in (16-bit) to d_out (8-bit). */
+int svt_hip_picture_luma8(const uint16_t *d_in, uint32_t in_stride, uint8_t *d_out, uint32_t out_stride, uint32_t cols,
+                          uint32_t rows, int bd, void *stream);
 /* DecimateInputPicture (EbPictureAnalysisProcess.c:4907-4958): Decimation2D (:170) at step 2 (quarter) and 4 (sixteenth) of
  * the luma picture at d_luma (its ORIGIN sample), each followed by generate_padding of the decimated buffer; either output may
  * be NULL.  d_quarter / d_sixteenth = first sample of the buffer. */

@@ -6,6 +6,7 @@
  *   svt_oracle_pad_input_picture  pad_input_picture (Source/Lib/Common/Codec/EbMcp.c:273-317)
  *   svt_oracle_generate_padding   generate_padding / generate_padding16_bit (EbMcp.c:176-267)
  *   svt_oracle_decimation_2d      Decimation2D (EbPictureAnalysisProcess.c:170-195)
+ *   svt_oracle_unpack8            un_pack8_bit_data (C_DEFAULT/EbPackUnPack_C.c:152-175)
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -120,4 +121,10 @@ void svt_oracle_decimation_2d(const uint8_t *in, uint32_t in_stride, uint32_t w,
         in += (size_t)in_stride << (step >> 1);
         out += out_stride;
     }
+}
+
+/* C_DEFAULT/EbPackUnPack_C.c:152-175: the 8-bit plane of a 10-bit picture (the reference's shift is the literal 2) */
+void svt_oracle_unpack8(const uint16_t *in, uint32_t in_stride, uint8_t *out, uint32_t out_stride, uint32_t w, uint32_t h) {
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) out[(size_t)y * out_stride + x] = (uint8_t)(in[(size_t)y * in_stride + x] >> 2);
 }

@@ -6,6 +6,7 @@
  *   ref_generate_padding   generate_padding / generate_padding16_bit (Source/Lib/Common/Codec/EbMcp.c:176-267)
  *   ref_pad_input_picture  pad_input_picture (EbMcp.c:273-317)
  *   ref_decimation_2d      Decimation2D (EbPictureAnalysisProcess.c:170-195)
+ *   ref_unpack8            un_pack8_bit_data (C_DEFAULT/EbPackUnPack_C.c:152-175)
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -22,6 +23,9 @@ void pad_input_picture(uint8_t *src_pic, uint32_t src_stride, uint32_t original_
                        uint32_t pad_right, uint32_t pad_bottom);
 void Decimation2D(uint8_t *input_samples, uint32_t input_stride, uint32_t input_area_width, uint32_t input_area_height,
                   uint8_t *decimSamples, uint32_t decimStride, uint32_t decimStep);
+
+void un_pack8_bit_data(uint16_t *in16_bit_buffer, uint32_t in_stride, uint8_t *out8_bit_buffer, uint32_t out8_stride, uint32_t width,
+                       uint32_t height);
 
 /* out[0..7] = is_y4m, rc, width, height, fr_n, fr_d, bit depth, interlaced; returns the file offset after the header */
 long ref_y4m_header(const char *path, int32_t *out) {
@@ -57,4 +61,7 @@ void ref_pad_input_picture(uint8_t *pic, uint32_t stride, uint32_t w, uint32_t h
 }
 void ref_decimation_2d(uint8_t *in, uint32_t in_stride, uint32_t w, uint32_t h, uint8_t *out, uint32_t out_stride, uint32_t step) {
     Decimation2D(in, in_stride, w, h, out, out_stride, step);
+}
+void ref_unpack8(uint16_t *in, uint32_t in_stride, uint8_t *out, uint32_t out_stride, uint32_t w, uint32_t h) {
+    un_pack8_bit_data(in, in_stride, out, out_stride, w, h);
 }

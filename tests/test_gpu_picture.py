@@ -102,6 +102,19 @@ def test_decimation_vs_oracle_1080p(dsp):
     assert np.array_equal(q.cpu().numpy(), exp[0]) and np.array_equal(s.cpu().numpy(), exp[1])
 
 
+def test_luma8_plane_vs_oracle(dsp):
+    """svt_hip_picture_luma8 == un_pack8_bit_data (through the oracle, pinned to the reference in test_oracle_vs_ref.py)"""
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(3)
+    for (w, h) in ((1, 1), (15, 3), (16, 2), (33, 9), (200, 50), (2056, 20)):
+        src = rng.integers(0, 1024, (h, w + 7)).astype(np.uint16)
+        exp = np.full((h, w + 9), 0x66, np.uint8)
+        O.svt_oracle_unpack8(ptr(src), w + 7, ptr(exp), w + 9, w, h)
+        out = dev(np.full((h, w + 9), 0x66, np.uint8))
+        dsp.picture_luma8(as_t(src), out, w, h, 10)
+        assert np.array_equal(out.cpu().numpy(), exp), (w, h)
+
+
 def test_bad_arguments_are_errors(dsp, pkg):
     buf = torch.zeros((20, 16), dtype=torch.uint8, device="cuda")
     fr = torch.zeros(64, dtype=torch.uint8, device="cuda")
@@ -144,8 +157,10 @@ def test_y4m_file_through_picture_input(dsp, pkg, tmp_path, bd):
             O.svt_oracle_generate_padding(ptr(e), stride, pw + ppr, ph + ppb, po, po, es)
             fw = pw + ppr + 2 * po
             assert np.array_equal(got[:, :fw], e[:, :fw]), (n, i)
-        if bd == 8:
-            ypad = back(planes[0], dt)
+        if bd == 10:                                   # the analysis plane: top 8 bits of the padded luma buffer
+            assert np.array_equal(pi.luma8.cpu().numpy()[:, :w + 6 + 136], (back(planes[0], dt)[:, :w + 6 + 136] >> 2).astype(np.uint8))
+        if True:
+            ypad = back(planes[0], dt) if bd == 8 else pi.luma8.cpu().numpy()
             W, H = w + 6, h + 4
             for step, buf, o in ((2, pi.quarter, 34), (4, pi.sixteenth, 17)):
                 got = buf.cpu().numpy()

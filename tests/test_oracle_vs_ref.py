@@ -564,6 +564,13 @@ def test_padding_and_decimation_vs_reference(is16):
         xx = np.clip(np.arange(w + 2 * pw) - pw, 0, w - 1)
         assert np.array_equal(a[:, :w + 2 * pw], a[ph:ph + h, pw:pw + w][np.ix_(yy, xx)])
     if is16:
+        for trial in range(10):                            # un_pack8_bit_data: the 8-bit plane of a 10-bit picture
+            w, h = int(rng.integers(1, 90)), int(rng.integers(1, 40))
+            src = rng.integers(0, 1024, (h, w + 3)).astype(np.uint16)
+            a = np.full((h, w + 5), 9, np.uint8); b = a.copy()
+            R.ref_unpack8(ptr(src), w + 3, ptr(a), w + 5, w, h)
+            O.svt_oracle_unpack8(ptr(src), w + 3, ptr(b), w + 5, w, h)
+            assert np.array_equal(a, b) and np.array_equal(a[:, :w], (src[:, :w] >> 2).astype(np.uint8))
         return
     for trial in range(40):
         w, h = int(rng.integers(1, 70)), int(rng.integers(1, 50))
