@@ -49,7 +49,29 @@ def test_pipeline_finds_the_known_motion_and_is_deterministic(dsp, tmp_path):
             # HME level 2 arrives at the same vector for those SBs
             hm = o["hme_mv"].cpu().numpy()
             assert all(tuple(hm[i]) == (4, 4) for i in inner), hm[inner[:6]]
-            assert o["enc_digest"][0] > 0
+            assert tool.digest_of(o)["enc_digest"][0] > 0
         digests.append([tool.digest_of(o) for o in outs])
         p.pi.close()
     assert digests[0] == digests[1]
+
+
+def test_pipeline_as_a_hip_graph_equals_the_eager_chain(dsp, tmp_path):
+    """the per-picture analysis captured once and replayed == issuing every launch from Python"""
+    tool = load_tool()
+    path = str(tmp_path / "pan.y4m")
+    tool.synthetic_clip(path, 320, 192, 6, pan=(4, 4))
+    got = []
+    for use_graph in (False, True):
+        p = tool.Pipeline(dsp, path, use_graph=use_graph)
+        d = []
+        while True:
+            o = p.step()
+            if o is None:
+                break
+            torch.cuda.synchronize()
+            d.append(tool.digest_of(o))
+        assert use_graph == (p.graph is not None)
+        got.append(d)
+        p.pi.close()
+        del p
+    assert got[0] == got[1] and len(got[0]) == 6
