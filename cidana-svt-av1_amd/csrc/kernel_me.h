@@ -996,26 +996,43 @@ __global__ __launch_bounds__(ME_THREADS) void hme_level_kernel(
     unsigned long long best = ~0ull;
     const int ncand = saw * sah;
     const int bq = (sbw + 3) >> 2;                                    // dwords per block row
-    for (int cand = tid; cand < ncand; cand += ME_THREADS) {
-        const int ys = cand / saw, xs = cand - ys * saw;
-        const unsigned sh = (unsigned)(xs & 3);
-        unsigned acc = 0;
-        for (int r = 0; r < hh; r++) {
-            const uint32_t* rrow = reinterpret_cast<const uint32_t*>(s_ref + (size_t)(ys + 2 * r) * wpitch) + (xs >> 2);
-            const uint32_t* srow = s_src + r * 16;
-            uint32_t lo = rrow[0];
-            for (int q = 0; q < bq; q++) {
-                const uint32_t hi = rrow[q + 1];                      // wpitch leaves 8 spare bytes per row
-                uint32_t rv = __builtin_amdgcn_alignbyte(hi, lo, sh);
-                const int rem = sbw - 4 * q;
-                if (rem < 4) rv &= (1u << (8 * rem)) - 1;             // ragged last dword: the source side is zero-padded
-                acc = __builtin_amdgcn_sad_u8(srow[q], rv, acc);
-                lo = hi;
+    // whole SBs of the three levels (16x16 / 32x32 / 64x64: the block size is the same for every lane of the workgroup) take an
+    // unrolled row body - the general loop's trip counts are run-time values, each LDS read waits for the one before it
+    auto search = [&](auto bq_c) {
+        constexpr int BQ = decltype(bq_c)::value;                     // dwords per block row; 0 = run-time width (ragged allowed)
+        for (int cand = tid; cand < ncand; cand += ME_THREADS) {
+            const int ys = cand / saw, xs = cand - ys * saw;
+            const unsigned sh = (unsigned)(xs & 3);
+            unsigned acc = 0;
+            for (int r = 0; r < hh; r++) {
+                const uint32_t* rrow = reinterpret_cast<const uint32_t*>(s_ref + (size_t)(ys + 2 * r) * wpitch) + (xs >> 2);
+                const uint32_t* srow = s_src + r * 16;
+                if constexpr (BQ > 0) {
+                    uint32_t rw[BQ + 1];
+#pragma unroll
+                    for (int q = 0; q <= BQ; q++) rw[q] = rrow[q];    // wpitch leaves 8 spare bytes per row
+#pragma unroll
+                    for (int q = 0; q < BQ; q++) acc = __builtin_amdgcn_sad_u8(srow[q], __builtin_amdgcn_alignbyte(rw[q + 1], rw[q], sh), acc);
+                } else {
+                    uint32_t lo = rrow[0];
+                    for (int q = 0; q < bq; q++) {
+                        const uint32_t hi = rrow[q + 1];
+                        uint32_t rv = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                        const int rem = sbw - 4 * q;
+                        if (rem < 4) rv &= (1u << (8 * rem)) - 1;     // ragged last dword: the source side is zero-padded
+                        acc = __builtin_amdgcn_sad_u8(srow[q], rv, acc);
+                        lo = hi;
+                    }
+                }
             }
+            const unsigned long long key = ((unsigned long long)acc << 32) | (unsigned)cand;
+            best = key < best ? key : best;
         }
-        const unsigned long long key = ((unsigned long long)acc << 32) | (unsigned)cand;
-        best = key < best ? key : best;
-    }
+    };
+    if (sbw == 16) search(std::integral_constant<int, 4>{});
+    else if (sbw == 32) search(std::integral_constant<int, 8>{});
+    else if (sbw == 64) search(std::integral_constant<int, 16>{});
+    else search(std::integral_constant<int, 0>{});
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const unsigned long long o = __shfl_xor(best, m, 64);
