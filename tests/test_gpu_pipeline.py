@@ -21,11 +21,12 @@ def load_tool():
     return m
 
 
-def test_pipeline_finds_the_known_motion_and_is_deterministic(dsp, tmp_path):
+@pytest.mark.parametrize("bd", [8, 10])
+def test_pipeline_finds_the_known_motion_and_is_deterministic(dsp, tmp_path, bd):
     tool = load_tool()
     path = str(tmp_path / "pan.y4m")
     w, h, nf = 448, 320, 4
-    tool.synthetic_clip(path, w, h, nf, pan=(4, 4))
+    tool.synthetic_clip(path, w, h, nf, pan=(4, 4), bd=bd)
     digests = []
     for rep in range(2):
         p = tool.Pipeline(dsp, path)

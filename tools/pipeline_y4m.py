@@ -27,23 +27,24 @@ pkg = ge.load_package()
 from cidana_svt_av1_amd import frames
 
 
-def synthetic_clip(path, w, h, nf, seed=3, pan=(3, 1)):
-    """a textured picture panning by `pan` samples per frame: the motion search has something to find"""
+def synthetic_clip(path, w, h, nf, seed=3, pan=(3, 1), bd=8):
+    """a textured picture panning by `pan` samples per frame: the motion search has something to find (bd 8, or 10 as 16-bit samples)"""
     rng = np.random.default_rng(seed)
     dx, dy = pan
     big = rng.integers(0, 256, (h + dy * nf + 64, w + dx * nf + 64)).astype(np.float32)
     k = np.ones(5, np.float32) / 5
     big = np.apply_along_axis(lambda r: np.convolve(r, k, "same"), 1, big)
     big = np.apply_along_axis(lambda c: np.convolve(c, k, "same"), 0, big)
-    big = ((big - big.min()) / (big.max() - big.min()) * 255).astype(np.uint8)
+    top = (1 << bd) - 1
+    big = ((big - big.min()) / (big.max() - big.min()) * top).astype(np.uint8 if bd == 8 else np.dtype("<u2"))
     with open(path, "wb") as f:
-        f.write(f"YUV4MPEG2 W{w} H{h} F30:1 Ip C420jpeg\n".encode())
+        f.write(f"YUV4MPEG2 W{w} H{h} F30:1 Ip {'C420jpeg' if bd == 8 else 'C420p10'}\n".encode())
         for i in range(nf):
             y = big[dy * i:dy * i + h, dx * i:dx * i + w]
             f.write(b"FRAME\n")
             f.write(np.ascontiguousarray(y).tobytes())
             f.write(np.ascontiguousarray(y[::2, ::2]).tobytes())
-            f.write(np.ascontiguousarray(255 - y[::2, ::2]).tobytes())
+            f.write(np.ascontiguousarray(top - y[::2, ::2]).tobytes())
 
 
 class Pipeline:
@@ -52,8 +53,8 @@ class Pipeline:
         self.use_graph, self.graph, self.graph_out, self.count = use_graph, None, None, 0
         self.pi = frames.PictureInput(dsp, pkg, path, origin=(68, 68))
         pi = self.pi
-        if pi.is16:
-            raise SystemExit("this tool runs the 8-bit chain")
+        # a 10-bit clip: the analysis stages read the 8-bit plane (the samples' top 8 bits, as in the reference), the encode pass the
+        # 16-bit samples at bd 10
         dev = pi.planes[0].device
         self.W, self.H, self.pad = pi.W, pi.H, pi.ox
         W, H = self.W, self.H
@@ -88,7 +89,7 @@ class Pipeline:
             xy = torch.from_numpy(np.array([(y << 16) | x for x, y in blocks], np.uint32).view(np.int32)).to(dev)
             modes, deltas = dsp.ois_candidates(bsize)
             self.ois_groups.append((xy, bsize, modes, deltas))
-        qt = pkg.tables.quant_tables(8)
+        qt = pkg.tables.quant_tables(10 if pi.is16 else 8)
         self.qrow = {k: v[qindex].copy() for k, v in qt.items()}
         self.prev = None
         self.fp = None
@@ -102,7 +103,7 @@ class Pipeline:
         """every stage after the picture import, on the current stream; reads self.prev, returns the stages' output tensors"""
         dsp, pi, t = self.dsp, self.pi, torch
         out = {}
-        y = planes[0]
+        y = pi.luma8 if pi.is16 else planes[0]             # the plane HME / ME / the intra search read
         pic = y[self.pad:, self.pad:]
         # open-loop intra search on the source picture
         out["ois"] = dsp.ois_search_frame(pic, y.stride(0), self.W, self.H, self.ois_groups)
@@ -129,18 +130,20 @@ class Pipeline:
             oy = t.minimum(t.maximum(oy, -self.pad - sy), self.H + self.pad - (64 + self.SH - 1) - sy)
             origins = t.stack([ox, oy], dim=1).to(t.int16).contiguous()
             ref_off = ((sy + oy + self.pad) * self.stride + sx + ox + self.pad).to(t.int32)
-            out["me_sad"], out["me_mv"] = dsp.me_fullpel_search(y, self.prev["planes"][0], self.SW, self.SH, origins=origins, nsq=True,
+            out["me_sad"], out["me_mv"] = dsp.me_fullpel_search(y, self.prev["pyr"][2], self.SW, self.SH, origins=origins, nsq=True,
                                                                 src_stride=self.stride, src_offsets=self.src_off, ref_stride=self.stride,
                                                                 ref_offsets=ref_off, n=self.nsb)
             # encode pass: source against the previous picture at zero motion (views into the padded buffers, no copies)
             if self.fp is None:
-                self.fp = frames.FramePass(dsp, pkg, self.interior(planes), self.interior(self.prev["planes"]))
+                self.fp = frames.FramePass(dsp, pkg, self.interior(planes), self.interior(self.prev["planes"]), is_16bit=pi.is16)
             self.fp.run(self.qrow)
             out["enc"] = self.fp                               # outputs stay in the pass's buffers; digest_of() sums them on request
             # the buffers of this picture become the reference of the next (PictureInput overwrites its planes on the next call)
             for d, s in zip(self.prev["planes"], planes):
                 d.copy_(s)
             self.prev["pyr"][0].copy_(pi.sixteenth); self.prev["pyr"][1].copy_(pi.quarter)
+            if pi.is16:
+                self.prev["pyr"][2].copy_(pi.luma8)
         return out
 
     def step(self):
@@ -154,7 +157,7 @@ class Pipeline:
         if self.prev is None:                              # first picture: nothing to search against yet
             out = self.analyse(planes)
             self.prev = {"planes": tuple(p.clone() for p in planes), "pyr": {0: self.pi.sixteenth.clone(), 1: self.pi.quarter.clone(), 2: None}}
-            self.prev["pyr"][2] = self.prev["planes"][0]
+            self.prev["pyr"][2] = self.pi.luma8.clone() if self.pi.is16 else self.prev["planes"][0]
             return out
         if not self.use_graph or self.count == 2:
             return self.analyse(planes)
@@ -190,6 +193,7 @@ def main():
     ap.add_argument("file", nargs="?")
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--size", default="1920x1080")
+    ap.add_argument("--bd", type=int, default=8, choices=(8, 10), help="bit depth of the synthetic clip")
     ap.add_argument("--graph", action="store_true", help="capture the per-picture analysis into a HIP graph and replay it")
     a = ap.parse_args()
     dsp = pkg.SvtHipDsp(0)
@@ -199,7 +203,7 @@ def main():
         w, h = (int(v) for v in a.size.split("x"))
         tmp = tempfile.mkdtemp(prefix="svt_pipe_")
         path = os.path.join(tmp, "clip.y4m")
-        synthetic_clip(path, w, h, a.frames)
+        synthetic_clip(path, w, h, a.frames, bd=a.bd)
     results = []
     for rep in range(2):                                  # the second pass is timed (page cache, allocator, first-launch costs settled)
         p = Pipeline(dsp, path, use_graph=a.graph)
