@@ -330,6 +330,21 @@ def test_y4m_reader_host_side_equals_oracle_and_reference_fixture(pkg, tmp_path)
             assert not rd.read_into(buf)                 # end of file
             with pytest.raises(pkg.SvtHipError):
                 rd.read_into(np.zeros(4, np.uint8))      # too small a buffer is an error, not a short read
+    # frames of 4 MiB and more are read by several threads (pread on disjoint ranges): same bytes, end of file and truncation as before
+    w, h = 2048, 1536
+    big = [tuple(rng.integers(0, 256, s).astype(np.uint8) for s in ((h, w), (h // 2, w // 2), (h // 2, w // 2))) for _ in range(2)]
+    path = str(tmp_path / "big.y4m")
+    svtlibs.write_y4m(path, f" W{w} H{h} F30:1 Ip C420jpeg\n", big)
+    with pkg.Y4mReader(lib, path) as rd:
+        buf = np.zeros(rd.frame_bytes, np.uint8)
+        for fr in big:
+            assert rd.read_into(buf) and buf.tobytes() == b"".join(p.tobytes() for p in fr)
+        assert not rd.read_into(buf)
+    os.truncate(path, os.path.getsize(path) - 1000)
+    with pkg.Y4mReader(lib, path) as rd:
+        assert rd.read_into(buf)
+        with pytest.raises(pkg.SvtHipError):
+            rd.read_into(buf)
     bad = str(tmp_path / "raw.yuv")
     open(bad, "wb").write(b"\x10" * 100)
     with pytest.raises(pkg.SvtHipError):
