@@ -153,9 +153,13 @@ extern "C" int svt_hip_y4m_read_frame(svt_hip_y4m* h, void* host_dst, size_t cap
             ok[t] = done >= e;
         };
         std::thread th[NT - 1];
-        for (int t = 1; t < NT; t++) th[t - 1] = std::thread(work, t);
+        int started = 0;
+        try {
+            for (int t = 1; t < NT; t++) { th[t - 1] = std::thread(work, t); started = t; }
+        } catch (...) {}                                   // no thread to be had: this one reads the remaining shares itself
         work(0);
-        for (int t = 1; t < NT; t++) th[t - 1].join();
+        for (int t = started + 1; t < NT; t++) work(t);
+        for (int t = 1; t <= started; t++) th[t - 1].join();
         for (int t = 0; t < NT; t++)
             if (!ok[t]) return set_err(SVT_HIP_ERR_INVALID, "read error in a frame of %zu bytes", h->frame_bytes);
         if (fseeko(h->f, pos + (off_t)h->frame_bytes, SEEK_SET) != 0) return set_err(SVT_HIP_ERR_INVALID, "seek past the frame failed");
