@@ -122,10 +122,10 @@ __device__ __forceinline__ uint32_t group_sum_rt(uint32_t v, uint32_t lanes) {
     return v;
 }
 __device__ __forceinline__ uint32_t group_min_rt(uint32_t v, uint32_t lanes) {
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
-    if (lanes >= 8) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));
-    if (lanes >= 16) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, true));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, true));
+    if (lanes >= 8) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, true));
+    if (lanes >= 16) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, true));
     if (lanes >= 32) v = min(v, (uint32_t)__shfl_xor((int)v, 16, 64));
     if (lanes >= 64) v = min(v, (uint32_t)__shfl_xor((int)v, 32, 64));
     return v;

@@ -219,12 +219,12 @@ __global__ __launch_bounds__(ME_THREADS) void me_sb_search_kernel(
 // then the gfx9 row broadcasts; no LDS round trip (a ds_bpermute chain is six dependent LDS latencies
 // per PU, and there are 85 PUs).  The result is valid in LANE 63 only.
 __device__ __forceinline__ unsigned wave_min_u32_to_lane63(unsigned v) {
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast15 -> rows 1, 3
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast31 -> rows 2, 3
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast15 -> rows 1, 3
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast31 -> rows 2, 3
     return v;
 }
 
@@ -518,18 +518,18 @@ __device__ __forceinline__ unsigned me_wave_min16(unsigned (&k)[16], bool bit3, 
     for (int i = 0; i < 4; i++) k[i] = me_min_swap16(k[i], k[i + 4]);           // lane bit 4 picks k[i] / k[i + 4]
 #pragma unroll
     for (int i = 0; i < 2; i++) {                                                // lane bit 3 picks k[i] / k[i + 2] (row_mirror: i <-> 15 - i)
-        const unsigned a = min(k[i], (unsigned)__builtin_amdgcn_update_dpp((int)k[i], (int)k[i], 0x140, 0xF, 0xF, false));
-        const unsigned b = min(k[i + 2], (unsigned)__builtin_amdgcn_update_dpp((int)k[i + 2], (int)k[i + 2], 0x140, 0xF, 0xF, false));
+        const unsigned a = min(k[i], (unsigned)__builtin_amdgcn_update_dpp((int)k[i], (int)k[i], 0x140, 0xF, 0xF, true));
+        const unsigned b = min(k[i + 2], (unsigned)__builtin_amdgcn_update_dpp((int)k[i + 2], (int)k[i + 2], 0x140, 0xF, 0xF, true));
         k[i] = bit3 ? b : a;
     }
     {                                                                            // lane bit 2 picks k[0] / k[1] (row_half_mirror)
-        const unsigned a = min(k[0], (unsigned)__builtin_amdgcn_update_dpp((int)k[0], (int)k[0], 0x141, 0xF, 0xF, false));
-        const unsigned b = min(k[1], (unsigned)__builtin_amdgcn_update_dpp((int)k[1], (int)k[1], 0x141, 0xF, 0xF, false));
+        const unsigned a = min(k[0], (unsigned)__builtin_amdgcn_update_dpp((int)k[0], (int)k[0], 0x141, 0xF, 0xF, true));
+        const unsigned b = min(k[1], (unsigned)__builtin_amdgcn_update_dpp((int)k[1], (int)k[1], 0x141, 0xF, 0xF, true));
         k[0] = bit2 ? b : a;
     }
     unsigned v = k[0];
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
     return v;
 }
 
