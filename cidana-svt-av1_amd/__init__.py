@@ -229,6 +229,14 @@ class SvtHipDsp:
     def device_name(self):
         return self.lib.svt_hip_device_name().decode()
 
+    def membw_probe(self, mode, dst, src=None, nbytes=None):
+        """svt_hip_membw_probe: mode 0 fill / 1 copy / 2 the fused kernel's 1 : 6 read / write mix; enqueues one kernel"""
+        if nbytes is None:
+            nbytes = (src if mode else dst).numel() * (src if mode else dst).element_size()
+        self.lib.svt_hip_membw_probe.argtypes = [c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+        self._check(self.lib.svt_hip_membw_probe(mode, self._p(dst), self._p(src) if src is not None else None, nbytes,
+                                                 self._stream()), "svt_hip_membw_probe")
+
     # -- K1 ---------------------------------------------------------------------
     def fwd_txfm2d(self, residual, tx_size, tx_type, bd=8, out=None):
         """residual: int16 [n, H, W] contiguous (dense blocks). -> int32 [n, H*W]"""

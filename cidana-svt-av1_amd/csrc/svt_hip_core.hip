@@ -1,5 +1,5 @@
 // svt_hip_core.hip — library state, initialisation, tuning knobs, device-memory helpers and the RTCD override table of
-// libsvt_hip_dsp.so (C ABI: include/svt_hip_dsp.h).  No kernels live here.
+// libsvt_hip_dsp.so (C ABI: include/svt_hip_dsp.h).  The only kernels here are the three bandwidth probes of svt_hip_membw_probe.
 #include "host_common.h"
 
 namespace svthost {
@@ -165,6 +165,41 @@ extern "C" int svt_hip_memcpy_d2h(void* h, const void* d, size_t n, void* s) {
 extern "C" int svt_hip_stream_sync(void* s) {
     HIP_TRY(hipStreamSynchronize((hipStream_t)s));
     return SVT_HIP_OK;
+}
+
+// ---- box calibration: one 16-byte access per lane, grid as large as the job (the store shape of DESIGN 4.0) -----------
+typedef int v4i_probe __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void membw_fill_kernel(v4i_probe* __restrict__ dst, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) __builtin_nontemporal_store(v4i_probe{(int)i, 1, 2, 3}, &dst[i]);
+}
+__global__ __launch_bounds__(256) void membw_copy_kernel(v4i_probe* __restrict__ dst, const v4i_probe* __restrict__ src, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
+}
+// a workgroup reads 4 KiB and writes six 4-KiB runs (the fused 32x32 kernel: 2 KiB in, 12 KiB out per block)
+__global__ __launch_bounds__(256) void membw_mix_kernel(v4i_probe* __restrict__ dst, const v4i_probe* __restrict__ src, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    v4i_probe v = __builtin_nontemporal_load(&src[i]);
+    const size_t o = (size_t)blockIdx.x * 6 * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { v.x += k; __builtin_nontemporal_store(v, &dst[o + (size_t)k * 256]); }
+}
+extern "C" int svt_hip_membw_probe(int mode, void* dst, const void* src, size_t bytes, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (!dst || (mode != 0 && !src) || mode < 0 || mode > 2 || (bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))
+        return set_err(SVT_HIP_ERR_INVALID, "membw_probe: bad arguments");
+    if (mode == 2 && (bytes & 4095)) return set_err(SVT_HIP_ERR_INVALID, "membw_probe: mode 2 takes a multiple of 4096 bytes");
+    const size_t n16 = bytes >> 4;
+    if (!n16) return SVT_HIP_OK;
+    const size_t grid = (n16 + 255) / 256;
+    if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "membw_probe: more than 2^31 workgroups");
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) membw_fill_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>((v4i_probe*)dst, n16);
+    else if (mode == 1) membw_copy_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>((v4i_probe*)dst, (const v4i_probe*)src, n16);
+    else membw_mix_kernel<<<dim3((unsigned)grid), dim3(256), 0, s>>>((v4i_probe*)dst, (const v4i_probe*)src, n16);
+    return launch_status("membw_probe");
 }
 
 extern "C" int svt_hip_rtcd_override(const svt_hip_rtcd_table* t) {

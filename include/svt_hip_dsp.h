@@ -93,6 +93,12 @@ void svt_hip_free(void *dptr);
 int svt_hip_memcpy_h2d(void *dptr, const void *hptr, size_t bytes, void *stream);
 int svt_hip_memcpy_d2h(void *hptr, const void *dptr, size_t bytes, void *stream);
 int svt_hip_stream_sync(void *stream);
+/* Box calibration for the roofline report (bench.py): streams `bytes` through HBM in the access shape the kernels of this
+ * library use (one 16-byte access per lane, a grid as large as the job, non-temporal stores) so that a measured kernel rate
+ * can be put next to what THIS device delivers today.  mode 0 = fill `bytes` of dst; 1 = copy `bytes` from src to dst;
+ * 2 = the headline kernel's 1 : 6 read / write mix (reads `bytes` from src, writes 6 x `bytes` to dst).  `bytes` is a
+ * multiple of 16, pointers 16-byte aligned.  Enqueues one kernel on `stream`. */
+int svt_hip_membw_probe(int mode, void *dst, const void *src, size_t bytes, void *stream);
 
 /* ---- host-side tables for callers outside the encoder (csrc/host_tables.cpp; no device involved) ------------------
  * y-plane quantiser rows of av1_build_quantizer(bit_depth, 0, 0, 0, 0, 0) (EbModeDecisionConfigurationProcess.c:429-520):
@@ -797,7 +803,11 @@ int svt_hip_picture_decimate(const uint8_t *d_luma, uint32_t luma_stride, uint32
  * setup_rtcd_internal(asm_type) (EbEncHandle.c:917) and BEFORE init_intra_predictors_internal() the host calls, per slot,
  *     svt_hip_rtcd_override_slot("aom_dc_predictor_16x16", (void **)&aom_dc_predictor_16x16);
  * (INTEGRATION.md has the macro that does it for every slot).  Unknown names return SVT_HIP_ERR_INVALID and leave the
- * slot alone.  The *_funcPtrArray[asm_type] tables are static per translation unit in the reference, so their ASM_HIP rows
+ * slot alone.  GRACEFUL REFUSAL: when the device is unusable (no HIP runtime, no gfx950 part) both override calls return
+ * SVT_HIP_ERR_NO_DEVICE and store nothing - the host's pointers keep what setup_rtcd_internal put there (the AVX2 kernels:
+ * the encoder's own fallback; integration/asm_hip.patch also takes asm_type back to ASM_AVX2 then).  Once a slot has been
+ * handed out, a HIP error in the middle of a run still abort()s inside the drop-in: its reference signature has no error
+ * channel and there is deliberately no CPU path in this library.  The *_funcPtrArray[asm_type] tables are static per translation unit in the reference, so their ASM_HIP rows
  * are added at compile time (integration/asm_hip.patch). */
 int svt_hip_rtcd_slot_count(void);
 const char *svt_hip_rtcd_slot_name(int index);        /* NULL when out of range */

@@ -3,7 +3,7 @@
  * global function pointers with the reference's own slot names and signatures (aom_dsp_rtcd.h), filled first with local
  * scalar stand-ins (the role of setup_rtcd_internal's C defaults), then overridden BY NAME through
  * svt_hip_rtcd_override_slot, then called through the pointers.  Each result is compared with the stand-in's.
- * Exit codes: 0 ok, 3 the library refused the override (no usable device: there is no CPU fallback), 4.. a mismatch.
+ * Exit codes: 0 ok, 3 the library refused every override (no usable device) and left the host's pointers alone, 4.. a mismatch.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -70,8 +70,12 @@ static void levels_c(const int32_t *const coeff, const int32_t w, const int32_t 
 static uint32_t rnd_state = 13596u;
 static uint32_t rnd(void) { rnd_state = rnd_state * 1664525u + 1013904223u; return rnd_state >> 8; }
 
+/* A refused override (no usable device) must leave the host's pointer as it was: the host then keeps the kernel it already
+ * had - in the encoder its AVX2 one (SURVEY 8b "Errors").  Exit 3 = refused AND every pointer still the stand-in AND still
+ * callable; 6 = a refused override touched a pointer. */
+static int refused;
 #define OVERRIDE(slot) do { if (svt_hip_rtcd_override_slot(#slot, (void **)&slot) != SVT_HIP_OK) { \
-        fprintf(stderr, "override of %s refused: %s\n", #slot, svt_hip_last_error()); return 3; } } while (0)
+        fprintf(stderr, "override of %s refused: %s\n", #slot, svt_hip_last_error()); refused++; } } while (0)
 
 int main(void) {
     aom_dc_predictor_16x16 = dc16_c; aom_v_predictor_8x8 = v8_c; aom_highbd_h_predictor_4x8 = hbd_h4x8_c; aom_sad16x16 = sad16_c;
@@ -79,6 +83,17 @@ int main(void) {
     if (svt_hip_rtcd_slot_count() < 480) { fprintf(stderr, "registry too small\n"); return 4; }
     OVERRIDE(aom_dc_predictor_16x16); OVERRIDE(aom_v_predictor_8x8); OVERRIDE(aom_highbd_h_predictor_4x8); OVERRIDE(aom_sad16x16);
     OVERRIDE(aom_sad8x8x4d); OVERRIDE(ResidualKernel); OVERRIDE(subtract_average); OVERRIDE(av1_txb_init_levels);
+    if (refused) {
+        if ((void *)aom_dc_predictor_16x16 != (void *)dc16_c || (void *)aom_v_predictor_8x8 != (void *)v8_c ||
+            (void *)aom_highbd_h_predictor_4x8 != (void *)hbd_h4x8_c || (void *)aom_sad16x16 != (void *)sad16_c ||
+            (void *)aom_sad8x8x4d != (void *)sad8x4d_c || (void *)ResidualKernel != (void *)residual_c ||
+            (void *)subtract_average != (void *)sub_avg_c || (void *)av1_txb_init_levels != (void *)levels_c || refused != 8)
+            return 6;
+        uint8_t x[256], y[256];
+        for (int i = 0; i < 256; i++) { x[i] = (uint8_t)rnd(); y[i] = (uint8_t)rnd(); }
+        if (aom_sad16x16(x, 16, y, 16) != sad_c(x, 16, y, 16, 16, 16)) return 6;      /* the host's own kernel still answers */
+        return 3;
+    }
     if ((void *)aom_dc_predictor_16x16 == (void *)dc16_c) return 5;
 
     uint8_t nb_a[96], nb_l[96], a[64 * 24], b[4][64 * 24];

@@ -212,7 +212,27 @@ def test_c_caller_compiles_and_links_against_the_library(tmp_path):
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: tests/test_gpu_dropin.py runs it")
     pr = subprocess.run([exe], capture_output=True, text=True)
-    assert pr.returncode == 3, (pr.returncode, pr.stdout, pr.stderr)      # 3 = override refused (no device), nothing called
+    assert pr.returncode == 3, (pr.returncode, pr.stdout, pr.stderr)      # 3 = every override refused (no device), the host's own pointers intact and callable
+
+
+def test_rtcd_override_refuses_without_a_device_and_leaves_the_pointers_alone(pkg):
+    """SURVEY 8(b) "Errors": with no usable device svt_hip_rtcd_override / _override_slot return an error and do not touch the
+    caller's dispatch pointers - the encoder keeps the AVX2 kernels setup_rtcd_internal already stored (its own fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the override succeeds (tests/test_gpu_dropin.py)")
+    lib = pkg.load_library()
+    for name in registry(lib)[::37]:
+        slot = ctypes.c_void_p(0x5a5a)
+        rc = lib.svt_hip_rtcd_override_slot(name.encode(), ctypes.byref(slot))
+        assert rc == -1 and slot.value == 0x5a5a, name                      # SVT_HIP_ERR_NO_DEVICE
+    assert b"HIP device" in lib.svt_hip_last_error() or b"gfx950" in lib.svt_hip_last_error()
+    # the table form: 19 + 19 + 8 pointer-to-pointer members (include/svt_hip_dsp.h, svt_hip_rtcd_table)
+    nslots = 19 + 19 + 8
+    store = (ctypes.c_void_p * nslots)(*([0x77] * nslots))
+    table = (ctypes.c_void_p * nslots)(*[ctypes.addressof(store) + i * ctypes.sizeof(ctypes.c_void_p) for i in range(nslots)])
+    assert lib.svt_hip_rtcd_override(ctypes.byref(table)) == -1
+    assert all(v == 0x77 for v in store)
 
 
 def test_intra_availability_host_helper_equals_reference_tables_and_oracle(pkg):

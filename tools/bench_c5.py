@@ -7,7 +7,8 @@ own GOP's planes (one GOP resident at a time: 30 x 2 x 24.9 MB); the only exchan
 (cidana-svt-av1_amd/sharding.py) at the end, and the barrier / max-reduce around the timed region.
 
     python tools/bench_c5.py                      # 1 GPU: all 8 GOPs, one after the other
-    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_c5.py --gpus N
+    python tools/bench_c5.py --gpus N             # starts its own N ranks (one per GPU) as child processes
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_c5.py --gpus N   # or under a launcher
     options: --frames 240 --gop 30 --width 3840 --height 2160 --sizes 64,32,16,8,4 --qindex 120
              --rehearse  (all ranks on cuda:0 with the gloo backend: exercises the N > 1 code path on a one-GPU box)
 
@@ -40,12 +41,16 @@ def main():
     ap.add_argument("--json-out", default=None)
     args = ap.parse_args()
 
-    import torch
+    # bare `python tools/bench_c5.py --gpus N`: this process only starts the N ranks (before torch / HIP are loaded)
     import __graft_entry__ as ge
     pkg = ge.load_package()
-    from cidana_svt_av1_amd import frames, sharding
+    from cidana_svt_av1_amd import launcher
+    if launcher.needs_spawn(args.gpus):
+        sys.exit(launcher.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    world = launcher.check_world(args.gpus)     # exits non-zero when WORLD_SIZE and --gpus disagree
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    from cidana_svt_av1_amd import frames, sharding
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.rehearse else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:

@@ -156,9 +156,12 @@ RTCD_TAIL = r'''
 #ifdef SVT_HIP_BACKEND
         /* ASM_HIP: every dispatch slot libsvt_hip_dsp implements is overridden BY NAME (its registry holds a drop-in of the
          * exact signature); slots it does not implement keep the AVX2 kernels chosen above.  The X-macro lists come from
-         * svt_hip_dsp.h.  aom_highbd_paeth_predictor_* are #defines to the C functions in this header, not pointers. */
+         * svt_hip_dsp.h.  aom_highbd_paeth_predictor_* are #defines to the C functions in this header, not pointers.
+         * svt_hip_rtcd_override_slot refuses (non-zero, pointer untouched) when the device is unusable: a refused slot keeps
+         * its AVX2 kernel, which is this encoder's own fallback, and the refusals are counted and logged. */
         if (asm_type == ASM_HIP) {
-#define SVT_HIP_OVR(slot) (void)svt_hip_rtcd_override_slot(#slot, (void **)&slot);
+            int svt_hip_refused = 0;
+#define SVT_HIP_OVR(slot) if (svt_hip_rtcd_override_slot(#slot, (void **)&slot) != SVT_HIP_OK) svt_hip_refused++;
 #define SVT_HIP_OVR_TX(A, B, W, H) SVT_HIP_OVR(av1_fwd_txfm2d_##W##x##H) SVT_HIP_OVR(av1_inv_txfm2d_add_##W##x##H)
 #define SVT_HIP_OVR_PRED(mode, MODE, W, H) SVT_HIP_OVR(aom_##mode##_predictor_##W##x##H)
 #define SVT_HIP_OVR_HPRED(mode, MODE, W, H) SVT_HIP_OVR(aom_highbd_##mode##_predictor_##W##x##H)
@@ -185,6 +188,8 @@ RTCD_TAIL = r'''
 #undef SVT_HIP_OVR_HPRED
 #undef SVT_HIP_OVR_SAD
 #undef SVT_HIP_HIGHBD_MODES
+            if (svt_hip_refused)
+                SVT_LOG("Warning: -asm 2: %d dispatch slots kept their AVX2 kernels (%s)\n", svt_hip_refused, svt_hip_last_error());
         }
 #endif
 '''
@@ -223,7 +228,14 @@ def edit(path, text):
         text = text.replace(old, "#ifdef SVT_HIP_BACKEND\n    if (((int32_t)(config->asm_type) != 1) && ((int32_t)(config->asm_type) != ASM_HIP)) {   // 2: HIP backend\n#else\n" + old + "\n#endif")
         old = "    setup_rtcd_internal(encHandlePtr->sequence_control_set_instance_array[0]->encode_context_ptr->asm_type);"
         assert old in text
-        text = text.replace(old, "#ifdef SVT_HIP_BACKEND\n    /* the library has no CPU fallback: refuse to start when the device is not usable (single-threaded here: no worker\n     * thread exists yet, EbEncHandle.c creates them further down) */\n    if (encHandlePtr->sequence_control_set_instance_array[0]->encode_context_ptr->asm_type == ASM_HIP && svt_hip_init(0) != SVT_HIP_OK) {\n        SVT_LOG(\"Error: -asm 2 needs a usable gfx950 device: %s\\n\", svt_hip_last_error());\n        return EB_ErrorBadParameter;\n    }\n#endif\n" + old)
+        ectx = "encHandlePtr->sequence_control_set_instance_array[0]->encode_context_ptr"
+        text = text.replace(old, "#ifdef SVT_HIP_BACKEND\n    /* -asm 2 without a usable gfx950 device: svt_hip_init says so, and the encoder keeps its AVX2 kernels - the asm_type\n"
+                                 "     * every *_funcPtrArray[asm_type] table and setup_rtcd_internal see goes back to ASM_AVX2 (single-threaded here: no\n"
+                                 "     * worker thread exists yet, EbEncHandle.c creates them further down).  A HIP error in the middle of a run is a\n"
+                                 "     * different matter: the drop-ins have no error channel and abort (include/svt_hip_dsp.h). */\n"
+                                 f"    if ({ectx}->asm_type == ASM_HIP && svt_hip_init(0) != SVT_HIP_OK) {{\n"
+                                 "        SVT_LOG(\"Warning: -asm 2: no usable gfx950 device (%s); keeping the AVX2 kernels\\n\", svt_hip_last_error());\n"
+                                 f"        {ectx}->asm_type = ASM_AVX2;\n    }}\n#endif\n" + old)
     new, names = add_third_rows(text)
     return new, names
 
