@@ -13,7 +13,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libsvt_hip_dsp.so")
-SOURCES = ["csrc/svt_hip_core.hip", "csrc/svt_hip_txfm.hip", "csrc/svt_hip_pixel.hip", "csrc/svt_hip_intra.hip", "csrc/svt_hip_picture.hip", "csrc/host_tables.cpp"]
+SOURCES = ["csrc/svt_hip_core.hip", "csrc/svt_hip_txfm.hip", "csrc/svt_hip_pixel.hip", "csrc/svt_hip_intra.hip", "csrc/svt_hip_picture.hip", "csrc/host_tables.cpp", "csrc/y4m_reader.cpp", "csrc/host_err.cpp"]
+HOST_ONLY = [s for s in SOURCES if s.endswith(".cpp")]          # no HIP header, no device: also built under sanitizers (tests/test_host_sanitizers.py)
 OBJ_DIR = os.path.join(PKG, "build_obj")            # git-ignored; objects do not travel, the linked .so does
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fwrapv", "-Wall", "-Wno-unused-function"]
 HOST_FLAGS = ["-x", "c++", "-O2", "-fPIC", "-std=c++17", "-Wall"]        # host-only units: no device pass
@@ -42,6 +43,11 @@ def build_product(force=False, verbose=True):
     tools = [os.path.join(PKG, "tools", f) for f in ("txfm_net.py", "gen_device.py")]
     if _stale(gen, tools):
         subprocess.check_call([sys.executable, os.path.join(PKG, "tools", "gen_device.py")])
+    # the quantiser look-up header of host_tables.cpp: generator or its data newer than the header -> regenerate (the depfile
+    # rule then sees a changed header and rebuilds the unit)
+    qgen = os.path.join(PKG, "csrc", "gen", "qlookup_gen.h")
+    if _stale(qgen, [os.path.join(PKG, "tools", "gen_qlookup.py"), os.path.join(PKG, "qlookup_data.py")]):
+        subprocess.check_call([sys.executable, os.path.join(PKG, "tools", "gen_qlookup.py")])
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     jobs, objs = [], []

@@ -12,11 +12,11 @@
 #include <mutex>
 
 #include "../../include/svt_hip_dsp.h"
+#include "host_err.h"
 
 namespace svthost {
 
 
-extern thread_local char g_err[512];
 extern std::atomic<int> g_inited;
 extern std::mutex g_init_mu;
 extern int g_device;
@@ -46,7 +46,6 @@ extern int g_tune_frame_single_launch;
 extern int g_tune_inv32_waves;
 extern int g_tune_inv32_var;
 
-int set_err(int code, const char* fmt, ...);
 #define HIP_TRY(expr)                                                                            \
     do {                                                                                         \
         hipError_t e_ = (expr);                                                                  \

@@ -954,6 +954,12 @@ __global__ __launch_bounds__(ME_THREADS) void hme_level_kernel(
     const int tid = threadIdx.x;
     const int ox = sb_origin[2 * task], oy = sb_origin[2 * task + 1];
     const int sbw = sb_size[2 * task], sbh = sb_size[2 * task + 1];
+    // The size table lives in device memory, the host cannot check it; s_src holds 32 rows of 64 bytes and the window is sized for
+    // blocks of at most 64x64 (include/svt_hip_dsp.h).  An entry outside 1..64 x 2..64 is answered, not searched.
+    if (sbw < 1 || sbh < 2 || sbw > 64 || sbh > 64) {
+        if (tid == 0) { best_sad[task] = ~0ull; mv[2 * task] = 0; mv[2 * task + 1] = 0; }
+        return;
+    }
     const int xc = centers ? (centers[2 * task] >> center_shift) : 0, yc = centers ? (centers[2 * task + 1] >> center_shift) : 0;
     int saw = p.search_area_width, sah = p.search_area_height;
     int xo = p.x_origin_offset + xc, yo = p.y_origin_offset + yc;

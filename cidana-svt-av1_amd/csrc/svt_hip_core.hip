@@ -5,7 +5,6 @@
 namespace svthost {
 
 
-thread_local char g_err[512] = "";
 std::atomic<int> g_inited{0};
 std::mutex g_init_mu;
 int g_device = -1;
@@ -35,14 +34,6 @@ int g_tune_no_enc64 = 0;
 int g_tune_frame_single_launch = -1;      // -1: by call size (svt_hip_encode_recon_frame), 0 never, 1 always
 int g_tune_inv32_waves = 4;
 int g_tune_inv32_var = 0;
-
-int set_err(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
 
 // The HIP "current device" is a per-THREAD setting and the encoder calls from many pthreads (Threading):
 // every entry point passes through here, so every thread is bound to the library's device once.
@@ -117,7 +108,6 @@ extern "C" void svt_hip_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_init_mu);
     g_inited.store(0, std::memory_order_release);
 }
-extern "C" const char* svt_hip_last_error(void) { return g_err; }
 extern "C" int svt_hip_tune(const char* key, int value) {
     if (!key) return SVT_HIP_ERR_INVALID;
     if (!strcmp(key, "f32_min_waves")) { g_tune_f32_min_waves = value; return SVT_HIP_OK; }

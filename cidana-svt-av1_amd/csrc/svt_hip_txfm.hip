@@ -519,6 +519,7 @@ extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int
     if (int rc = require_init()) return rc;
     if (ngroups == 0) return SVT_HIP_OK;
     if (!groups || ngroups < 0) return set_err(SVT_HIP_ERR_INVALID, "NULL group list");
+    if (ngroups > 256) return set_err(SVT_HIP_ERR_INVALID, "more than 256 groups in one call");
     for (int g = 0; g < ngroups; g++) {            // validate everything before anything is enqueued
         const svt_hip_frame_group& G = groups[g];
         if (G.nblocks == 0) continue;
@@ -587,13 +588,15 @@ extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int
     if (int rc = t_fan.ensure()) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int nstreams = ngroups < kFanStreams ? ngroups : kFanStreams;
+    // From the fork on nothing returns early: a side stream that has waited on the fork event must be joined back, or a
+    // caller capturing this call into a graph is left with dangling branches.  Failures become rc and fall through to the join.
     HIP_TRY(hipEventRecord(t_fan.fork, s));
-    for (int i = 0; i < nstreams; i++) HIP_TRY(hipStreamWaitEvent(t_fan.s[i], t_fan.fork, 0));
-    int rc = SVT_HIP_OK;
+    int rc = SVT_HIP_OK, forked = 0;
+    for (; forked < nstreams; forked++)
+        if (hipStreamWaitEvent(t_fan.s[forked], t_fan.fork, 0) != hipSuccess) { rc = set_err(SVT_HIP_ERR_RUNTIME, "stream fork failed"); break; }
     // largest groups first, round-robin: the long kernels start early and the small ones fill in beside them
     int order[256];
-    const int ng = ngroups < 256 ? ngroups : 256;
-    if (ngroups > 256) return set_err(SVT_HIP_ERR_INVALID, "more than 256 groups in one call");
+    const int ng = ngroups;                        // <= 256, checked with the arguments
     for (int i = 0; i < ng; i++) order[i] = i;
     for (int i = 1; i < ng; i++) {                 // insertion sort by work (pixels), descending
         const int v = order[i];
@@ -620,7 +623,7 @@ extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int
         }
     }
     // always join, also after an error: the caller's stream (or capture) must not be left with dangling branches
-    for (int i = 0; i < nstreams; i++) {
+    for (int i = 0; i < forked; i++) {
         if (hipEventRecord(t_fan.join[i], t_fan.s[i]) != hipSuccess || hipStreamWaitEvent(s, t_fan.join[i], 0) != hipSuccess)
             if (rc == SVT_HIP_OK) rc = set_err(SVT_HIP_ERR_RUNTIME, "stream join failed");
     }

@@ -353,6 +353,7 @@ int svt_hip_me_sb_search_planes_batch(const uint8_t *d_src_plane, uint32_t src_s
  * picture: HmeLevel0 / HmeLevel1 / HmeLevel2 (EbMotionEstimation.c:5689, 5883, 6016; called per SB at :7739-7830) INCLUDING
  * the search-area placement and clipping the reference does per SB on the host (:5729-5798).  Per task t:
  *   d_sb_origin[t] = (x, y) of the SB and d_sb_size[t] = (width, height), at the level's resolution (origin >> 2 / >> 1 / >> 0);
+ *   width 1..64, height 2..64 (the reference's SBs); an entry outside that range gets best_sad = 2^64 - 1 and mv = (0, 0);
  *   search centre  = d_centers[t] >> center_shift (NULL: (0, 0)): level 0 takes the caller's centre, level 1 the level-0
  *                    result >> 1, level 2 the level-1 result (the reference's call sites), so the levels chain ON THE DEVICE;
  *   d_src_pic / d_ref_pic point at sample (0, 0) of the level's source / padded reference picture (the reference buffer

@@ -374,3 +374,17 @@ def test_y4m_reader_host_side_equals_oracle_and_reference_fixture(pkg, tmp_path)
     with pkg.Y4mReader(lib, broken) as rd:
         with pytest.raises(pkg.SvtHipError):
             rd.read_into(np.zeros(rd.frame_bytes, np.uint8))
+
+
+def test_committed_generated_headers_are_what_their_generators_emit(tmp_path):
+    """csrc/gen/qlookup_gen.h == tools/gen_qlookup.py's output for qlookup_data.py (an edit to either must not leave the committed
+    header, and with it the library's quantiser tables, behind; build.py regenerates on a newer generator, this catches the rest)"""
+    import importlib.util
+    import io
+    import contextlib
+    spec = importlib.util.spec_from_file_location("gen_qlookup", os.path.join(PKG, "tools", "gen_qlookup.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    out = str(tmp_path / "qlookup_gen.h")
+    with contextlib.redirect_stdout(io.StringIO()):
+        m.main(out)
+    assert open(out).read() == open(os.path.join(PKG, "csrc", "gen", "qlookup_gen.h")).read()
