@@ -56,6 +56,11 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_malloc.restype = c_void_p
     L.svt_hip_malloc.argtypes = [c_size_t]
     L.svt_hip_free.argtypes = [c_void_p]
+    L.svt_hip_me_setup_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32] + [c_void_p] * 7 + [c_size_t, c_void_p]
+    L.svt_hip_me_fullpel_search_areas_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                                        c_void_p, c_void_p, c_uint32, c_size_t, c_void_p]
+    L.svt_hip_me_bipred_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p, c_uint32] + [c_void_p] * 5 + [c_uint32, c_int, c_int, c_int,
+                                          c_void_p, c_void_p, c_size_t, c_void_p]
     L.svt_hip_fwd_txfm2d_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]
     L.svt_hip_pack64_batch.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_void_p]
     L.svt_hip_inv_txfm2d_add_batch.argtypes = [c_void_p, c_void_p, c_int, c_int32, c_size_t, c_void_p, c_size_t,
@@ -778,6 +783,78 @@ class SvtHipDsp:
             self._p(origins) if origins is not None else None, x_origin, y_origin, flavour, 1 if nsq else 0, self._p(best_sad),
             self._p(best_mv), best_sad.shape[1], n, self._stream()), "svt_hip_me_fullpel_search_batch")
         return best_sad, best_mv
+
+    # -- MotionEstimateLcu's glue: set-up, per-SB areas, bi-prediction + result rows ------------------------
+    class MeSetupParams(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_int32) for n in ("picture_width", "picture_height", "ref_width", "ref_height", "search_area_width",
+                                                  "search_area_height", "regions_w", "regions_h", "second_best", "zz_check")]
+
+    class MeResult(ctypes.Structure):
+        _fields_ = [("x_mv_l0", ctypes.c_int16), ("y_mv_l0", ctypes.c_int16), ("x_mv_l1", ctypes.c_int16), ("y_mv_l1", ctypes.c_int16),
+                    ("distortion", ctypes.c_uint32 * 3), ("direction", ctypes.c_uint8 * 3), ("total_me_candidate_index", ctypes.c_uint8)]
+
+    def me_setup(self, src_pic00, src_stride, ref_pic00, ref_stride, sb_origin, sb_size, hme_sad, hme_mv, params):
+        """svt_hip_me_setup_batch: search centre (best HME region, CheckZeroZeroCenter) and clipped search area per task.
+        src_pic00 / ref_pic00: uint8 views whose data_ptr() is sample (0, 0) of the padded planes; sb_origin / sb_size int16 [n, 2];
+        hme_sad int64 [regions, n] and hme_mv int16 [regions, n, 2] (or None).  -> (center int16 [n, 2], area int16 [n, 4])"""
+        t = self.torch
+        n = sb_origin.shape[0]
+        center = t.zeros((n, 2), dtype=t.int16, device=sb_origin.device)
+        area = t.zeros((n, 4), dtype=t.int16, device=sb_origin.device)
+        self._check(self.lib.svt_hip_me_setup_batch(self._p(src_pic00), src_stride, self._p(ref_pic00), ref_stride, self._p(sb_origin),
+                                                    self._p(sb_size), self._p(hme_sad) if hme_sad is not None else None,
+                                                    self._p(hme_mv) if hme_mv is not None else None, ctypes.byref(params), self._p(center),
+                                                    self._p(area), n, self._stream()), "svt_hip_me_setup_batch")
+        return center, area
+
+    def me_fullpel_search_areas(self, src, src_stride, src_offsets, ref, ref_stride, ref_offsets, areas, max_w, max_h, flavour=0, nsq=False,
+                                best_sad=None, best_mv=None):
+        """svt_hip_me_fullpel_search_areas_batch: one search area per SB, read on the device from `areas` (int16 [n, 4]).
+        ref_offsets: the SB's co-located byte offset in the reference plane.  -> (best_sad, best_mv) int32 [n, 85 | 209]"""
+        t = self.torch
+        n = src_offsets.numel()
+        npu = self.ME_PUS_ALL if nsq else 85
+        if best_sad is None:
+            best_sad = t.full((n, npu), self.MAX_SAD_VALUE, dtype=t.int32, device=src.device)
+            best_mv = t.zeros((n, npu), dtype=t.int32, device=src.device)
+        self._check(self.lib.svt_hip_me_fullpel_search_areas_batch(self._p(src), src_stride, self._p(src_offsets), self._p(ref), ref_stride,
+                                                                   self._p(ref_offsets), self._p(areas), max_w, max_h, flavour, 1 if nsq else 0,
+                                                                   self._p(best_sad), self._p(best_mv), best_sad.shape[1], n, self._stream()),
+                    "svt_hip_me_fullpel_search_areas_batch")
+        return best_sad, best_mv
+
+    def me_bipred(self, src_pic00, src_stride, ref0_pic00, ref0_stride, ref1_pic00, ref1_stride, sb_origin, best_sad0, best_mv0, best_sad1=None,
+                  best_mv1=None, npus=209, bipred_all_pus=True, sub_sad=True):
+        """svt_hip_me_bipred_batch -> (bipred_sad int32 [n, pu_pitch] in storage order, results uint8 [n, npus, 24] = svt_hip_me_result
+        rows in raster PU order)"""
+        t = self.torch
+        n = sb_origin.shape[0]
+        pitch = best_sad0.shape[1]
+        bip = t.zeros((n, pitch), dtype=t.int32, device=sb_origin.device)
+        res = t.zeros((n, npus, ctypes.sizeof(self.MeResult)), dtype=t.uint8, device=sb_origin.device)
+        two = best_sad1 is not None
+        self._check(self.lib.svt_hip_me_bipred_batch(self._p(src_pic00), src_stride, self._p(ref0_pic00) if two else None, ref0_stride,
+                                                     self._p(ref1_pic00) if two else None, ref1_stride, self._p(sb_origin), self._p(best_sad0),
+                                                     self._p(best_mv0), self._p(best_sad1) if two else None, self._p(best_mv1) if two else None,
+                                                     pitch, npus, int(bipred_all_pus), int(sub_sad), self._p(bip), self._p(res), n,
+                                                     self._stream()), "svt_hip_me_bipred_batch")
+        return bip, res
+
+    @staticmethod
+    def me_results_as_rows(res):
+        """uint8 [n, npus, 24] svt_hip_me_result rows -> int64 numpy [n, npus, 11] in the column order of oracle/ref_me.c's results:
+        xMvL0 yMvL0 xMvL1 yMvL1 dist0 dir0 dist1 dir1 dist2 dir2 totalMeCandidateIndex"""
+        import numpy as np
+        a = res.cpu().numpy()
+        n, npus, _ = a.shape
+        out = np.zeros((n, npus, 11), np.int64)
+        out[..., 0:4] = a[..., 0:8].copy().view(np.int16).reshape(n, npus, 4)
+        d = a[..., 8:20].copy().view(np.uint32).reshape(n, npus, 3)
+        for k in range(3):
+            out[..., 4 + 2 * k] = d[..., k]
+            out[..., 5 + 2 * k] = a[..., 20 + k]
+        out[..., 10] = a[..., 23]
+        return out
 
     # -- general fused chain on planes ------------------------------------------------------
     def fwd_quant_planes(self, src, src_stride, pred, pred_stride, xy, tx_size, tx_type, qrow, iscan, bd=8,

@@ -254,26 +254,20 @@ __device__ __forceinline__ unsigned long long me_pk_add(unsigned long long a, un
 }
 
 // MASKED: the search width is not a multiple of 16; the last 16-point group of a row is partly outside the area.
+// The search of one SB by one workgroup (body shared by me_sb_search16_kernel and me_fullpel_areas_kernel): gs / gr = the SB's
+// source block and the top-left sample of its search window, bs / bm = its result rows, (ox, oy) = the search area's origin.
 template <bool MASKED>
-__global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void me_sb_search16_kernel(
-    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
-    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
-    const int16_t* __restrict__ origins /* [n][2] x,y or NULL */, int x_origin, int y_origin,
-    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t wpitch,
-    const uint32_t* __restrict__ src_offs, const uint32_t* __restrict__ ref_offs, uint32_t nblocks,
+__device__ __forceinline__ void me_sb_search16_body(
+    uint8_t* smem, const uint8_t* __restrict__ gs, uint32_t src_stride, const uint8_t* __restrict__ gr, uint32_t ref_stride,
+    int search_w, int search_h, int ox, int oy, uint32_t* __restrict__ bs, uint32_t* __restrict__ bm, uint32_t wpitch,
     // w8q > 0: SVT_HIP_FLAVOUR_AVX2 - inside the full groups of eight search points of a row (xs < w8q = search_w & ~7) the four
     // 32x32 PUs rank and report point p of the group as p ^ 4 (see me_fullpel_exact_kernel).  ref_layout: results in the
-    // reference's EbMeTierZeroPu order with pu_pitch words per SB instead of 8x8 | 16x16 | 32x32 | 64x64 back to back.
-    int w8q = 0, int ref_layout = 0, uint32_t pu_pitch = ME_PUS) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // reference's EbMeTierZeroPu order instead of 8x8 | 16x16 | 32x32 | 64x64 back to back.
+    int w8q, int ref_layout) {
     uint32_t* s_src = reinterpret_cast<uint32_t*>(smem);            // [32 even rows][16 dwords]
     uint8_t* s_ref = smem + 32 * 64;                                // [(64+sh-1)][wpitch], wpitch % 16 == 0
     __shared__ unsigned s_red[4][ME_PUS];
-    const uint32_t blk = blockIdx.x;
-    if (blk >= nblocks) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
-    const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
     // ---- stage the even source rows and the reference window (16-B unaligned loads, 4 in flight) ----
     if (tid < 128) {
         const int r = tid >> 2, c = tid & 3;
@@ -438,16 +432,31 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const unsigned sad = tid < 80 ? (key >> 16) << 1 : key >> 12;
         const unsigned cand = key & 0xfffu;
         const int ys = (int)cand / search_w, xs = (int)cand - ys * search_w;
-        const int ox = origins ? origins[2 * blk] : x_origin, oy = origins ? origins[2 * blk + 1] : y_origin;
         // legacy order 8x8 [0..63] | 16x16 [64..79] | 32x32 [80..83] | 64x64 [84] -> EbMeTierZeroPu order
         const int o = !ref_layout ? tid : (tid < 64 ? 21 + tid : (tid < 80 ? 5 + (tid - 64) : (tid < 84 ? 1 + (tid - 80) : 0)));
-        uint32_t* bs = best_sad + (size_t)blk * pu_pitch;
-        uint32_t* bm = best_mv + (size_t)blk * pu_pitch;
         if (sad < bs[o]) {
             bs[o] = sad;
             bm[o] = (((uint32_t)(uint16_t)(ys + oy)) << 18) | (uint32_t)(uint16_t)((xs + ox) << 2);
         }
     }
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void me_sb_search16_kernel(
+    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
+    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
+    const int16_t* __restrict__ origins /* [n][2] x,y or NULL */, int x_origin, int y_origin,
+    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t wpitch,
+    const uint32_t* __restrict__ src_offs, const uint32_t* __restrict__ ref_offs, uint32_t nblocks,
+    int w8q = 0, int ref_layout = 0, uint32_t pu_pitch = ME_PUS) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t blk = blockIdx.x;
+    if (blk >= nblocks) return;
+    const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
+    const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
+    const int ox = origins ? origins[2 * blk] : x_origin, oy = origins ? origins[2 * blk + 1] : y_origin;
+    me_sb_search16_body<MASKED>(smem, gs, src_stride, gr, ref_stride, search_w, search_h, ox, oy, best_sad + (size_t)blk * pu_pitch,
+                                best_mv + (size_t)blk * pu_pitch, wpitch, w8q, ref_layout);
 }
 
 // ---------------------------------------------------------------------------
@@ -598,21 +607,21 @@ __device__ __forceinline__ unsigned me_bigkey4_min(const unsigned (&s2)[4], cons
     return min(min((s2[0] << 12) | c[0], (s2[1] << 12) | c[1]), min((s2[2] << 12) | c[2], (s2[3] << 12) | c[3]));
 }
 
-__global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void me_nsq4_kernel(
-    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
-    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
-    const int16_t* __restrict__ origins /* [n][2] x,y or NULL */, int x_origin, int y_origin,
-    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t wpitch,
-    const uint32_t* __restrict__ src_offs, const uint32_t* __restrict__ ref_offs, uint32_t nblocks, uint32_t pu_pitch) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// One SB by one workgroup (shared by me_nsq4_kernel and me_fullpel_areas_kernel).  Widths: a multiple of 8 (every point in the
+// eight-point form), or BELOW 8 with s_pair != NULL - the C flavour's single-search-point form, which production reaches when
+// the clipped search area of a picture-edge SB is narrower than 8 (EbMotionEstimation.c:8016-8021 rounds every other width down
+// to a multiple of 8).  There the SADs are the same and every PU still keeps its first strict minimum, except 32x16_5 (index 92):
+// ExtSadCalculation (:732-736) tests the stale `sad` of 64x32_1 against its best and then stores sad_32x16[5] - a sequential
+// rule, not a minimum.  The lanes leave (64x32_1 SAD, 32x16_5 SAD) of every point in s_pair [search_w * search_h] and one lane
+// replays the rule in search order at the end (<= 7 x search_h steps); lanes past the row's end carry all-ones keys.
+__device__ __forceinline__ void me_nsq4_body(
+    uint8_t* smem, const uint8_t* __restrict__ gs, uint32_t src_stride, const uint8_t* __restrict__ gr, uint32_t ref_stride,
+    int search_w, int search_h, int ox, int oy, uint32_t* __restrict__ bs, uint32_t* __restrict__ bm, uint32_t wpitch, uint2* s_pair) {
     uint32_t* s_src = reinterpret_cast<uint32_t*>(smem);            // [32 even rows][16 dwords]
     uint8_t* s_ref = smem + 32 * 64;                                // [(64+sh-1)][wpitch], wpitch % 16 == 0
     __shared__ unsigned s_red[4][NSQ_BATCHES * 16];                 // [wave][batch][slot]
-    const uint32_t blk = blockIdx.x;
-    if (blk >= nblocks) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
-    const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
+    const bool sp = (search_w & 7) != 0;                            // single-search-point form (search_w < 8)
     if (tid < 128) {
         const int r = tid >> 2, c = tid & 3;
         uint4 v;
@@ -647,15 +656,16 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const unsigned v = me_wave_min16(k, bit3, bit2);
         if (writer) __hip_atomic_fetch_min(my_red + batch * 16, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
-    const int xq = search_w >> 2;
+    const int xq = (search_w + 3) >> 2;
     const int ntasks = xq * search_h;
     for (int t0 = 0; t0 < ntasks; t0 += ME_THREADS) {
         const int t = t0 + tid;
         const bool act = t < ntasks;
         const int tc = act ? t : 0;
         const int ys = tc / xq, xs0 = (tc - ys * xq) * 4;
-        const unsigned idb = (unsigned)(ys * search_w + xs0);          // a multiple of 4: idb + j == idb | j
-        const unsigned cj[4] = {act ? idb : 0xffffffffu, act ? idb | 1u : 0xffffffffu, act ? idb | 2u : 0xffffffffu, act ? idb | 3u : 0xffffffffu};
+        const unsigned idb = (unsigned)(ys * search_w + xs0);
+        const int nv = act ? search_w - xs0 : 0;                       // valid points of the lane (>= 4 except at a narrow row's end)
+        const unsigned cj[4] = {nv > 0 ? idb : 0xffffffffu, nv > 1 ? idb + 1u : 0xffffffffu, nv > 2 ? idb + 2u : 0xffffffffu, nv > 3 ? idb + 3u : 0xffffffffu};
         const uint8_t* rbase = s_ref + (size_t)ys * wpitch + xs0;
         unsigned s64[4] = {0, 0, 0, 0};
         unsigned s32top[2][4];
@@ -733,6 +743,7 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     krow[14] = me_bigkey4_min(s2, cj);
                 }
                 krow[15] = 0xffffffffu;
+                if (h16 == 1 && sp && h32 == 1) krow[12] = 0xffffffffu;               // 32x16_5 in the single-point form: replayed below
                 put16(7 * h32 + 3 * h16 + 2, krow);
                 if (h16 == 0) {
 #pragma unroll
@@ -766,6 +777,13 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                 for (int j = 0; j < 4; j++) w[j] = s32[0][j] + s32[1][j];
                 khalf[14] = me_bigkey4_min(w, cj);
+                if (sp && h32 == 1) {                                                 // (64x32_1, 32x16_5) of the lane's points
+                    unsigned b5[4];
+                    me_unpack4(PB[0], b5);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (cj[j] != 0xffffffffu) s_pair[cj[j]] = make_uint2(w[j], b5[j] << 1);
+                }
             }
             khalf[15] = 0xffffffffu;
             put16(7 * h32 + 6, khalf);
@@ -809,14 +827,37 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const unsigned sad = wide ? key >> 12 : (key >> 16) << 1;
         const unsigned cand = key & 0xfffu;
         const int ys = (int)cand / search_w, xs = (int)cand - ys * search_w;
-        const int ox = origins ? origins[2 * blk] : x_origin, oy = origins ? origins[2 * blk + 1] : y_origin;
-        uint32_t* bs = best_sad + (size_t)blk * pu_pitch;
-        uint32_t* bm = best_mv + (size_t)blk * pu_pitch;
-        if (sad < bs[tid]) {
+        if (sad < bs[tid] && !(sp && tid == 92)) {         // (32x16_5 in the single-point form has no key: it is replayed below)
             bs[tid] = sad;
             bm[tid] = (((uint32_t)(uint16_t)(ys + oy)) << 18) | (uint32_t)(uint16_t)((xs + ox) << 2);
         }
     }
+    if (sp && tid == ME_THREADS - 1) {                     // 32x16_5, single-point form: the reference's rule in search order
+        unsigned best = bs[92], mv = bm[92];
+        const int np = search_w * search_h;
+        for (int p = 0, ys = 0, xs = 0; p < np; p++) {
+            const uint2 v = s_pair[p];
+            if (v.x < best) { best = v.y; mv = (((uint32_t)(uint16_t)(ys + oy)) << 18) | (uint32_t)(uint16_t)((xs + ox) << 2); }
+            if (++xs == search_w) { xs = 0; ys++; }
+        }
+        bs[92] = best; bm[92] = mv;
+    }
+}
+
+__global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void me_nsq4_kernel(
+    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
+    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
+    const int16_t* __restrict__ origins /* [n][2] x,y or NULL */, int x_origin, int y_origin,
+    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t wpitch,
+    const uint32_t* __restrict__ src_offs, const uint32_t* __restrict__ ref_offs, uint32_t nblocks, uint32_t pu_pitch) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t blk = blockIdx.x;
+    if (blk >= nblocks) return;
+    const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
+    const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
+    const int ox = origins ? origins[2 * blk] : x_origin, oy = origins ? origins[2 * blk + 1] : y_origin;
+    me_nsq4_body(smem, gs, src_stride, gr, ref_stride, search_w, search_h, ox, oy, best_sad + (size_t)blk * pu_pitch,
+                 best_mv + (size_t)blk * pu_pitch, wpitch, nullptr);
 }
 
 // me_fullpel_exact_kernel — the reference's search, search point by search point, in its own order: every width, both
@@ -835,18 +876,12 @@ __global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 //     own) beats its best (ExtSadCalculation's stale `sad`, EbMotionEstimation.c:732-736) - both flavours;
 //   * the same points, flavour 1: the lower 8x8 pair of every 16x16 reads its first reference row 8 SOURCE strides below
 //     the 16x16's reference origin (ext_sad_calculation_8x8_16x16_avx2_intrin, EbComputeSAD_Intrinsic_AVX2.c:50-52).
-__global__ __launch_bounds__(ME_THREADS) void me_fullpel_exact_kernel(
-    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch, const uint32_t* __restrict__ src_offs,
-    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, const uint32_t* __restrict__ ref_offs,
-    int search_w, int search_h, const int16_t* __restrict__ origins, int x_origin, int y_origin, int flavour, int nsq,
-    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t pu_pitch, uint32_t nblocks) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_src[32 * 16];      // even source rows
-    __shared__ uint32_t s_s8[8][64];                                       // [point of the step][8x8 block, raster]
-    const uint32_t blk = blockIdx.x;
-    if (blk >= nblocks) return;
+// body: s_src = 2 KiB (even source rows), s_s8 = 2 KiB ([point of the step][8x8 block, raster]) of the caller's LDS
+__device__ __forceinline__ void me_exact_body(
+    uint32_t* s_src, uint32_t (*s_s8)[64], const uint8_t* __restrict__ gs, uint32_t src_stride, const uint8_t* __restrict__ gr,
+    uint32_t ref_stride, int search_w, int search_h, int ox, int oy, int flavour, int nsq, uint32_t* __restrict__ bs_row,
+    uint32_t* __restrict__ bm_row) {
     const int tid = threadIdx.x;
-    const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
-    const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
     if (tid < 128) {
         const int r = tid >> 2, c = tid & 3;
         uint4 v;
@@ -854,13 +889,12 @@ __global__ __launch_bounds__(ME_THREADS) void me_fullpel_exact_kernel(
         reinterpret_cast<uint4*>(s_src)[tid] = v;
     }
     const int npus = nsq ? ME_PUS_ALL : ME_PUS;
-    const int ox = origins ? origins[2 * blk] : x_origin, oy = origins ? origins[2 * blk + 1] : y_origin;
     int px = 0, py = 0, pw = 0, ph = 0;
     uint32_t bsad = 0, bmv = 0;
     if (tid < npus) {
         me_pu_rect(tid, px, py, pw, ph);
-        bsad = best_sad[(size_t)blk * pu_pitch + tid];
-        bmv = best_mv[(size_t)blk * pu_pitch + tid];
+        bsad = bs_row[tid];
+        bmv = bm_row[tid];
     }
     const int w8 = search_w & ~7;
     __syncthreads();
@@ -909,8 +943,262 @@ __global__ __launch_bounds__(ME_THREADS) void me_fullpel_exact_kernel(
         }
     }
     if (tid < npus) {
-        best_sad[(size_t)blk * pu_pitch + tid] = bsad;
-        best_mv[(size_t)blk * pu_pitch + tid] = bmv;
+        bs_row[tid] = bsad;
+        bm_row[tid] = bmv;
+    }
+}
+
+__global__ __launch_bounds__(ME_THREADS) void me_fullpel_exact_kernel(
+    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch, const uint32_t* __restrict__ src_offs,
+    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, const uint32_t* __restrict__ ref_offs,
+    int search_w, int search_h, const int16_t* __restrict__ origins, int x_origin, int y_origin, int flavour, int nsq,
+    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t pu_pitch, uint32_t nblocks) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_src[32 * 16];      // even source rows
+    __shared__ uint32_t s_s8[8][64];                                       // [point of the step][8x8 block, raster]
+    const uint32_t blk = blockIdx.x;
+    if (blk >= nblocks) return;
+    const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
+    const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
+    const int ox = origins ? origins[2 * blk] : x_origin, oy = origins ? origins[2 * blk + 1] : y_origin;
+    me_exact_body(s_src, s_s8, gs, src_stride, gr, ref_stride, search_w, search_h, ox, oy, flavour, nsq, best_sad + (size_t)blk * pu_pitch,
+                  best_mv + (size_t)blk * pu_pitch);
+}
+
+// ---------------------------------------------------------------------------
+// me_fullpel_areas_kernel — the full-pel search of a batch whose SBs each have their OWN search area (x_origin, y_origin,
+// width, height), as svt_hip_me_setup_batch derives them on the device (MotionEstimateLcu clips every SB's area against the
+// picture, EbMotionEstimation.c:7955-8040): one launch for a picture's interior and edge SBs alike.  A workgroup reads its
+// area, points at its window (the SB's co-located position in the reference plane + the area's origin) and takes the body
+// that covers its shape: square search -> me_sb_search16_body (any width, both flavours); all 209 PUs -> me_nsq4_body when the
+// width is a multiple of 8, or below 8 in the C flavour; everything else (widths >= 9 that are not a multiple of 8, which the
+// reference's rounding never produces, and narrow areas in the AVX2 flavour with its source-stride row fetch) ->
+// me_exact_body, whose cost is proportional to the number of search points.  An area with a non-positive size or more than
+// max_w x max_h points (what the launch's LDS was sized for) is skipped: the SB's rows keep their incoming values.
+// ---------------------------------------------------------------------------
+template <bool NSQ>
+__global__ __launch_bounds__(ME_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void me_fullpel_areas_kernel(
+    const uint8_t* __restrict__ src, uint32_t src_stride, const uint32_t* __restrict__ src_offs, const uint8_t* __restrict__ ref,
+    uint32_t ref_stride, const uint32_t* __restrict__ ref_offs, const int16_t* __restrict__ areas /* [n][4] */, int max_w, int max_h,
+    int flavour, uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t pu_pitch, uint32_t wpitch, uint32_t pair_off,
+    uint32_t nblocks) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t blk = blockIdx.x;
+    if (blk >= nblocks) return;
+    const int ox = areas[4 * blk], oy = areas[4 * blk + 1], sw = areas[4 * blk + 2], sh = areas[4 * blk + 3];
+    if (sw < 1 || sh < 1 || sw > max_w || sh > max_h) return;
+    const uint8_t* gs = src + (size_t)src_offs[blk];
+    const uint8_t* gr = ref + (size_t)ref_offs[blk] + (ptrdiff_t)oy * (ptrdiff_t)ref_stride + ox;
+    uint32_t* bs = best_sad + (size_t)blk * pu_pitch;
+    uint32_t* bm = best_mv + (size_t)blk * pu_pitch;
+    if (!NSQ) {
+        me_sb_search16_body<true>(smem, gs, src_stride, gr, ref_stride, sw, sh, ox, oy, bs, bm, wpitch, flavour == 1 ? (sw & ~7) : 0, 1);
+    } else if ((sw & 7) == 0 || (sw < 8 && flavour == 0 && pair_off)) {
+        me_nsq4_body(smem, gs, src_stride, gr, ref_stride, sw, sh, ox, oy, bs, bm, wpitch, reinterpret_cast<uint2*>(smem + pair_off));
+    } else {
+        me_exact_body(reinterpret_cast<uint32_t*>(smem), reinterpret_cast<uint32_t(*)[64]>(smem + 2048), gs, src_stride, gr, ref_stride, sw, sh, ox,
+                      oy, flavour, 1, bs, bm);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// me_setup_kernel — what MotionEstimateLcu does per SB x reference between the HME levels and the full-pel search
+// (EbMotionEstimation.c:7849-8040), for a whole batch: (1) the search centre = the first strict minimum of the last HME level's
+// SADs over its search regions in the order the reference visits them, or, for list 1 of a picture whose two references are the
+// same picture, the second entry after its sort of the regions (:7906-7936); no HME result is used for SBs that are not 64 rows
+// high ("no HME in boundaries", :7678); (2) CheckZeroZeroCenter (:6844-6930): the centre is clipped into the reference picture
+// and kept only if the SB's SAD there (every other row, doubled) is strictly below its SAD at (0, 0); (3) the search area: width
+// rounded up to 8, centred, clipped left / right / top / bottom in the reference's statement order (its "shrink" statements test
+// the corrected origin and never fire), width rounded down to 8 unless below 8.  One wave per task: lanes 0..31 take the rows of
+// the (0, 0) SAD, lanes 32..63 those of the HME-centre SAD.
+// ---------------------------------------------------------------------------
+struct MeSetupParams {      // == svt_hip_me_setup_params (include/svt_hip_dsp.h)
+    int32_t picture_width, picture_height, ref_width, ref_height, search_area_width, search_area_height, regions_w, regions_h,
+        second_best, zz_check;
+};
+
+__global__ __launch_bounds__(256) void me_setup_kernel(
+    const uint8_t* __restrict__ src_pic, uint32_t src_stride, const uint8_t* __restrict__ ref_pic, uint32_t ref_stride,
+    const int16_t* __restrict__ sb_origin /* [n][2] */, const uint16_t* __restrict__ sb_size /* [n][2] */,
+    const unsigned long long* __restrict__ hme_sad /* [regions][n] or NULL */, const int16_t* __restrict__ hme_mv /* [regions][n][2] */,
+    const MeSetupParams p, int16_t* __restrict__ center /* [n][2] or NULL */, int16_t* __restrict__ area /* [n][4] */, uint32_t ntasks) {
+    const uint32_t task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (task >= ntasks) return;                             // wave-uniform; nothing below synchronises across waves
+    const int ox = sb_origin[2 * task], oy = sb_origin[2 * task + 1];
+    const int sbw = sb_size[2 * task], sbh = sb_size[2 * task + 1];
+    const int nreg = p.regions_w * p.regions_h;
+    int xc = 0, yc = 0;
+    if (hme_sad && nreg > 0 && sbh == 64) {
+        // region r = rh * regions_w + rw: r = 0, 1, 2, 3 is the reference's visiting order [w][h] = [0][0], [1][0], [0][1], [1][1]
+        unsigned long long s[4];
+        int cx[4], cy[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const bool on = r < nreg;
+            s[r] = on ? hme_sad[(size_t)r * ntasks + task] : ~0ull;
+            cx[r] = on ? hme_mv[((size_t)r * ntasks + task) * 2] : 0;
+            cy[r] = on ? hme_mv[((size_t)r * ntasks + task) * 2 + 1] : 0;
+        }
+        unsigned long long best = s[0];
+        xc = cx[0]; yc = cy[0];
+#pragma unroll
+        for (int r = 1; r < 4; r++)
+            if (r < nreg && s[r] < best) { best = s[r]; xc = cx[r]; yc = cy[r]; }
+        if (p.second_best && nreg > 1) {
+            // the reference sorts its [width][height] arrays through the index [q / regions_w][q % regions_w] (:7912-7930): entry q
+            // is region (rw, rh) = (q / W, q % W), i.e. r = (q % W) * W + q / W (square region grids only; the host checks)
+            const int W = p.regions_w;
+            int rq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) rq[q] = q < nreg ? (q % W) * W + q / W : 0;
+            unsigned long long t[4];
+            int tx[4], ty[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { t[q] = s[rq[q]]; tx[q] = cx[rq[q]]; ty[q] = cy[rq[q]]; }
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int n = q + 1; n < 4; n++)
+                    if (n < nreg && t[q] > t[n]) {
+                        const unsigned long long ts = t[q]; t[q] = t[n]; t[n] = ts;
+                        const int a = tx[q]; tx[q] = tx[n]; tx[n] = a;
+                        const int b = ty[q]; ty[q] = ty[n]; ty[n] = b;
+                    }
+            xc = tx[1]; yc = ty[1];
+        }
+    }
+    const int pad = 63;                                     // BLOCK_SIZE_64 - 1
+    if ((xc != 0 || yc != 0) && p.zz_check) {
+        int hx = xc, hy = yc;
+        if (ox + hx < -pad) hx = -pad - ox;
+        if (ox + hx > p.ref_width - 1) hx -= (ox + hx) - (p.ref_width - 1);
+        if (oy + hy < -pad) hy = -pad - oy;
+        if (oy + hy > p.ref_height - 1) hy -= (oy + hy) - (p.ref_height - 1);
+        const bool second = lane >= 32;
+        const int row = lane & 31;
+        unsigned sad = 0;
+        if (row < (sbh >> 1)) {
+            const uint8_t* a = src_pic + (ptrdiff_t)(oy + 2 * row) * (ptrdiff_t)src_stride + ox;
+            const uint8_t* b = ref_pic + (ptrdiff_t)(oy + (second ? hy : 0) + 2 * row) * (ptrdiff_t)ref_stride + ox + (second ? hx : 0);
+            for (int c = 0; c < sbw; c += 4) {
+                uint32_t va = 0, vb = 0;
+                if (c + 4 <= sbw) { __builtin_memcpy(&va, a + c, 4); __builtin_memcpy(&vb, b + c, 4); }
+                else for (int k = 0; c + k < sbw; k++) { va |= (uint32_t)a[c + k] << (8 * k); vb |= (uint32_t)b[c + k] << (8 * k); }
+                sad = __builtin_amdgcn_sad_u8(va, vb, sad);
+            }
+        }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) sad += (unsigned)__shfl_xor((int)sad, m, 64);
+        const unsigned zero = (unsigned)__shfl((int)sad, 0, 64) << 1, hme = (unsigned)__shfl((int)sad, 32, 64) << 1;
+        // MIN(zero cost, hme cost) == zero cost: hmeMvdRate is 0 and MD_OFFSET >> MD_SHIFT is 0, the costs are the SADs << 8
+        if (zero <= hme) { xc = 0; yc = 0; } else { xc = hx; yc = hy; }
+    }
+    int saw = (p.search_area_width + 7) & ~7, sah = p.search_area_height;
+    int xo = xc - (saw >> 1), yo = yc - (sah >> 1);
+    const int W = p.picture_width, H = p.picture_height;
+    if (ox + xo < -pad) xo = -pad - ox;
+    if (ox + xo < -pad) saw -= -pad - (ox + xo);            // never true after the line above (as in the reference)
+    if (ox + xo > W - 1) xo -= (ox + xo) - (W - 1);
+    if (ox + xo + saw > W) saw = max(1, saw - ((ox + xo + saw) - W));
+    if (saw >= 8) saw &= ~7;
+    if (oy + yo < -pad) yo = -pad - oy;
+    if (oy + yo < -pad) sah -= -pad - (oy + yo);
+    if (oy + yo > H - 1) yo -= (oy + yo) - (H - 1);
+    if (oy + yo + sah > H) sah = max(1, sah - ((oy + yo + sah) - H));
+    if (lane == 0) {
+        if (center) { center[2 * task] = (int16_t)xc; center[2 * task + 1] = (int16_t)yc; }
+        area[4 * task] = (int16_t)xo; area[4 * task + 1] = (int16_t)yo; area[4 * task + 2] = (int16_t)saw; area[4 * task + 3] = (int16_t)sah;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// me_bipred_kernel — BiPredictionSearch (EbMotionEstimation.c:6639 -> BiPredictionCompensation :6457 -> BiPredAverging :6317,
+// integer vectors) and the candidate ordering MotionEstimateLcu writes into me_results (:8308-8440) for every SB of a batch.
+// One workgroup per SB.  Phase 1: a work item is one compared row of one PU (src row against the rounded average of the two
+// lists' blocks at that PU's best vectors; every other row and doubled when sub_sad); the items of a PU add into its LDS cell.
+// Phase 2: lane p < npus takes RASTER PU p (the order of me_results, partitionWidth / puSearchIndexMap), whose vectors and SADs
+// sit at storage index n = map.storage[p] of the result rows (EbMeTierZeroPu order, 16x16 / 8x8 derived shapes in z-order), and
+// orders {list 0, list 1, bi} as Sort3Elements (:6809) / the two-candidate rule do.
+// ---------------------------------------------------------------------------
+struct MePuMap {
+    uint8_t storage[ME_PUS_ALL];        // raster PU index -> storage index
+    uint8_t x8[ME_PUS_ALL], y8[ME_PUS_ALL], w8[ME_PUS_ALL], h8[ME_PUS_ALL];   // rectangle of RASTER PU p in units of 8 samples
+    uint16_t row0[ME_PUS_ALL + 1];      // number of every-other-row rows (h / 2 per PU) of the raster PUs before p: the work-item numbering
+};
+struct MeResult {                       // == svt_hip_me_result (include/svt_hip_dsp.h)
+    int16_t x_mv_l0, y_mv_l0, x_mv_l1, y_mv_l1;
+    uint32_t distortion[3];
+    uint8_t direction[3], total_me_candidate_index;
+};
+
+__global__ __launch_bounds__(ME_THREADS) void me_bipred_kernel(
+    const uint8_t* __restrict__ src_pic, uint32_t src_stride, const uint8_t* __restrict__ ref0_pic, uint32_t ref0_stride,
+    const uint8_t* __restrict__ ref1_pic, uint32_t ref1_stride, const int16_t* __restrict__ sb_origin,
+    const uint32_t* __restrict__ best_sad0, const uint32_t* __restrict__ best_mv0, const uint32_t* __restrict__ best_sad1,
+    const uint32_t* __restrict__ best_mv1, uint32_t pu_pitch, int npus, int bipred_all_pus, int sub_sad, const MePuMap map,
+    uint32_t* __restrict__ bipred_sad /* [n][pu_pitch] storage order, or NULL */, MeResult* __restrict__ results /* [n][npus] raster order */,
+    uint32_t nsb) {
+    __shared__ unsigned s_bi[ME_PUS_ALL];
+    const uint32_t sb = blockIdx.x;
+    if (sb >= nsb) return;
+    const int tid = threadIdx.x;
+    const int ox = sb_origin[2 * sb], oy = sb_origin[2 * sb + 1];
+    const bool two = best_sad1 != nullptr;
+    for (int i = tid; i < ME_PUS_ALL; i += ME_THREADS) s_bi[i] = 0;
+    __syncthreads();
+    if (two) {
+        const int nbi = bipred_all_pus ? npus : min(npus, 21);
+        const int nitems = sub_sad ? map.row0[nbi] : 2 * map.row0[nbi];
+        for (int it = tid; it < nitems; it += ME_THREADS) {
+            const int key = sub_sad ? it : (it >> 1);        // position in the sub-sampled row numbering
+            int lo = 0, hi = nbi - 1;                        // PU whose item range holds `key`
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (map.row0[mid] <= key) lo = mid; else hi = mid - 1; }
+            const int p = lo, n = map.storage[p];
+            const int row = sub_sad ? 2 * (key - map.row0[p]) : 2 * (key - map.row0[p]) + (it & 1);
+            const uint32_t m0 = best_mv0[(size_t)sb * pu_pitch + n], m1 = best_mv1[(size_t)sb * pu_pitch + n];
+            const int x0 = (int16_t)(m0 & 0xffffu) >> 2, y0 = (int16_t)(m0 >> 16) >> 2, x1 = (int16_t)(m1 & 0xffffu) >> 2, y1 = (int16_t)(m1 >> 16) >> 2;
+            const int px = ox + 8 * map.x8[p], py = oy + 8 * map.y8[p] + row, w = 8 * map.w8[p];
+            const uint8_t* a = src_pic + (ptrdiff_t)py * (ptrdiff_t)src_stride + px;
+            const uint8_t* b = ref0_pic + (ptrdiff_t)(py + y0) * (ptrdiff_t)ref0_stride + px + x0;
+            const uint8_t* c = ref1_pic + (ptrdiff_t)(py + y1) * (ptrdiff_t)ref1_stride + px + x1;
+            unsigned sad = 0;
+            for (int k = 0; k < w; k += 8) {
+                uint2 va, vb, vc;
+                __builtin_memcpy(&va, a + k, 8); __builtin_memcpy(&vb, b + k, 8); __builtin_memcpy(&vc, c + k, 8);
+                // rounded average of four byte pairs: (x | y) - (((x ^ y) >> 1) & 0x7f7f7f7f)
+                const uint32_t ax = (vb.x | vc.x) - (((vb.x ^ vc.x) >> 1) & 0x7f7f7f7fu), ay = (vb.y | vc.y) - (((vb.y ^ vc.y) >> 1) & 0x7f7f7f7fu);
+                sad = __builtin_amdgcn_sad_u8(va.x, ax, sad);
+                sad = __builtin_amdgcn_sad_u8(va.y, ay, sad);
+            }
+            atomicAdd(&s_bi[n], sub_sad ? sad << 1 : sad);
+        }
+    }
+    __syncthreads();
+    if (tid < npus) {
+        const int p = tid, n = map.storage[p];
+        const uint32_t l0 = best_sad0[(size_t)sb * pu_pitch + n], m0 = best_mv0[(size_t)sb * pu_pitch + n];
+        const uint32_t l1 = two ? best_sad1[(size_t)sb * pu_pitch + n] : 0, m1 = two ? best_mv1[(size_t)sb * pu_pitch + n] : 0;
+        const bool has_bi = two && (bipred_all_pus || p < 21);
+        const uint32_t bi = s_bi[n];
+        if (bipred_sad && has_bi) bipred_sad[(size_t)sb * pu_pitch + n] = bi;
+        MeResult r;
+        r.x_mv_l0 = (int16_t)(m0 & 0xffffu); r.y_mv_l0 = (int16_t)(m0 >> 16); r.x_mv_l1 = (int16_t)(m1 & 0xffffu); r.y_mv_l1 = (int16_t)(m1 >> 16);
+        const uint32_t d[3] = {l0, l1, bi};
+        int o0 = 0, o1 = 1, o2 = 2, total = two ? 2 : 1;
+        if (has_bi) {
+            total = 3;
+            if (l0 <= l1 && l0 <= bi) { o0 = 0; o1 = l1 <= bi ? 1 : 2; o2 = l1 <= bi ? 2 : 1; }
+            else if (l1 <= l0 && l1 <= bi) { o0 = 1; o1 = l0 <= bi ? 0 : 2; o2 = l0 <= bi ? 2 : 0; }
+            else if (l0 <= l1) { o0 = 2; o1 = 0; o2 = 1; }
+            else { o0 = 2; o1 = 1; o2 = 0; }
+        } else if (two) {
+            o0 = l0 <= l1 ? 0 : 1; o1 = 1 - o0;
+        }
+        r.distortion[0] = d[o0]; r.direction[0] = (uint8_t)o0;
+        r.distortion[1] = total > 1 ? d[o1] : 0; r.direction[1] = total > 1 ? (uint8_t)o1 : 0;
+        r.distortion[2] = total > 2 ? d[o2] : 0; r.direction[2] = total > 2 ? (uint8_t)o2 : 0;
+        r.total_me_candidate_index = (uint8_t)total;
+        results[(size_t)sb * npus + p] = r;
     }
 }
 

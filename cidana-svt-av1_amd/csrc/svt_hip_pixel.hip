@@ -421,6 +421,118 @@ extern "C" int svt_hip_me_fullpel_search_batch(const uint8_t* d_src, uint32_t sr
     return launch_status("me_fullpel_exact");
 }
 
+// ---- MotionEstimateLcu's glue: set-up, per-SB areas, bi-prediction + result rows (include/svt_hip_dsp.h) --------------------
+extern "C" int svt_hip_me_setup_batch(const uint8_t* d_src_pic, uint32_t src_stride, const uint8_t* d_ref_pic, uint32_t ref_stride,
+                                      const int16_t* d_sb_origin, const uint16_t* d_sb_size, const uint64_t* d_hme_sad, const int16_t* d_hme_mv,
+                                      const svt_hip_me_setup_params* params, int16_t* d_center, int16_t* d_area, size_t ntasks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (ntasks == 0) return SVT_HIP_OK;
+    if (!d_src_pic || !d_ref_pic || !d_sb_origin || !d_sb_size || !params || !d_area) return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    if ((d_hme_sad == nullptr) != (d_hme_mv == nullptr)) return set_err(SVT_HIP_ERR_INVALID, "d_hme_sad and d_hme_mv go together");
+    const svt_hip_me_setup_params& P = *params;
+    if (P.regions_w < 0 || P.regions_w > 2 || P.regions_h < 0 || P.regions_h > 2 || (P.regions_w == 0) != (P.regions_h == 0))
+        return set_err(SVT_HIP_ERR_INVALID, "%d x %d search regions (0 x 0, or 1 .. 2 each)", P.regions_w, P.regions_h);
+    // the reference's sort walks its [width][height] arrays through [q / regions_w][q % regions_w]: outside a square grid that reads
+    // entries no level has written (stack garbage in the reference) - refused rather than guessed
+    if (P.second_best && P.regions_w != P.regions_h) return set_err(SVT_HIP_ERR_INVALID, "second_best needs regions_w == regions_h");
+    if (P.search_area_width < 1 || P.search_area_height < 1 || P.search_area_width > 4096 || P.search_area_height > 4096 || P.picture_width < 1 ||
+        P.picture_height < 1 || P.ref_width < 1 || P.ref_height < 1)
+        return set_err(SVT_HIP_ERR_INVALID, "search area %d x %d, picture %d x %d", P.search_area_width, P.search_area_height, P.picture_width, P.picture_height);
+    if (ntasks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many tasks");
+    static_assert(sizeof(MeSetupParams) == sizeof(svt_hip_me_setup_params), "layout");
+    MeSetupParams mp;
+    memcpy(&mp, params, sizeof(mp));
+    hipLaunchKernelGGL(me_setup_kernel, dim3((uint32_t)((ntasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_src_pic, src_stride, d_ref_pic,
+                       ref_stride, d_sb_origin, d_sb_size, (const unsigned long long*)d_hme_sad, d_hme_mv, mp, d_center, d_area, (uint32_t)ntasks);
+    return launch_status("me_setup");
+}
+
+extern "C" int svt_hip_me_fullpel_search_areas_batch(const uint8_t* d_src, uint32_t src_stride, const uint32_t* d_src_offsets, const uint8_t* d_ref,
+                                                     uint32_t ref_stride, const uint32_t* d_ref_offsets, const int16_t* d_areas, int max_search_w,
+                                                     int max_search_h, int flavour, int nsq, uint32_t* d_best_sad, uint32_t* d_best_mv,
+                                                     uint32_t pu_pitch, size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_src || !d_ref || !d_src_offsets || !d_ref_offsets || !d_areas || !d_best_sad || !d_best_mv) return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    if (flavour != SVT_HIP_FLAVOUR_C && flavour != SVT_HIP_FLAVOUR_AVX2) return set_err(SVT_HIP_ERR_INVALID, "flavour %d", flavour);
+    const uint32_t npus = nsq ? SVT_HIP_ME_PUS_ALL : SVT_HIP_ME_PUS;
+    if (pu_pitch < npus) return set_err(SVT_HIP_ERR_INVALID, "pu_pitch %u < %u PUs", pu_pitch, npus);
+    if (max_search_w <= 0 || max_search_h <= 0 || max_search_w * max_search_h > 4096)
+        return set_err(SVT_HIP_ERR_INVALID, "search area bound %dx%d (1..4096 points)", max_search_w, max_search_h);
+    if (nblocks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks");
+    const uint32_t win_w = 64 + max_search_w - 1, win_h = 64 + max_search_h - 1;
+    const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+    size_t lds = 32 * 64 + (size_t)wpitch * win_h;
+    uint32_t pair_off = 0;
+    if (nsq) {                                            // (64x32_1, 32x16_5) pairs of the narrow single-point areas: <= 7 x max_h points
+        pair_off = (uint32_t)((lds + 15) & ~(size_t)15);
+        lds = pair_off + (size_t)8 * 7 * max_search_h;
+    }
+    if (lds > 58 * 1024) return set_err(SVT_HIP_ERR_INVALID, "search window of %dx%d needs %zu B of LDS (> 58 KiB)", max_search_w, max_search_h, lds);
+    if (nsq)
+        hipLaunchKernelGGL(me_fullpel_areas_kernel<true>, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src, src_stride, d_src_offsets,
+                           d_ref, ref_stride, d_ref_offsets, d_areas, max_search_w, max_search_h, flavour, d_best_sad, d_best_mv, pu_pitch, wpitch,
+                           pair_off, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL(me_fullpel_areas_kernel<false>, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src, src_stride, d_src_offsets,
+                           d_ref, ref_stride, d_ref_offsets, d_areas, max_search_w, max_search_h, flavour, d_best_sad, d_best_mv, pu_pitch, wpitch,
+                           pair_off, (uint32_t)nblocks);
+    return launch_status("me_fullpel_areas");
+}
+
+// raster PU order (partitionWidth / partitionHeight / puSearchIndexMap, EbMotionEstimation.h:178-315): 14 shape groups, each a
+// raster walk of its grid; the storage index is the PU of the result rows with the same rectangle (me_pu_rect)
+static const MePuMap& me_pu_map() {
+    static const MePuMap m = [] {
+        MePuMap t;
+        memset(&t, 0, sizeof(t));
+        static const int gw[14] = {8, 4, 2, 1, 8, 4, 2, 4, 2, 1, 4, 1, 8, 2}, gh[14] = {8, 4, 2, 1, 4, 2, 1, 8, 4, 2, 1, 4, 2, 8};
+        int p = 0, rows = 0;
+        for (int g = 0; g < 14; g++) {
+            const int cols = 8 / gw[g], n = cols * (8 / gh[g]);
+            for (int i = 0; i < n; i++, p++) {
+                const int x = (i % cols) * gw[g], y = (i / cols) * gh[g];
+                t.x8[p] = (uint8_t)x; t.y8[p] = (uint8_t)y; t.w8[p] = (uint8_t)gw[g]; t.h8[p] = (uint8_t)gh[g];
+                t.row0[p] = (uint16_t)rows;
+                rows += 4 * gh[g];
+                int found = 255;
+                for (int q = 0; q < ME_PUS_ALL; q++) {
+                    int qx, qy, qw, qh;
+                    me_pu_rect(q, qx, qy, qw, qh);
+                    if (qx == x && qy == y && qw == gw[g] && qh == gh[g]) { found = q; break; }
+                }
+                t.storage[p] = (uint8_t)found;
+            }
+        }
+        t.row0[ME_PUS_ALL] = (uint16_t)rows;
+        return t;
+    }();
+    return m;
+}
+extern "C" int svt_hip_me_pu_storage_index(int pu_index) {
+    if (pu_index < 0 || pu_index >= ME_PUS_ALL) return -1;
+    return me_pu_map().storage[pu_index];
+}
+
+extern "C" int svt_hip_me_bipred_batch(const uint8_t* d_src_pic, uint32_t src_stride, const uint8_t* d_ref0_pic, uint32_t ref0_stride,
+                                       const uint8_t* d_ref1_pic, uint32_t ref1_stride, const int16_t* d_sb_origin, const uint32_t* d_best_sad0,
+                                       const uint32_t* d_best_mv0, const uint32_t* d_best_sad1, const uint32_t* d_best_mv1, uint32_t pu_pitch, int npus,
+                                       int bipred_all_pus, int sub_sad, uint32_t* d_bipred_sad, svt_hip_me_result* d_results, size_t nsb, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nsb == 0) return SVT_HIP_OK;
+    if (!d_src_pic || !d_sb_origin || !d_best_sad0 || !d_best_mv0 || !d_results) return set_err(SVT_HIP_ERR_INVALID, "NULL argument");
+    if ((d_best_sad1 == nullptr) != (d_best_mv1 == nullptr)) return set_err(SVT_HIP_ERR_INVALID, "d_best_sad1 and d_best_mv1 go together");
+    if (d_best_sad1 && (!d_ref0_pic || !d_ref1_pic)) return set_err(SVT_HIP_ERR_INVALID, "two lists need both reference planes");
+    if (npus != SVT_HIP_ME_PUS && npus != SVT_HIP_ME_PUS_ALL) return set_err(SVT_HIP_ERR_INVALID, "npus %d (85 or 209)", npus);
+    if (pu_pitch < (uint32_t)npus) return set_err(SVT_HIP_ERR_INVALID, "pu_pitch %u < %d PUs", pu_pitch, npus);
+    if (nsb > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many SBs");
+    static_assert(sizeof(MeResult) == sizeof(svt_hip_me_result), "layout");
+    hipLaunchKernelGGL(me_bipred_kernel, dim3((uint32_t)nsb), dim3(ME_THREADS), 0, (hipStream_t)stream, d_src_pic, src_stride, d_ref0_pic, ref0_stride,
+                       d_ref1_pic, ref1_stride, d_sb_origin, d_best_sad0, d_best_mv0, d_best_sad1, d_best_mv1, pu_pitch, npus, bipred_all_pus ? 1 : 0,
+                       sub_sad ? 1 : 0, me_pu_map(), d_bipred_sad, reinterpret_cast<MeResult*>(d_results), (uint32_t)nsb);
+    return launch_status("me_bipred");
+}
+
 static int full_distortion32_impl(const int32_t* d_coeff, uint32_t coeff_stride, size_t coeff_block_pitch, const int32_t* d_recon,
                                   uint32_t recon_stride, size_t recon_block_pitch, uint32_t width, uint32_t height,
                                   int cbf_zero, const uint32_t* d_nz, int flavour, uint64_t* d_out, size_t nblocks, void* stream) {

@@ -415,6 +415,63 @@ int svt_hip_me_fullpel_search_batch(const uint8_t *d_src, uint32_t src_stride, s
                                     int flavour, int nsq, uint32_t *d_best_sad, uint32_t *d_best_mv,
                                     uint32_t pu_pitch, size_t nblocks, void *stream);
 
+/* ---- MotionEstimateLcu's per-SB glue around the full-pel search (EbMotionEstimation.c:7527) ---------------------
+ * (1) svt_hip_me_setup_batch: between the HME levels and the search - per task (SB x reference picture) the search centre
+ *     (first strict minimum of the last enabled HME level's SADs over its search regions, :7849-7941; for list 1 of a picture
+ *     whose two references are the same picture the second entry of the reference's region sort, :7906-7936; SBs that are not
+ *     64 rows high take no HME result, :7678), CheckZeroZeroCenter (:6844-6930, run when zz_check = is_used_as_reference_flag)
+ *     and the search area: width rounded up to 8, centred, clipped against the picture in the reference's statement order,
+ *     width rounded down to 8 unless below 8 (:7955-8040).
+ *       d_src_pic / d_ref_pic    sample (0, 0) of the padded 8-bit source / reference luma planes (>= 63 + 64 samples of padding)
+ *       d_sb_origin / d_sb_size  [n][2] (x, y) / (width, height) of the SBs
+ *       d_hme_sad / d_hme_mv     [region][n] / [region][n][2] outputs of the last enabled level (svt_hip_hme_level_regions_batch),
+ *                                region r = rh * regions_w + rw; NULL (or regions 0 x 0): no HME, every centre is (0, 0)
+ *       d_center (may be NULL)   [n][2] the centre after CheckZeroZeroCenter;  d_area  [n][4] x_origin, y_origin, width, height
+ * (2) svt_hip_me_fullpel_search_areas_batch: svt_hip_me_fullpel_search_batch with ONE AREA PER SB, read on the device from
+ *     d_areas (so a picture's interior and clipped edge SBs share one launch and nothing returns to the host in between).
+ *     d_ref_offsets[b] is the byte offset of the SB's CO-LOCATED position in the reference plane; the window starts at that
+ *     position + the area's origin.  max_search_w / _h bound every area of the call (they size the LDS window: the nominal
+ *     area, width rounded up to 8); an area outside 1 .. max is skipped (its rows keep their incoming values).
+ * (3) svt_hip_me_bipred_batch: BiPredictionSearch (:6639, integer vectors: the SAD of each PU against the rounded average of
+ *     its two lists' best blocks; sub_sad = fractionalSearchMethod == SUB_SAD_SEARCH: every other row, doubled) and the
+ *     me_results rows MotionEstimateLcu writes (:8308-8440): vectors, up to three (distortion, direction) candidates in the
+ *     reference's order (Sort3Elements :6809), candidate count.  Result rows are in RASTER PU order (partitionWidth /
+ *     puSearchIndexMap, EbMotionEstimation.h:178-315) and read the SAD / vector rows at the storage index of the same rectangle
+ *     (svt_hip_me_pu_storage_index).  d_best_sad1 / d_best_mv1 NULL: P picture, one candidate.  bipred_all_pus = (cu8x8_mode ==
+ *     CU_8x8_MODE_0 || pic_depth_mode <= PIC_ALL_C_DEPTH_MODE): otherwise only PUs 0 .. 20 are bi-predicted (:8297).  npus 85 or
+ *     209.  me_nsq[] of the reference's rows is not produced (it is written by the sub-pel stage, which is outside this path). */
+typedef struct svt_hip_me_setup_params {
+    int32_t picture_width, picture_height;        /* SequenceControlSet luma_width / luma_height: the search area's clip */
+    int32_t ref_width, ref_height;                /* refPicPtr->width / height: the clip of the HME centre in CheckZeroZeroCenter */
+    int32_t search_area_width, search_area_height;/* MeContext_t values, before the round-up to 8 */
+    int32_t regions_w, regions_h;                 /* number_hme_search_region_in_width / _height (1 or 2 each; 0: no HME) */
+    int32_t second_best;                          /* HME level 2 on && list 1 && ref_pic_poc_array[0] == [1] (needs regions_w == regions_h) */
+    int32_t zz_check;                             /* is_used_as_reference_flag */
+} svt_hip_me_setup_params;
+int svt_hip_me_setup_batch(const uint8_t *d_src_pic, uint32_t src_stride, const uint8_t *d_ref_pic, uint32_t ref_stride,
+                           const int16_t *d_sb_origin, const uint16_t *d_sb_size, const uint64_t *d_hme_sad,
+                           const int16_t *d_hme_mv, const svt_hip_me_setup_params *params, int16_t *d_center, int16_t *d_area,
+                           size_t ntasks, void *stream);
+int svt_hip_me_fullpel_search_areas_batch(const uint8_t *d_src, uint32_t src_stride, const uint32_t *d_src_offsets,
+                                          const uint8_t *d_ref, uint32_t ref_stride, const uint32_t *d_ref_offsets,
+                                          const int16_t *d_areas, int max_search_w, int max_search_h, int flavour, int nsq,
+                                          uint32_t *d_best_sad, uint32_t *d_best_mv, uint32_t pu_pitch, size_t nblocks,
+                                          void *stream);
+typedef struct svt_hip_me_result {                /* MeCuResults_t (EbMotionEstimationLcuResults.h:62-77) without me_nsq */
+    int16_t x_mv_l0, y_mv_l0, x_mv_l1, y_mv_l1;
+    uint32_t distortion[3];
+    uint8_t direction[3];                         /* UNI_PRED_LIST_0 0, UNI_PRED_LIST_1 1, BI_PRED 2 */
+    uint8_t total_me_candidate_index;
+} svt_hip_me_result;
+int svt_hip_me_bipred_batch(const uint8_t *d_src_pic, uint32_t src_stride, const uint8_t *d_ref0_pic, uint32_t ref0_stride,
+                            const uint8_t *d_ref1_pic, uint32_t ref1_stride, const int16_t *d_sb_origin,
+                            const uint32_t *d_best_sad0, const uint32_t *d_best_mv0, const uint32_t *d_best_sad1,
+                            const uint32_t *d_best_mv1, uint32_t pu_pitch, int npus, int bipred_all_pus, int sub_sad,
+                            uint32_t *d_bipred_sad, svt_hip_me_result *d_results, size_t nsb, void *stream);
+/* HOST helper: index in the SAD / vector rows (EbMeTierZeroPu order) of raster PU `pu_index` (0 .. 208), or -1; the
+ * reference's tab8x8 / tab16x16 / tab32x16 ... tables (EbMotionEstimation.h:90-175), derived from the rectangles */
+int svt_hip_me_pu_storage_index(int pu_index);
+
 /* K7 coefficient-domain distortion (full_distortion_kernel32_bits_func_ptr_array /
  * full_distortion_kernel_cbf_zero32_bits_func_ptr_array, EbPictureOperators.h:268-280;
  * C: EbPictureOperators.c:283-346).  d_out: uint64[nblocks][2] =

@@ -679,6 +679,79 @@ def gen_picture():
     np.savez_compressed(os.path.join(HERE, "picture.npz"), **d)
 
 
+ME_SETUP_PARAM_SETS = [
+    # (picture set, keyword overrides of svtlibs.ME_LCU_DEFAULTS)
+    ("edge", dict()),                                                                 # P picture, 85 PUs, 2 x 2 regions, three HME levels
+    ("edge", dict(slice_type=0, pic_depth_mode=0)),                                   # B picture, 209 PUs, bi-prediction on every PU
+    ("edge", dict(slice_type=0, pic_depth_mode=0, search_area_width=7, search_area_height=5, regions_w=1, regions_h=1)),   # widths < 8 everywhere
+    ("edge", dict(slice_type=0, pic_depth_mode=0, ref1_poc=8, temporal_layer_index=2)),                      # same-POC list 1: second-best region
+    ("edge", dict(slice_type=0, pic_depth_mode=0, ref1_poc=8, temporal_layer_index=0)),                      # base layer: list 1 without HME
+    ("edge", dict(slice_type=0, pic_depth_mode=2, cu8x8_mode=1, fractional_search_method=1, is_used_as_reference_flag=0)),   # bi-pred on PUs 0..20, full SAD, no (0,0) check
+    ("edge", dict(slice_type=0, pic_depth_mode=0, hme_l1=0, search_area_width=24, search_area_height=16)),   # level 1 off: level 2 starts from (0, 0)
+    ("edge", dict(slice_type=1, pic_depth_mode=0, hme_l2=0, hme_l0=0, temporal_layer_index=0, hierarchical_levels=4)),
+    ("edge", dict(slice_type=0, pic_depth_mode=0, enable_hme_flag=0, search_area_width=64, search_area_height=16)),
+    ("noise", dict(slice_type=0, pic_depth_mode=0, asm_type=1)),                      # the AVX2 build's flavour on whole SBs
+    ("noise", dict(slice_type=0, pic_depth_mode=2, asm_type=1, search_area_width=30, search_area_height=9, temporal_layer_index=0, hierarchical_levels=5)),
+    ("noise", dict(slice_type=1, pic_depth_mode=0, regions_w=1, regions_h=1, search_area_width=8, search_area_height=64)),
+    # "noise_edge": 200 x 136 of noise - the HME vectors of the 8-wide last SB column are arbitrary, so its 8-wide search areas run over
+    # the right picture edge and are clipped to 1 .. 7 columns: the single-search-point form of the 209-PU search (ExtSadCalculation's
+    # 32x16_5 rule), of the 85-PU search, and (asm_type 1 is not used here: the AVX2 HME kernels are undefined on 2- / 4-wide blocks)
+    ("noise_edge", dict(slice_type=0, pic_depth_mode=0, search_area_width=8, search_area_height=7, is_used_as_reference_flag=0)),
+    ("noise_edge", dict(slice_type=0, pic_depth_mode=0, search_area_width=8, search_area_height=12, temporal_layer_index=0)),
+    ("noise_edge", dict(slice_type=0, pic_depth_mode=2, search_area_width=6, search_area_height=9, is_used_as_reference_flag=0, regions_w=1, regions_h=1)),
+]
+
+
+def me_setup_pictures():
+    """two picture triples (source, list-0 reference, list-1 reference).  "edge": 200 x 136 (an 8-wide last SB column, an 8-high last
+    SB row), smooth content; the references are the source displaced by (+37, +6) and (-29, -11), so HME finds real motion and the
+    search areas of the SBs at the right / left picture edge are clipped to a few columns.  "noise": 256 x 192 of noise with a
+    coarse half (ties), whole SBs only."""
+    rng = np.random.default_rng(7527)
+    a = rng.integers(0, 256, (70, 120)).astype(np.float64)
+    a = np.kron(a, np.ones((4, 4)))
+    k = np.ones(7) / 7
+    a = np.apply_along_axis(lambda r: np.convolve(r, k, "same"), 1, a); a = np.apply_along_axis(lambda r: np.convolve(r, k, "same"), 0, a)
+    base = (a + rng.integers(-5, 6, a.shape)).clip(0, 255).astype(np.uint8)
+    W, H = 200, 136
+    edge = tuple(np.ascontiguousarray(base[64 + dy:64 + dy + H, 64 + dx:64 + dx + W]) for dx, dy in ((0, 0), (37, 6), (-29, -11)))
+    n = [rng.integers(0, 256, (192, 256), dtype=np.uint8) for _ in range(3)]
+    for m in n:
+        m[96:, :] = (m[96:, :] >> 6) << 6
+    n[1][10:74, 20:84] = n[0][64:128, 64:128]
+    ne = tuple(rng.integers(0, 256, (136, 200), dtype=np.uint8) for _ in range(3))
+    return {"edge": edge, "noise": tuple(n), "noise_edge": ne}
+
+
+def gen_me_setup():
+    """MotionEstimateLcu, whole: HME levels -> best-of-regions centre -> CheckZeroZeroCenter -> search-area clipping ->
+    full-pel search -> BiPredictionSearch -> me_results, by the reference's OWN function through oracle/ref_me.c
+    (ref_motion_estimate_lcu), for every SB of two small pictures under fifteen parameter sets."""
+    import svtlibs
+    pics = me_setup_pictures()
+    d = {}
+    prm_all, key_all, outs = [], [], {k: [] for k in ("best_sad", "best_mv", "area_origin", "bipred_sad", "results")}
+    for name, planes in pics.items():
+        for i, pl in enumerate(planes):
+            d[f"{name}_pic{i}"] = pl
+    for si, (name, kw) in enumerate(ME_SETUP_PARAM_SETS):
+        src, r0, r1 = pics[name]
+        H, W = src.shape
+        ps, geo = svtlibs.me_pyramid(src); p0, _ = svtlibs.me_pyramid(r0); p1, _ = svtlibs.me_pyramid(r1)
+        for sy in range(0, H, 64):
+            for sx in range(0, W, 64):
+                prm = svtlibs.me_lcu_params(W, H, sx, sy, geo, **kw)
+                o = svtlibs.run_me_lcu(R.ref_motion_estimate_lcu, prm, ps, p0, p1)
+                prm_all.append(prm); key_all.append(si)
+                for k in outs:
+                    outs[k].append(o[k])
+    d["prm"] = np.array(prm_all); d["param_set"] = np.array(key_all, np.int32)
+    d["picture_of_set"] = np.array([n for n, _ in ME_SETUP_PARAM_SETS])
+    for k, v in outs.items():
+        d[k] = np.array(v)
+    np.savez_compressed(os.path.join(HERE, "me_setup.npz"), **d)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                    # one family only: python make_golden.py cfl_levels
         globals()["gen_" + sys.argv[1]]()
@@ -695,6 +768,7 @@ if __name__ == "__main__":
     gen_hme()
     gen_bip()
     gen_picture()
+    gen_me_setup()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -329,3 +329,72 @@ def random_y4m_header(rng):
         toks.append(pool[rng.integers(0, len(pool))]())
     line = " " + " ".join(toks)
     return line[:78] + "\n"
+
+
+# ---- whole-SB motion estimation (MotionEstimateLcu): shared by make_golden.py, the oracle tests and the GPU tests -----------------
+ME_PADS = (68, 34, 17)                    # left / top padding of the full, 1/4 and 1/16 pictures (sb_sz + ME_FILTER_TAP, >> 1, >> 2)
+
+
+def me_pyramid(luma):
+    """(planes, geometry) of one picture as the reference's PA reference object holds it: the padded full-resolution plane and
+    its 1/4 and 1/16 decimations (Decimation2D keeps every 2nd / 4th sample, generate_padding replicates the edge; both pinned to
+    the reference in picture.npz), each with 5 spare columns of stride.  geometry[level] = (stride, origin_x, origin_y, w, h)."""
+    planes, geo = [], []
+    for lvl, pad in enumerate(ME_PADS):
+        step = 1 << lvl
+        p = np.ascontiguousarray(luma[::step, ::step])
+        h, w = p.shape
+        buf = np.zeros((h + 2 * pad, w + 2 * pad + 5), np.uint8)
+        buf[:, : w + 2 * pad] = np.pad(p, pad, mode="edge")
+        planes.append(buf)
+        geo.append((buf.shape[1], pad, pad, w, h))
+    return planes, geo
+
+
+ME_LCU_DEFAULTS = dict(slice_type=1, pic_depth_mode=2, temporal_layer_index=1, hierarchical_levels=3, enable_hme_flag=1, hme_l0=1, hme_l1=1,
+                       hme_l2=1, is_used_as_reference_flag=1, search_area_width=16, search_area_height=9, regions_w=2, regions_h=2,
+                       ref0_poc=8, ref1_poc=16, asm_type=0, input_resolution=1, cu8x8_mode=0, fractional_search_method=0,
+                       nsq_search_level=0, hme0_w=(16, 16), hme0_h=(8, 8), hme1_w=(8, 8), hme1_h=(4, 4), hme2_w=(8, 8), hme2_h=(4, 4))
+
+
+def me_lcu_params(luma_w, luma_h, sb_x, sb_y, geo, **kw):
+    """the int32 parameter block of ref_motion_estimate_lcu / svt_oracle_me_lcu (oracle/ref_me.c documents the slots)"""
+    k = dict(ME_LCU_DEFAULTS); k.update(kw)
+    nsq = k["pic_depth_mode"] <= 1
+    prm = [luma_w, luma_h, sb_x, sb_y, k["slice_type"], k["pic_depth_mode"], k["temporal_layer_index"], k["hierarchical_levels"], k["enable_hme_flag"],
+           k["hme_l0"], k["hme_l1"], k["hme_l2"], k["is_used_as_reference_flag"], k["search_area_width"], k["search_area_height"], k["regions_w"],
+           k["regions_h"], sum(k["hme0_w"][: k["regions_w"]]), sum(k["hme0_h"][: k["regions_h"]]), k["ref0_poc"], k["ref1_poc"], k["asm_type"],
+           k["input_resolution"], k["cu8x8_mode"], k["fractional_search_method"], 209 if nsq else 85, k["nsq_search_level"]]
+    for g in geo:
+        prm += list(g)
+    for name in ("hme0_w", "hme0_h", "hme1_w", "hme1_h", "hme2_w", "hme2_h"):
+        prm += list(k[name])
+    assert len(prm) == 54
+    return np.array(prm, np.int32)
+
+
+def run_me_lcu(fn, prm, src_planes, ref0_planes, ref1_planes):
+    """call ref_motion_estimate_lcu (or the oracle's twin of the same signature) -> dict of its five outputs"""
+    bufs = (ctypes.c_void_p * 9)(*[p.ctypes.data for p in list(src_planes) + list(ref0_planes) + list(ref1_planes)])
+    out = dict(best_sad=np.zeros((2, 209), np.uint32), best_mv=np.zeros((2, 209), np.uint32), area_origin=np.zeros((2, 2), np.int16),
+               bipred_sad=np.zeros(209, np.uint32), results=np.zeros((209, 11), np.int32))
+    rc = fn(ptr(prm), bufs, ptr(out["best_sad"]), ptr(out["best_mv"]), ptr(out["area_origin"]), ptr(out["bipred_sad"]), ptr(out["results"]))
+    assert rc == 0, rc
+    return out
+
+
+def me_setup_fixture():
+    """tests/golden/me_setup.npz -> (fixture, {picture set: ((planes, geometry) of source, list-0 ref, list-1 ref)})"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "me_setup.npz"))
+    names = sorted({str(n) for n in g["picture_of_set"]})
+    return g, {n: [me_pyramid(g[f"{n}_pic{i}"]) for i in range(3)] for n in names}
+
+
+def smooth_picture(rng, h, w, grain=6):
+    """low-pass noise with a little grain: content on which the hierarchical search finds real motion"""
+    a = rng.integers(0, 256, (h // 4 + 3, w // 4 + 3)).astype(np.float64)
+    a = np.kron(a, np.ones((4, 4)))
+    k = np.ones(5) / 5
+    a = np.apply_along_axis(lambda r: np.convolve(r, k, "same"), 1, a)
+    a = np.apply_along_axis(lambda r: np.convolve(r, k, "same"), 0, a)
+    return (a[:h, :w] + rng.integers(-grain, grain + 1, (h, w))).clip(0, 255).astype(np.uint8)

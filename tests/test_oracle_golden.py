@@ -442,3 +442,26 @@ def test_picture_input_golden():
             O.svt_oracle_decimation_2d(ptr(luma), stride, w, h, ctypes.c_void_p(buf.ctypes.data + o * ds + o), ds, step)
             O.svt_oracle_generate_padding(ptr(buf), ds, dw, dh, o, o, 1)
             assert np.array_equal(buf, exp), (k, key)
+
+
+def test_motion_estimate_lcu_golden():
+    """the oracle's per-SB motion estimation driver (oracle/me_lcu.c: HME levels -> best-of-regions centre -> CheckZeroZeroCenter ->
+    search-area clipping -> 85 / 209-PU full-pel search -> bi-prediction -> me_results) against the reference's OWN MotionEstimateLcu
+    on every SB of three small pictures under fifteen parameter sets (tests/golden/me_setup.npz, made by make_golden.gen_me_setup)"""
+    O = svtlibs.oracle()
+    g, pics = svtlibs.me_setup_fixture()
+    assert g["prm"].shape[0] >= 180
+    for i, prm in enumerate(g["prm"]):
+        (ps, _), (p0, _), (p1, _) = pics[str(g["picture_of_set"][g["param_set"][i]])]
+        o = svtlibs.run_me_lcu(O.svt_oracle_me_lcu, np.ascontiguousarray(prm), ps, p0, p1)
+        for k, v in o.items():
+            assert np.array_equal(v, g[k][i]), (i, prm[:27].tolist(), k)
+
+
+def test_me_pu_raster_to_storage_map_is_a_bijection_and_matches_the_rectangles():
+    """raster PU order (me_results, BiPredictionSearch) -> index in the SAD / vector rows; pinned to the reference through the
+    me_results rows of the fixture above, checked here for shape"""
+    O = svtlibs.oracle()
+    m = [O.svt_oracle_me_raster_to_storage(p) for p in range(209)]
+    assert sorted(m) == list(range(209))
+    assert m[:5] == [0, 1, 2, 3, 4] and m[5:9] == [5, 6, 9, 10] and m[85:87] == [85, 86] and m[87:91] == [87, 89, 88, 90]

@@ -589,3 +589,44 @@ def test_padding_and_decimation_vs_reference(is16):
             O.svt_oracle_decimation_2d(ptr(src), w + 3, w, h, ptr(d1), ow + 2, step)
             assert np.array_equal(d0, d1)
             assert np.array_equal(d0[:, :ow], src[::step, :w:step])
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_motion_estimate_lcu_vs_reference_randomized(seed):
+    """oracle/me_lcu.c against the reference's whole MotionEstimateLcu (oracle/ref_me.c) on random pictures, picture sizes with partial
+    SBs, random parameter sets: slice type, 85 / 209 PUs, HME level switches, 1 x 1 / 2 x 2 regions, equal reference POCs (second-best
+    region, base-layer list 1), search areas, CheckZeroZeroCenter on / off, bi-prediction gating, SAD sub-sampling.  asm_type 1 only
+    on pictures of whole SBs: the AVX2 HME kernels are undefined on the 2- / 4-wide blocks of a partial SB (DESIGN 2 e)."""
+    O = svtlibs.oracle()
+    rng = np.random.default_rng(seed)
+    ncase = nnarrow = 0
+    for trial in range(14):
+        W = int(rng.choice([200, 256, 328])); H = int(rng.choice([136, 192, 200]))
+        base = svtlibs.smooth_picture(rng, H + 96, W + 96)
+        dx0, dy0, dx1, dy1 = (int(v) for v in rng.integers(-20, 21, 4))
+        src = base[48:48 + H, 48:48 + W].copy()
+        ref0 = base[48 + dy0:48 + dy0 + H, 48 + dx0:48 + dx0 + W].copy() if trial % 4 else rng.integers(0, 256, (H, W), dtype=np.uint8)
+        ref1 = base[48 + dy1:48 + dy1 + H, 48 + dx1:48 + dx1 + W].copy() if trial % 3 else rng.integers(0, 256, (H, W), dtype=np.uint8)
+        (ps, geo), (p0, _), (p1, _) = svtlibs.me_pyramid(src), svtlibs.me_pyramid(ref0), svtlibs.me_pyramid(ref1)
+        kw = dict(slice_type=int(rng.integers(0, 2)), pic_depth_mode=int(rng.choice([0, 2])), temporal_layer_index=int(rng.integers(0, 4)),
+                  hme_l0=int(rng.integers(0, 2)), hme_l1=int(rng.integers(0, 2)), hme_l2=int(rng.integers(0, 2)),
+                  enable_hme_flag=int(rng.integers(0, 4) > 0), is_used_as_reference_flag=int(rng.integers(0, 2)),
+                  search_area_width=int(rng.choice([7, 8, 16, 24, 30])), search_area_height=int(rng.choice([5, 9, 16])),
+                  regions_w=int(rng.choice([1, 2])), ref1_poc=int(rng.choice([8, 16])), asm_type=int(rng.integers(0, 2)) if W % 64 == 0 else 0,
+                  cu8x8_mode=int(rng.integers(0, 2)), fractional_search_method=int(rng.choice([0, 1])))
+        kw["regions_h"] = kw["regions_w"]
+        for sy in range(0, H, 64):
+            for sx in range(0, W, 64):
+                prm = svtlibs.me_lcu_params(W, H, sx, sy, geo, **kw)
+                a = svtlibs.run_me_lcu(R.ref_motion_estimate_lcu, prm, ps, p0, p1)
+                bufs = (ctypes.c_void_p * 9)(*[p.ctypes.data for p in list(ps) + list(p0) + list(p1)])
+                b = dict(best_sad=np.zeros((2, 209), np.uint32), best_mv=np.zeros((2, 209), np.uint32), area_origin=np.zeros((2, 2), np.int16),
+                         bipred_sad=np.zeros(209, np.uint32), results=np.zeros((209, 11), np.int32))
+                areas = np.zeros((2, 4), np.int16)
+                assert O.svt_oracle_me_lcu_ex(ptr(prm), bufs, ptr(b["best_sad"]), ptr(b["best_mv"]), ptr(b["area_origin"]), ptr(b["bipred_sad"]),
+                                              ptr(b["results"]), None, ptr(areas), None, None) == 0
+                for k in a:
+                    assert np.array_equal(a[k], b[k]), (trial, (W, H), (sx, sy), kw, k)
+                ncase += 1
+                nnarrow += int(0 < areas[0, 2] < 8) + int(0 < areas[1, 2] < 8)
+    assert ncase > 150 and nnarrow > 0            # search areas clipped below 8 columns (the single-search-point form) did occur
