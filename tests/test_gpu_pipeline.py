@@ -32,9 +32,14 @@ def test_pipeline_finds_the_known_motion_and_is_deterministic(dsp, tmp_path, bd)
         p = tool.Pipeline(dsp, path)
         outs = []
         while True:
+            ref_before = p.prev["pyr"][2].clone() if p.prev is not None else None      # the reference luma plane of the coming step
             o = p.step()
             if o is None:
                 break
+            if bd == 8 and rep == 0 and ref_before is not None:
+                # every SB, corners included: the search area the device derived (best region, CheckZeroZeroCenter, clipping against the
+                # picture) is the oracle's for the HME results the device produced
+                check_areas_against_oracle(p, o, ref_before, w, h)
             outs.append(o)
         assert len(outs) == nf and "me_mv" not in outs[0] and "me_mv" in outs[1]
         for o in outs[1:]:
@@ -54,6 +59,30 @@ def test_pipeline_finds_the_known_motion_and_is_deterministic(dsp, tmp_path, bd)
         digests.append([tool.digest_of(o) for o in outs])
         p.pi.close()
     assert digests[0] == digests[1]
+
+
+def check_areas_against_oracle(p, o, ref_luma, w, h):
+    import ctypes
+    import svtlibs
+    from svtlibs import ptr
+    O = svtlibs.oracle()
+    cur = o["_cur_luma"].cpu().numpy(); ref = ref_luma.cpu().numpy()
+    stride, pad = cur.shape[1], p.pad
+    c00 = ctypes.c_void_p(cur.ctypes.data + pad * stride + pad); r00 = ctypes.c_void_p(ref.ctypes.data + pad * stride + pad)
+    hs = o["hme_sad"].cpu().numpy(); hm = o["hme_regions_mv"].cpu().numpy()
+    area = o["me_area"].cpu().numpy(); centre = o["hme_mv"].cpu().numpy()
+    narrow = 0
+    for i, (x, y) in enumerate(p.sb_xy.cpu().numpy().tolist()):
+        s4 = np.zeros((2, 2), np.uint64); x4 = np.zeros((2, 2), np.int16); y4 = np.zeros((2, 2), np.int16)
+        for r in range(4):
+            s4[r % 2, r // 2] = hs[r, i]; x4[r % 2, r // 2] = hm[r, i, 0]; y4[r % 2, r // 2] = hm[r, i, 1]
+        ce = np.zeros(2, np.int16); ar = np.zeros(4, np.int16)
+        sw, sh = min(64, w - x), min(64, h - y)
+        O.svt_oracle_me_setup(c00, stride, r00, stride, x, y, sw, sh, w, h, w, h, int(sh == 64), ptr(s4), ptr(x4), ptr(y4), 2, 2, 0, 1, p.SW, p.SH,
+                              ptr(ce), ptr(ar))
+        assert area[i].tolist() == ar.tolist() and centre[i].tolist() == ce.tolist(), (i, (x, y), area[i], ar, centre[i], ce)
+        narrow += int(ar[2] < p.SW or ar[3] < p.SH)
+    return narrow                            # (areas clipped against the picture; a (4, 4) pan clips none - test_gpu_me_setup.py covers those)
 
 
 def test_pipeline_as_a_hip_graph_equals_the_eager_chain(dsp, tmp_path):

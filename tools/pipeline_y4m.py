@@ -2,7 +2,8 @@
 """The hot path end to end on a y4m file (every row of SURVEY 8(f) working on the others' outputs), per frame:
    picture input    file -> pinned -> HBM -> padded planes + 1/4 and 1/16 luma pictures   (frames.PictureInput, n4)
    HME 0 / 1 / 2    every 64x64 SB against the previous picture's pyramid, vectors stay on the device   (svt_hip_hme_level_batch, n1)
-   full-pel ME      209 PUs per SB around the HME vector, 64x64 search area   (svt_hip_me_fullpel_search_batch, a11)
+   ME set-up        best HME region, CheckZeroZeroCenter, per-SB search area clipped as MotionEstimateLcu does   (svt_hip_me_setup_batch, n1)
+   full-pel ME      209 PUs per SB over its own (up to 64x64) area, one launch   (svt_hip_me_fullpel_search_areas_batch, a11)
    open-loop intra  every 8x8 ... 64x64 block, the reference's candidate lists   (svt_hip_ois_search_frame, n2)
    encode pass      residual -> FwdTxfm2d -> quant / dequant -> InvTxfm2d -> recon, five CU sizes, luma + chroma   (svt_hip_encode_recon_frame, n3)
 The prediction of the encode pass is the previous source picture at zero motion (inter prediction itself is outside SURVEY 8).
@@ -82,6 +83,7 @@ class Pipeline:
         self.stride = pi.planes[0].stride(0)
         self.src_off = ((self.sb_xy[:, 1] + self.pad) * self.stride + self.sb_xy[:, 0] + self.pad).to(torch.int32)
         self.SW = self.SH = 64
+        self.me_setup_params = dsp.MeSetupParams(W, H, W, H, self.SW, self.SH, 2, 2, 0, 1)      # 2 x 2 HME regions, CheckZeroZeroCenter on
         # open-loop intra search groups
         self.ois_groups = []
         for bsize in (8, 16, 32, 64):
@@ -109,30 +111,23 @@ class Pipeline:
         out["ois"] = dsp.ois_search_frame(pic, y.stride(0), self.W, self.H, self.ois_groups)
         if self.prev is not None:
             pyr_cur = {0: pi.sixteenth, 1: pi.quarter, 2: y}
-            # the four regions of a level in one launch, three launches per picture; the best level-2 SAD wins (strict: the first
-            # region keeps ties, as the reference's region loop does)
+            # the four regions of a level in one launch, three launches per picture
             centres = None
             for level in (0, 1, 2):
                 org, size, lpad = self.hme_geo[level]
                 cur, ref = pyr_cur[level], self.prev["pyr"][level]
                 b4, centres = dsp.hme_level_regions(cur[lpad:, lpad:], cur.stride(0), ref[lpad:, lpad:], ref.stride(0), org, size, centres,
-                                                    1 if level == 1 else 0, [self.hme[(level, rw, rh)] for rw in (0, 1) for rh in (0, 1)])
-            best, mv = b4[0], centres[0]
-            for r in (1, 2, 3):
-                take = b4[r] < best
-                best = t.where(take, b4[r], best); mv = t.where(take[:, None], centres[r], mv)
-            out["hme_sad"], out["hme_mv"] = best, mv
-            # search-area origin per SB: centred on the HME vector, kept inside the padded reference picture
-            sx, sy = self.sb_xy[:, 0], self.sb_xy[:, 1]
-            ox = mv[:, 0].to(t.int32) - self.SW // 2
-            oy = mv[:, 1].to(t.int32) - self.SH // 2
-            ox = t.minimum(t.maximum(ox, -self.pad - sx), self.W + self.pad - (64 + self.SW - 1) - sx)
-            oy = t.minimum(t.maximum(oy, -self.pad - sy), self.H + self.pad - (64 + self.SH - 1) - sy)
-            origins = t.stack([ox, oy], dim=1).to(t.int16).contiguous()
-            ref_off = ((sy + oy + self.pad) * self.stride + sx + ox + self.pad).to(t.int32)
-            out["me_sad"], out["me_mv"] = dsp.me_fullpel_search(y, self.prev["pyr"][2], self.SW, self.SH, origins=origins, nsq=True,
-                                                                src_stride=self.stride, src_offsets=self.src_off, ref_stride=self.stride,
-                                                                ref_offsets=ref_off, n=self.nsb)
+                                                    1 if level == 1 else 0, [self.hme[(level, rw, rh)] for rh in (0, 1) for rw in (0, 1)])   # region r = rh * 2 + rw
+            # MotionEstimateLcu's glue on the device (svt_hip_me_setup_batch): best region, CheckZeroZeroCenter against the previous
+            # picture, the search area clipped against the picture per SB - then ONE search launch whose SBs each read their own area
+            # (interior 64x64 areas and the clipped ones of the edge SBs alike), nothing returns to the host in between
+            org, size, _ = self.hme_geo[2]
+            cur00, ref00 = y[self.pad:, self.pad:], self.prev["pyr"][2][self.pad:, self.pad:]
+            centre, area = dsp.me_setup(cur00, self.stride, ref00, self.stride, org, size, b4, centres, self.me_setup_params)
+            out["hme_sad"], out["hme_regions_mv"], out["hme_mv"], out["me_area"] = b4, centres, centre, area
+            out["_cur_luma"] = y                                                  # (a view, for tests; not part of the digest)
+            out["me_sad"], out["me_mv"] = dsp.me_fullpel_search_areas(y, self.stride, self.src_off, self.prev["pyr"][2], self.stride, self.src_off, area,
+                                                                      self.SW, self.SH, nsq=True)
             # encode pass: source against the previous picture at zero motion (views into the padded buffers, no copies)
             if self.fp is None:
                 self.fp = frames.FramePass(dsp, pkg, self.interior(planes), self.interior(self.prev["planes"]), is_16bit=pi.is16)
@@ -178,6 +173,8 @@ class Pipeline:
 def digest_of(out):
     d = {}
     for k, v in out.items():
+        if k.startswith("_"):
+            continue
         if k == "ois":
             d["ois_best_sum"] = int(sum(int(b.to(torch.int64).sum()) for _, b in v))
             d["ois_dist_sum"] = int(sum(int(dd.to(torch.int64).sum()) for dd, _ in v))
