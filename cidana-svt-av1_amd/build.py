@@ -13,7 +13,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libsvt_hip_dsp.so")
-SOURCES = ["csrc/svt_hip_core.hip", "csrc/svt_hip_txfm.hip", "csrc/svt_hip_pixel.hip", "csrc/svt_hip_intra.hip", "csrc/svt_hip_picture.hip", "csrc/host_tables.cpp", "csrc/y4m_reader.cpp", "csrc/host_err.cpp"]
+SOURCES = ["csrc/svt_hip_core.hip", "csrc/svt_hip_txfm.hip", "csrc/svt_hip_pixel.hip", "csrc/svt_hip_intra.hip", "csrc/svt_hip_picture.hip", "csrc/svt_hip_frame.hip", "csrc/host_tables.cpp", "csrc/y4m_reader.cpp", "csrc/host_err.cpp"]
 HOST_ONLY = [s for s in SOURCES if s.endswith(".cpp")]          # no HIP header, no device: also built under sanitizers (tests/test_host_sanitizers.py)
 OBJ_DIR = os.path.join(PKG, "build_obj")            # git-ignored; objects do not travel, the linked .so does
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fwrapv", "-Wall", "-Wno-unused-function"]

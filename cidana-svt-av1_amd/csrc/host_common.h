@@ -23,7 +23,6 @@ extern int g_device;
 extern char g_devname[300];
 extern int g_num_cu;
 // tuning knobs (svt_hip_tune): fused 32x32 kernel occupancy / grid
-extern int g_tune_f32_min_waves;
 extern int g_tune_f32_wg_per_cu;
 extern int g_tune_f32_nt;
 extern int g_tune_f32_qmode1;
@@ -36,7 +35,6 @@ extern int g_tune_q2_su4;
 extern int g_tune_ois_no_fold;
 extern int g_tune_ois_no_nd;
 extern int g_tune_dir_no_split, g_tune_dir_split_target;
-extern int g_tune_no_me16;
 extern int g_tune_me_exact;
 extern int g_tune_no_f32p;
 extern int g_tune_no_inv_planes;
@@ -56,6 +54,11 @@ extern int g_tune_inv32_var;
 
 int require_init();
 int launch_status(const char* what);
+}  // namespace svthost
+namespace svtdev { struct FrameDesc; }
+namespace svthost {
+// svt_hip_frame.hip: the one-launch form of svt_hip_encode_recon_frame (its kernel lives in a translation unit of its own)
+int launch_enc_frame_one(const svtdev::FrameDesc* fd, uint32_t total_wgs, int is_16bit, hipStream_t s);
 
 extern const int kTxW[SVT_TX_SIZES_ALL];
 extern const int kTxH[SVT_TX_SIZES_ALL];

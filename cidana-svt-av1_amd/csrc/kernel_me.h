@@ -31,193 +31,6 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     return v;
 }
 
-__global__ __launch_bounds__(ME_THREADS) void me_sb_search_kernel(
-    const uint8_t* __restrict__ src, uint32_t src_stride, size_t src_block_pitch,
-    const uint8_t* __restrict__ ref, uint32_t ref_stride, size_t ref_block_pitch, int search_w, int search_h,
-    const int16_t* __restrict__ origins /* [n][2] x,y or NULL */, int x_origin, int y_origin,
-    uint32_t* __restrict__ best_sad, uint32_t* __restrict__ best_mv, uint32_t wpitch,
-    const uint32_t* __restrict__ src_offs, const uint32_t* __restrict__ ref_offs, uint32_t nblocks) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t* s_src = reinterpret_cast<uint32_t*>(smem);            // [32 even rows][16 dwords]
-    uint8_t* s_ref = smem + 32 * 64;                                // [(64+sh-1)][wpitch]
-    __shared__ unsigned s_red[4][ME_PUS];
-    const uint32_t blk = blockIdx.x;
-    if (blk >= nblocks) return;
-    const int tid = threadIdx.x;
-    const uint8_t* gs = src + (src_offs ? (size_t)src_offs[blk] : (size_t)blk * src_block_pitch);
-    const uint8_t* gr = ref + (ref_offs ? (size_t)ref_offs[blk] : (size_t)blk * ref_block_pitch);
-    // stage the even source rows and the reference window with 16-B unaligned loads
-    if (tid < 128) {
-        const int r = tid >> 2, c = tid & 3;
-        uint4 v;
-        __builtin_memcpy(&v, gs + (size_t)(2 * r) * src_stride + c * 16, 16);
-        reinterpret_cast<uint4*>(s_src)[tid] = v;
-    }
-    const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
-    {
-        const uint32_t cpr = (win_w + 15) >> 4;                       // 16-B chunks per window row (<= 16 for search_w <= 193)
-        const size_t span = (size_t)(win_h - 1) * ref_stride + win_w;  // the window's own footprint: never read past it
-        for (uint32_t c = tid & 15; c < cpr; c += 16)
-            for (uint32_t y0 = tid >> 4; y0 < win_h; y0 += 64) {       // 4 loads in flight per lane
-                uint4 v[4];
-                uint32_t back[4];           // a chunk that would end past the footprint is fetched `back` bytes earlier
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t y = y0 + 16 * k;
-                    v[k] = make_uint4(0, 0, 0, 0);
-                    back[k] = 0;
-                    if (y < win_h) {
-                        const size_t off = (size_t)y * ref_stride + c * 16;
-                        if (off + 16 <= span) __builtin_memcpy(&v[k], gr + off, 16);
-                        else if (off < span) {
-                            // the footprint's last 16 bytes (span >= 64 here), stored shifted: the bytes it
-                            // re-writes are the same data or row slack.  (Byte-wise global loads would cost
-                            // one memory latency each.)
-                            back[k] = (uint32_t)(off - (span - 16));
-                            __builtin_memcpy(&v[k], gr + (span - 16), 16);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t y = y0 + 16 * k;
-                    if (y < win_h) {
-                        if (back[k] == 0) *reinterpret_cast<uint4*>(s_ref + (size_t)y * wpitch + c * 16) = v[k];
-                        else {
-                            const uint8_t* vb = reinterpret_cast<const uint8_t*>(&v[k]);
-                            uint8_t* d = s_ref + (size_t)y * wpitch + c * 16 - back[k];
-#pragma unroll
-                            for (int b = 0; b < 16; b++) d[b] = vb[b];
-                        }
-                    }
-                }
-            }
-    }
-    __syncthreads();
-
-    unsigned best[ME_PUS];
-#pragma unroll
-    for (int i = 0; i < ME_PUS; i++) best[i] = 0xffffffffu;
-
-    // A lane owns FOUR horizontally adjacent search points (xs0 .. xs0+3, xs0 % 4 == 0): every
-    // reference dword pair is then aligned and one v_qsad_pk_u16_u8 gives 4 points x 4 pixels.
-    // Packed u16 sums are safe up to the 16x16 level (4 * 4 rows * 8 px * 255 * 4 = 32 640 before
-    // the final doubling); 32x32 / 64x64 are summed per point in u32.
-    const int gx = (search_w + 3) >> 2;
-    const int ngroups = gx * search_h;
-    const int ncand = search_w * search_h;
-    for (int grp = tid; grp < ngroups; grp += ME_THREADS) {
-        const int ys = grp / gx, xg = grp - ys * gx;
-        const int xs0 = xg * 4, cand0 = ys * search_w + xs0;
-        unsigned bad[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) bad[jj] = (xs0 + jj < search_w) ? 0u : 0xffffffffu;
-        const uint8_t* rbase = s_ref + (size_t)ys * wpitch + xs0;
-        unsigned s32acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // [quadrant][point]
-        unsigned long long s16acc[4] = {0, 0, 0, 0};      // packed 4 x u16, the four 16x16 of the current 16-row band
-#pragma unroll
-        for (int band = 0; band < 8; band++) {          // 8-row band = one row of 8x8 blocks
-            unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                const int r = band * 8 + rr * 2;
-                const uint32_t* rrow = reinterpret_cast<const uint32_t*>(rbase + (size_t)r * wpitch);
-                const uint32_t* srow = s_src + (r >> 1) * 16;
-                uint32_t lo = rrow[0];
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const uint32_t hi = rrow[q + 1];
-                    acc[q >> 1] = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)hi << 32) | lo, srow[q], acc[q >> 1]);
-                    lo = hi;
-                }
-            }
-            const int by16 = band >> 1, kr = band & 1;
-#pragma unroll
-            for (int bx = 0; bx < 8; bx++) {
-                const int bx16 = bx >> 1;
-                const int z = ((by16 >> 1) * 2 + (bx16 >> 1)) * 4 + (by16 & 1) * 2 + (bx16 & 1);
-                const int idx = 4 * z + kr * 2 + (bx & 1);
-                const unsigned alo = (unsigned)acc[bx], ahi = (unsigned)(acc[bx] >> 32);
-                // key = (2*s) << 12 | point = s << 13 | point
-                unsigned k0 = ((alo & 0xffffu) << 13) | (unsigned)(cand0 + 0) | bad[0];
-                unsigned k1 = ((alo >> 16) << 13) | (unsigned)(cand0 + 1) | bad[1];
-                unsigned k2 = ((ahi & 0xffffu) << 13) | (unsigned)(cand0 + 2) | bad[2];
-                unsigned k3 = ((ahi >> 16) << 13) | (unsigned)(cand0 + 3) | bad[3];
-                best[idx] = min(min(best[idx], min(k0, k1)), min(k2, k3));
-                // packed u16 add of the four lanes (no carry between lanes: sums stay < 2^16)
-                s16acc[bx16] += acc[bx];
-            }
-            if (kr == 1) {
-#pragma unroll
-                for (int bx16 = 0; bx16 < 4; bx16++) {
-                    const int z = ((by16 >> 1) * 2 + (bx16 >> 1)) * 4 + (by16 & 1) * 2 + (bx16 & 1);
-                    const unsigned alo = (unsigned)s16acc[bx16], ahi = (unsigned)(s16acc[bx16] >> 32);
-                    const unsigned s0 = (alo & 0xffffu) << 1, s1 = (alo >> 16) << 1, s2 = (ahi & 0xffffu) << 1, s3 = (ahi >> 16) << 1;
-                    const unsigned k0 = (s0 << 12) | (unsigned)(cand0 + 0) | bad[0], k1 = (s1 << 12) | (unsigned)(cand0 + 1) | bad[1];
-                    const unsigned k2 = (s2 << 12) | (unsigned)(cand0 + 2) | bad[2], k3 = (s3 << 12) | (unsigned)(cand0 + 3) | bad[3];
-                    best[64 + z] = min(min(best[64 + z], min(k0, k1)), min(k2, k3));
-                    const int qd = (by16 >> 1) * 2 + (bx16 >> 1);
-                    s32acc[qd][0] += s0; s32acc[qd][1] += s1; s32acc[qd][2] += s2; s32acc[qd][3] += s3;
-                    s16acc[bx16] = 0;
-                }
-            }
-        }
-        unsigned s64[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            unsigned kk[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) { kk[jj] = (s32acc[q][jj] << 12) | (unsigned)(cand0 + jj) | bad[jj]; s64[jj] += s32acc[q][jj]; }
-            best[80 + q] = min(min(best[80 + q], min(kk[0], kk[1])), min(kk[2], kk[3]));
-        }
-        {
-            unsigned kk[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) kk[jj] = (s64[jj] << 12) | (unsigned)(cand0 + jj) | bad[jj];
-            best[84] = min(min(best[84], min(kk[0], kk[1])), min(kk[2], kk[3]));
-        }
-    }
-    // workgroup min-reduction of the 85 keys
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int i = 0; i < ME_PUS; i++) {
-        const unsigned v = wave_min_u32(best[i]);
-        if (lane == 0) s_red[wave][i] = v;
-    }
-    __syncthreads();
-    if (tid < ME_PUS && ncand > 0) {
-        const unsigned key = min(min(s_red[0][tid], s_red[1][tid]), min(s_red[2][tid], s_red[3][tid]));
-        const unsigned sad = key >> 12, cand = key & 0xfffu;
-        const int ys = (int)cand / search_w, xs = (int)cand - ys * search_w;
-        const int ox = origins ? origins[2 * blk] : x_origin, oy = origins ? origins[2 * blk + 1] : y_origin;
-        uint32_t* bs = best_sad + (size_t)blk * ME_PUS;
-        uint32_t* bm = best_mv + (size_t)blk * ME_PUS;
-        if (sad < bs[tid]) {
-            bs[tid] = sad;
-            bm[tid] = (((uint32_t)(uint16_t)(ys + oy)) << 18) | (uint32_t)(uint16_t)((xs + ox) << 2);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// me_sb_search16_kernel — the same search for search areas whose width is a multiple of 16 (the
-// encoder's 64x64 default), written against the measured gfx950 costs.
-//
-// A lane owns SIXTEEN horizontally adjacent search points of one search row (xs0 % 16 == 0): the 20
-// reference dwords it needs per SB row are five ALIGNED ds_read_b128, the source row is four
-// broadcast ds_read_b128, and they feed 64 v_qsad_pk_u16_u8 (4 point groups x 16 dwords) - 9 wide LDS
-// reads per 64 qsads instead of 33 dword reads per 16.  With 256 lanes one pass covers 64 x 64
-// points, so no per-lane running best survives a pass: the 8x8 / 16x16 SADs stay PACKED (4 x u16 per
-// 64-bit accumulator, sums fit: 16x16 on even rows <= 32 640), a PU's 16 keys are built straight from
-// the packed words (v_lshl_or / v_and_or + v_add: key = sad << 16 | point) and min-reduced with
-// v_min3, then over the wave, and lane 0 folds the result into the workgroup's LDS table.  32x32 sums
-// are kept as two packed 16-row halves (each <= 65 280) and widened once per 32-row half.
-// Register budget ~200 VGPRs: two workgroups per CU (the first kernel: 256 VGPRs + 256 AGPRs + scratch,
-// one wave per SIMD, an s_waitcnt after almost every LDS read).
-// ---------------------------------------------------------------------------
-// Wave-wide unsigned minimum on the VALU cross-lane (DPP) path: quad swaps, row half-mirror / mirror,
-// then the gfx9 row broadcasts; no LDS round trip (a ds_bpermute chain is six dependent LDS latencies
-// per PU, and there are 85 PUs).  The result is valid in LANE 63 only.
 __device__ __forceinline__ unsigned wave_min_u32_to_lane63(unsigned v) {
     v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
     v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
@@ -292,7 +105,7 @@ __device__ __forceinline__ void me_sb_search16_body(
                     if (y < win_h) {
                         const size_t off = (size_t)y * ref_stride + c * 16;
                         if (off + 16 <= span) __builtin_memcpy(&v[k], gr + off, 16);
-                        else if (off < span) {           // footprint tail: see me_sb_search_kernel
+                        else if (off < span) {           // footprint tail: the last 16 bytes of the window's footprint, stored `back` bytes earlier
                             back[k] = (uint32_t)(off - (span - 16));
                             __builtin_memcpy(&v[k], gr + (span - 16), 16);
                         }
@@ -332,89 +145,96 @@ __device__ __forceinline__ void me_sb_search16_body(
         for (int i = 0; i < 16; i++) s64[i] = 0;
 #pragma unroll 1
         for (int h32 = 0; h32 < 2; h32++) {                           // top / bottom 32 rows of the SB
-            unsigned long long PA[2][4], PB[2][4];                    // 32x32 column c32, 16-row half A / B, point group
+            unsigned long long PA[2][4];                              // 32x16 sums of the upper 16 rows: 32x32 column c32, point group
 #pragma unroll
             for (int h16 = 0; h16 < 2; h16++) {
-                unsigned long long s16[4][4];                         // [point group][16x16 column]
+                // A 16-row band is walked as two 32-column halves (hq = the 32x32 column), each as two 8-row bands: 4 x 4 packed
+                // accumulators, 4 x 2 16x16 sums and 8 + 12 operand dwords are live at a time (the first version kept 4 x 8, 4 x 4 and
+                // 16 + 20 and spilled 69 dwords per lane to scratch at its 256-register budget).  The third reference chunk of the left
+                // half is read again by the right half (6 instead of 5 b128 reads per row: the LDS pipe has the room, the kernel is
+                // bound by v_qsad issue).
 #pragma unroll
-                for (int kb = 0; kb < 2; kb++) {
-                    const int band_in = h16 * 2 + kb;                 // band inside the 32-row half (compile time)
-                    unsigned long long acc[4][8];
+                for (int hq = 0; hq < 2; hq++) {
+                    unsigned long long s16[4][2];                     // [point group][16x16 column inside the half]
 #pragma unroll
-                    for (int g = 0; g < 4; g++)
-#pragma unroll
-                        for (int bx = 0; bx < 8; bx++) acc[g][bx] = 0;
-#pragma unroll
-                    for (int rr = 0; rr < 4; rr++) {
-                        const int row = band_in * 8 + rr * 2;         // SB row inside the half
-                        const uint4* sp = reinterpret_cast<const uint4*>(s_src + (h32 * 16 + (row >> 1)) * 16);
-                        const uint4* rp = reinterpret_cast<const uint4*>(rbase + (size_t)(h32 * 32 + row) * wpitch);
-                        uint32_t sw[16], rw[20];
-#pragma unroll
-                        for (int i = 0; i < 4; i++) { const uint4 a = sp[i]; sw[4 * i] = a.x; sw[4 * i + 1] = a.y; sw[4 * i + 2] = a.z; sw[4 * i + 3] = a.w; }
-#pragma unroll
-                        for (int i = 0; i < 5; i++) { const uint4 a = rp[i]; rw[4 * i] = a.x; rw[4 * i + 1] = a.y; rw[4 * i + 2] = a.z; rw[4 * i + 3] = a.w; }
-                        unsigned long long pr[19];                    // dword pairs (d, d+1): odd d costs one register copy, shared by 4 qsads
-#pragma unroll
-                        for (int d = 0; d < 19; d++) pr[d] = ((unsigned long long)rw[d + 1] << 32) | rw[d];
+                    for (int kb = 0; kb < 2; kb++) {
+                        const int band_in = h16 * 2 + kb;             // band inside the 32-row half (compile time)
+                        unsigned long long acc[4][4];
 #pragma unroll
                         for (int g = 0; g < 4; g++)
 #pragma unroll
-                            for (int q = 0; q < 16; q++)
-                                acc[g][q >> 1] = __builtin_amdgcn_qsad_pk_u16_u8(pr[g + q], sw[q], acc[g][q >> 1]);
-                    }
-                    // ---- 8x8 PUs of this band: 16 points -> one key per PU -> wave -> LDS table ----
+                            for (int bx = 0; bx < 4; bx++) acc[g][bx] = 0;
+#pragma unroll 2
+                        for (int rr = 0; rr < 4; rr++) {
+                            const int row = band_in * 8 + rr * 2;     // SB row inside the half
+                            const uint4* sp = reinterpret_cast<const uint4*>(s_src + (h32 * 16 + (row >> 1)) * 16) + 2 * hq;
+                            const uint4* rp = reinterpret_cast<const uint4*>(rbase + (size_t)(h32 * 32 + row) * wpitch) + 2 * hq;
+                            uint32_t sw[8], rw[12];
 #pragma unroll
-                    for (int bx = 0; bx < 8; bx++) {
-                        const unsigned long long a4[4] = {acc[0][bx], acc[1][bx], acc[2][bx], acc[3][bx]};
+                            for (int i = 0; i < 2; i++) { const uint4 a = sp[i]; sw[4 * i] = a.x; sw[4 * i + 1] = a.y; sw[4 * i + 2] = a.z; sw[4 * i + 3] = a.w; }
+#pragma unroll
+                            for (int i = 0; i < 3; i++) { const uint4 a = rp[i]; rw[4 * i] = a.x; rw[4 * i + 1] = a.y; rw[4 * i + 2] = a.z; rw[4 * i + 3] = a.w; }
+                            unsigned long long pr[11];                // dword pairs (d, d+1): odd d costs one register copy, shared by 4 qsads
+#pragma unroll
+                            for (int d = 0; d < 11; d++) pr[d] = ((unsigned long long)rw[d + 1] << 32) | rw[d];
+#pragma unroll
+                            for (int g = 0; g < 4; g++)
+#pragma unroll
+                                for (int q = 0; q < 8; q++)
+                                    acc[g][q >> 1] = __builtin_amdgcn_qsad_pk_u16_u8(pr[g + q], sw[q], acc[g][q >> 1]);
+                        }
+                        // ---- 8x8 PUs of this half band: 16 points -> one key per PU -> wave -> LDS table ----
+#pragma unroll
+                        for (int bxl = 0; bxl < 4; bxl++) {
+                            const int bx = 4 * hq + bxl;
+                            const unsigned long long a4[4] = {acc[0][bxl], acc[1][bxl], acc[2][bxl], acc[3][bxl]};
+                            const unsigned k = wave_min_u32_to_lane63(me_key16_min<MASKED>(a4, idb, nvalid) | dead);
+                            const int bx16 = bx >> 1;
+                            const int zc = (bx16 >> 1) * 4 + h16 * 2 + (bx16 & 1);           // z-order inside the half
+                            const int idx = 32 * h32 + 4 * zc + kb * 2 + (bx & 1);
+                            if (lane == 63) s_red[wave][idx] = min(s_red[wave][idx], k);
+                        }
+#pragma unroll
+                        for (int g = 0; g < 4; g++)
+#pragma unroll
+                            for (int cl = 0; cl < 2; cl++) {
+                                const unsigned long long v = me_pk_add(acc[g][2 * cl], acc[g][2 * cl + 1]);
+                                s16[g][cl] = kb == 0 ? v : me_pk_add(s16[g][cl], v);
+                            }
+                    }
+                    // ---- the two 16x16 PUs of this half, and its 32x16 sum ----
+#pragma unroll
+                    for (int cl = 0; cl < 2; cl++) {
+                        const int c16 = 2 * hq + cl;
+                        const unsigned long long a4[4] = {s16[0][cl], s16[1][cl], s16[2][cl], s16[3][cl]};
                         const unsigned k = wave_min_u32_to_lane63(me_key16_min<MASKED>(a4, idb, nvalid) | dead);
-                        const int bx16 = bx >> 1;
-                        const int zc = (bx16 >> 1) * 4 + h16 * 2 + (bx16 & 1);           // z-order inside the half
-                        const int idx = 32 * h32 + 4 * zc + kb * 2 + (bx & 1);
+                        const int zc = (c16 >> 1) * 4 + h16 * 2 + (c16 & 1);
+                        const int idx = 64 + 8 * h32 + zc;
                         if (lane == 63) s_red[wave][idx] = min(s_red[wave][idx], k);
                     }
+                    if (h16 == 0) {
 #pragma unroll
-                    for (int g = 0; g < 4; g++)
+                        for (int g = 0; g < 4; g++) PA[hq][g] = me_pk_add(s16[g][0], s16[g][1]);      // 32x16, <= 65 280 per lane
+                    } else {
+                        // ---- the 32x32 PU of this half (c32 = hq): widen, double (SADs are on every other row), key = sad << 12 | point ----
+                        unsigned best = 0xffffffffu;
 #pragma unroll
-                        for (int c16 = 0; c16 < 4; c16++) {
-                            const unsigned long long v = me_pk_add(acc[g][2 * c16], acc[g][2 * c16 + 1]);
-                            s16[g][c16] = kb == 0 ? v : me_pk_add(s16[g][c16], v);
+                        for (int g = 0; g < 4; g++) {
+                            const unsigned long long pb = me_pk_add(s16[g][0], s16[g][1]);
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj++) {
+                                const unsigned a = (unsigned)((PA[hq][g] >> (16 * jj)) & 0xffffu), b = (unsigned)((pb >> (16 * jj)) & 0xffffu);
+                                const unsigned sd = (a + b) << 1;
+                                s64[4 * g + jj] += sd;
+                                const unsigned key = (sd << 12) | (idb + ((unsigned)(4 * g + jj) ^ q4[g >> 1]));
+                                best = min(best, (MASKED && (unsigned)(4 * g + jj) >= nvalid) ? 0xffffffffu : key);
+                            }
                         }
-                }
-                // ---- 16x16 PUs of this 16-row band ----
-#pragma unroll
-                for (int c16 = 0; c16 < 4; c16++) {
-                    const unsigned long long a4[4] = {s16[0][c16], s16[1][c16], s16[2][c16], s16[3][c16]};
-                    const unsigned k = wave_min_u32_to_lane63(me_key16_min<MASKED>(a4, idb, nvalid) | dead);
-                    const int zc = (c16 >> 1) * 4 + h16 * 2 + (c16 & 1);
-                    const int idx = 64 + 8 * h32 + zc;
-                    if (lane == 63) s_red[wave][idx] = min(s_red[wave][idx], k);
-                }
-#pragma unroll
-                for (int c32 = 0; c32 < 2; c32++)
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        const unsigned long long v = me_pk_add(s16[g][2 * c32], s16[g][2 * c32 + 1]);     // <= 65 280 per lane
-                        if (h16 == 0) PA[c32][g] = v; else PB[c32][g] = v;
+                        const unsigned k = wave_min_u32_to_lane63(best | dead);
+                        const int idx = 80 + 2 * h32 + hq;
+                        if (lane == 63) s_red[wave][idx] = min(s_red[wave][idx], k);
                     }
-            }
-            // ---- 32x32 PUs of this half: widen, double (SADs are on every other row), key = sad << 12 | point ----
-#pragma unroll
-            for (int c32 = 0; c32 < 2; c32++) {
-                unsigned best = 0xffffffffu;
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        const unsigned a = (unsigned)((PA[c32][g] >> (16 * jj)) & 0xffffu), b = (unsigned)((PB[c32][g] >> (16 * jj)) & 0xffffu);
-                        const unsigned s = (a + b) << 1;
-                        s64[4 * g + jj] += s;
-                        const unsigned key = (s << 12) | (idb + ((unsigned)(4 * g + jj) ^ q4[g >> 1]));
-                        best = min(best, (MASKED && (unsigned)(4 * g + jj) >= nvalid) ? 0xffffffffu : key);
-                    }
-                const unsigned k = wave_min_u32_to_lane63(best | dead);
-                const int idx = 80 + 2 * h32 + c32;
-                if (lane == 63) s_red[wave][idx] = min(s_red[wave][idx], k);
+                }
             }
         }
         {
@@ -640,7 +460,7 @@ __device__ __forceinline__ void me_nsq4_body(
                 if (off + 16 <= span) {
                     __builtin_memcpy(&v, gr + off, 16);
                     *reinterpret_cast<uint4*>(s_ref + (size_t)y * wpitch + c * 16) = v;
-                } else if (off < span) {                   // footprint tail: the last 16 bytes, stored earlier (see me_sb_search_kernel)
+                } else if (off < span) {                   // footprint tail: the last 16 bytes, stored earlier 
                     const uint32_t back = (uint32_t)(off - (span - 16));
                     __builtin_memcpy(&v, gr + (span - 16), 16);
                     struct __attribute__((packed, aligned(1))) U4 { uint32_t a, b, c, d; };

@@ -1,5 +1,6 @@
 // kernel_pixel.h — batched quantize_b, SAD, SAD search, SSE, residual kernels.
 #pragma once
+#include <type_traits>
 #include "dev_common.h"
 
 namespace svtdev {
@@ -255,21 +256,29 @@ __global__ __launch_bounds__(256) void sad_search_q_kernel(
             uint32_t lxs = 1;
             while (lxs < cpr && lxs < lpb) lxs <<= 1;
             const uint32_t lx = l & (lxs - 1), ly = l / lxs, lys = lpb / lxs;
-            for (uint32_t y0 = ly; y0 < height; y0 += 4 * lys)
-                for (uint32_t c = lx; c < cpr; c += lxs) {
-                    uint4 v[4];
+            // (the chunk size is a compile-time constant inside each branch: with `cs` as a run-time memcpy length the generic
+            // <0, 0> instantiation kept v[] in SCRATCH, 80 bytes per lane)
+            auto stage_src = [&](auto CSC) {
+                constexpr uint32_t CS = decltype(CSC)::value;
+                for (uint32_t y0 = ly; y0 < height; y0 += 4 * lys)
+                    for (uint32_t c = lx; c < cpr; c += lxs) {
+                        uint4 v[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t y = y0 + k * lys;
-                        v[k] = make_uint4(0, 0, 0, 0);
-                        if (y < height) __builtin_memcpy(&v[k], gs + (size_t)y * src_stride + c * cs, cs == 16 ? 16 : (cs == 8 ? 8 : 4));
-                    }
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t y = y0 + k * lys;
+                            v[k] = make_uint4(0, 0, 0, 0);
+                            if (y < height) __builtin_memcpy(&v[k], gs + (size_t)y * src_stride + c * CS, CS);
+                        }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t y = y0 + k * lys;
-                        if (y < height) __builtin_memcpy(s_src + y * width + c * cs, &v[k], cs == 16 ? 16 : (cs == 8 ? 8 : 4));
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t y = y0 + k * lys;
+                            if (y < height) __builtin_memcpy(s_src + y * width + c * CS, &v[k], CS);
+                        }
                     }
-                }
+            };
+            if (cs == 16) stage_src(std::integral_constant<uint32_t, 16>{});
+            else if (cs == 8) stage_src(std::integral_constant<uint32_t, 8>{});
+            else stage_src(std::integral_constant<uint32_t, 4>{});
         }
         {   // reference window: rows of wpitch bytes in 16-B chunks; a chunk is loaded wide when it
             // ends inside the window's own footprint (row tails over-read the next row: harmless, only

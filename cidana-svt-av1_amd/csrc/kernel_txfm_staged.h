@@ -28,6 +28,20 @@ struct StagedGeom {
     }
 };
 
+// LDS layouts shared by the inverse / encode kernels below, chosen against the PMC (profiles/r02_pmc_c_enc8.json: 26 % of the LDS
+// cycles of the 8x8 encode kernel were bank conflicts, 14 % at 16x16):
+//  * coefficient tile (linear 16-byte stores -> one-row-per-lane b128 reads): rows of KW * 4 bytes whose 16-byte slots are
+//    XOR-swizzled by the row (the out tile's rule): stores AND reads are conflict-free.  The first version padded the row pitch
+//    by one slot instead, which kept the reads clean and made every linear store a 2-way conflict;
+//  * residual tile (column pass -> reconstruction): int16, W * H + ResPad<W> per block: with the dense pitch the column stores
+//    of all the wave's blocks fell on the same W / 2 banks (8-way at 8x8, 4-way at 16x16).
+template <int KW, int KH>
+__device__ __forceinline__ int coef_tile_addr(int b, int r, int sl) {
+    constexpr int NS = KW / 4, RDIV = (8 / NS) > 1 ? (8 / NS) : 1, SMASK = (NS < 8 ? NS : 8) - 1;
+    return (b * KH + r) * (KW * 4) + ((sl ^ ((r / RDIV) & SMASK)) << 4);
+}
+template <int W> struct ResPad { static constexpr int N = W > 8 ? W : 8; };
+
 // PixT: sample type of src / pred in MODE 1 (uint8_t, or uint16_t for 10-bit).  xy != NULL: the blocks are
 // addressed on picture planes (origin (x, y) = (xy[b] & 0xffff, xy[b] >> 16), row strides in samples) and are
 // fetched row segment by row segment into the same linear staging image; NULL: dense batches.
@@ -250,11 +264,11 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
     using S = StagedGeom<W, H>;
     using G = TxGeom<W, H>;
     constexpr int KW = S::KW, KH = S::KH, NC = S::NC;
-    constexpr int PQ = (KW == 4) ? 3 : KW / 4 + 1;       // row pitch of the coefficient tile in 16-B units (odd-ish: conflict-free b128 row reads)
-    constexpr int IN_BYTES = G::BPW * KH * PQ * 16;
+    constexpr int IN_BYTES = G::BPW * KH * KW * 4;        // coefficient tile, slots swizzled by the row (coef_tile_addr)
+    constexpr int RPAD = ResPad<W>::N;
     constexpr int P16 = W + 2;                           // int16 tile row pitch: (W+2)/2 is odd -> conflict-free row writes
     constexpr int TILE_BYTES = TILE16 ? G::BPW * H * P16 * 2 : G::BPW * G::TILE * 4;
-    constexpr int RES_BYTES = G::BPW * W * H * 2;
+    constexpr int RES_BYTES = G::BPW * (W * H + RPAD) * 2;
     constexpr int WAVE_LDS = (cmax(cmax(IN_BYTES, TILE_BYTES), RES_BYTES) + 15) & ~15;
     __shared__ __attribute__((aligned(16))) char lds[S::WAVES * WAVE_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
                 const int b = q / CPB, w4 = q % CPB;
                 int4 v = make_int4(0, 0, 0, 0);
                 if (first + b < nblocks) v = g[q];
-                *reinterpret_cast<int4*>(wl + ((b * KH + w4 / (KW / 4)) * PQ + w4 % (KW / 4)) * 16) = v;
+                *reinterpret_cast<int4*>(wl + coef_tile_addr<KW, KH>(b, w4 / (KW / 4), w4 % (KW / 4))) = v;
             }
         }
     }
@@ -291,7 +305,7 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
         if (l < KH) {
 #pragma unroll
             for (int s = 0; s < KW / 4; s++) {
-                const int4 v = *reinterpret_cast<const int4*>(wl + ((sub * KH + l) * PQ + s) * 16);
+                const int4 v = *reinterpret_cast<const int4*>(wl + coef_tile_addr<KW, KH>(sub, l, s));
                 x[4 * s] = v.x; x[4 * s + 1] = v.y; x[4 * s + 2] = v.z; x[4 * s + 3] = v.w;
             }
 #pragma unroll
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
     }
     wave_lds_fence();
     if (l < W) {
-        short* res = reinterpret_cast<short*>(wl) + sub * (W * H);
+        short* res = reinterpret_cast<short*>(wl) + sub * (W * H + RPAD);
 #pragma unroll
         // the add to the sample below runs on 16-bit lanes (the reference adds in int32, highbd_clip_pixel_add): exact for
         // bd <= 10, where every column kernel's output is at most 16 bits (12 after this shift, identities 14); bd 12 takes
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
             const int q = it * 64 + lane;
             if (org[it] != 0xffffffffu) {
                 // q-th chunk of the wave = PPC consecutive residuals of the row-major int16 tile
-                const uint32_t* rs = reinterpret_cast<const uint32_t*>(reinterpret_cast<const short*>(wl) + (size_t)q * PPC);
+                const uint32_t* rs = reinterpret_cast<const uint32_t*>(reinterpret_cast<const short*>(wl) + (size_t)q * PPC + (q / CPBP) * RPAD);
                 const uint32_t pw[4] = {pvv[it].x, pvv[it].y, pvv[it].z, pvv[it].w};
                 uint32_t ow[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(StagedWaves<W * H>::N * 64) void inv_staged_kernel(
             if ((NCH % 64 == 0 || q < NCH) && (first + q / CPB < nblocks)) {
                 // residuals arrive as packed int16 pairs; the add / clip runs on 16-bit lanes (v_pk_add_i16,
                 // v_sat_pk_u8_i16 or v_pk_max/min_i16) — SDWA / bfe byte arithmetic costs ~4x as much
-                const uint4* rs4 = reinterpret_cast<const uint4*>(reinterpret_cast<const short*>(wl) + (size_t)q * PPL);
+                const uint4* rs4 = reinterpret_cast<const uint4*>(reinterpret_cast<const short*>(wl) + (size_t)q * PPL + (q / CPB) * RPAD);
                 const uint4 pv = d4[q];
                 const uint32_t pw[4] = {pv.x, pv.y, pv.z, pv.w};
                 uint32_t ow[4];
@@ -437,9 +451,15 @@ template <int W, int H, typename PixT>
 struct EncStagedLds {                                    // LDS bytes per wave / per workgroup of enc_staged_body<W, H, ., PixT>
     using S = StagedGeom<W, H>;
     using G = TxGeom<W, H>;
-    static constexpr int ES = (int)sizeof(PixT), BB = W * H * ES, PADI = (W * ES >= 32) ? 32 : 16, IN_ONE = G::BPW * (BB + PADI);
-    static constexpr int PQ = (S::KW == 4) ? 3 : S::KW / 4 + 1;
-    static constexpr int WAVE = (cmax(cmax(cmax(IN_ONE * 2, G::BPW * G::TILE * 4), G::BPW * W * H * 4), G::BPW * S::KH * PQ * 16) + 15) & ~15;
+    static constexpr int ES = (int)sizeof(PixT), BB = W * H * ES;
+    // input staging: blocks padded by PADI bytes so that the column pass's per-sample reads spread over the banks.  (For 64-byte
+    // blocks - 8x8 8-bit - the pad makes the linear 16-byte staging stores 2-way conflicts; the unpadded form with the chunks of
+    // block b XOR-swizzled by b >> 1 is conflict-free on both sides and was measured 2 % SLOWER, A/B on one box: the kernel is
+    // bound by VALU issue, and the swizzle puts address arithmetic into the column pass.  SWZ_IN keeps that form selectable.)
+    static constexpr bool SWZ_IN = false;
+    static constexpr int PADI = SWZ_IN ? 0 : ((W * ES >= 32) ? 32 : 16), IN_ONE = G::BPW * (BB + PADI);
+    static constexpr int RPAD = ResPad<W>::N;              // residual tile: int16 per block = W * H + RPAD
+    static constexpr int WAVE = (cmax(cmax(IN_ONE * 2, G::BPW * G::TILE * 4), G::BPW * W * H * 4) + 15) & ~15;
     static constexpr int BYTES = S::WAVES * WAVE;
 };
 template <int W, int H, bool KEEP, typename PixT, int BD>
@@ -456,11 +476,10 @@ __device__ __forceinline__ void enc_staged_body(
     constexpr int KW = S::KW, KH = S::KH, NC = S::NC;
     constexpr int ES = (int)sizeof(PixT);                // 1, or 2 for 10-bit samples (BD = 10)
     constexpr int BB = W * H * ES;                       // input bytes per block and array
-    constexpr int PADI = (W * ES >= 32) ? 32 : 16;
-    constexpr int IN_ONE = G::BPW * (BB + PADI);
-    constexpr int PQ = (KW == 4) ? 3 : KW / 4 + 1;
-    constexpr int WAVE_LDS = (cmax(cmax(cmax(IN_ONE * 2, G::BPW * G::TILE * 4), G::BPW * W * H * 4), G::BPW * KH * PQ * 16) + 15) & ~15;
-    static_assert(WAVE_LDS == EncStagedLds<W, H, PixT>::WAVE, "EncStagedLds out of step");
+    using L = EncStagedLds<W, H, PixT>;
+    constexpr bool SWZ_IN = L::SWZ_IN;
+    constexpr int PADI = L::PADI, IN_ONE = L::IN_ONE, RPAD = L::RPAD, WAVE_LDS = L::WAVE;
+    auto dq_addr = [](int b, int r, int sl) { return coef_tile_addr<KW, KH>(b, r, sl); };      // dequantised rows -> inverse row pass
     static_assert(W * H % 16 == 0, "block must be a whole number of 16-B chunks");
     constexpr int in_bits = BD + 8, row_bits = BD == 8 ? 16 : (BD == 10 ? 18 : 20);      // av1_gen_inv_stage_range (:5404-5456)
     constexpr int cin_bits = BD + 6 > 16 ? BD + 6 : 16, col_bits = BD == 12 ? 18 : 16, maxpix = (1 << BD) - 1;
@@ -506,8 +525,10 @@ __device__ __forceinline__ void enc_staged_body(
         for (int it = 0; it < NIT; it++) {
             const int q = it * 64 + lane, b = q / CPBP;
             if (NCHP % 64 == 0 || q < NCHP) {
-                __builtin_memcpy(wl + q * CS + b * PADI, &v0[it], CS);
-                __builtin_memcpy(wl + IN_ONE + q * CS + b * PADI, &pk[it], CS);
+                // (SWZ_IN: 8-byte rows - two of them form a 16-byte chunk, chunk index (q % CPBP) >> 1)
+                const int o = SWZ_IN ? b * BB + (((((q % CPBP) * CS) >> 4) ^ ((b >> 1) & 3)) << 4) + (((q % CPBP) * CS) & 15) : q * CS + b * PADI;
+                __builtin_memcpy(wl + o, &v0[it], CS);
+                __builtin_memcpy(wl + IN_ONE + o, &pk[it], CS);
             }
         }
     } else {
@@ -522,8 +543,9 @@ __device__ __forceinline__ void enc_staged_body(
                 const bool ok = first + b < nblocks;
                 uint4 va = make_uint4(0, 0, 0, 0);
                 if (ok) { pk[it] = *reinterpret_cast<const uint4*>(g1 + (size_t)q * 16); va = *reinterpret_cast<const uint4*>(g0 + (size_t)q * 16); }
-                *reinterpret_cast<uint4*>(wl + q * 16 + b * PADI) = va;
-                *reinterpret_cast<uint4*>(wl + IN_ONE + q * 16 + b * PADI) = pk[it];
+                const int o = SWZ_IN ? b * BB + (((q & 3) ^ ((b >> 1) & 3)) << 4) : q * 16 + b * PADI;
+                *reinterpret_cast<uint4*>(wl + o) = va;
+                *reinterpret_cast<uint4*>(wl + IN_ONE + o) = pk[it];
             }
         }
     }
@@ -537,7 +559,8 @@ __device__ __forceinline__ void enc_staged_body(
 #pragma unroll
             for (int r = 0; r < H; r++) {
                 const int idx = (ud ? H - 1 - r : r) * W + l;
-                const int d = (int)*reinterpret_cast<const PixT*>(bs + idx * ES) - (int)*reinterpret_cast<const PixT*>(bs + IN_ONE + idx * ES);
+                const int io = SWZ_IN ? ((((idx >> 4) ^ ((sub >> 1) & 3)) << 4) | (idx & 15)) : idx * ES;
+                const int d = (int)*reinterpret_cast<const PixT*>(bs + io) - (int)*reinterpret_cast<const PixT*>(bs + IN_ONE + io);
                 sad_acc += (unsigned)(d < 0 ? -d : d);
                 x[r] = round_shift_c<-S0>(d);
             }
@@ -623,7 +646,7 @@ __device__ __forceinline__ void enc_staged_body(
         const int q = it * 64 + lane;
         if (NOUT % 64 == 0 || q < NOUT) {
             const int b = q / CPB, w4 = q % CPB;
-            *reinterpret_cast<int4*>(wl + ((b * KH + w4 / (KW / 4)) * PQ + w4 % (KW / 4)) * 16) = dvs[it];
+            *reinterpret_cast<int4*>(wl + dq_addr(b, w4 / (KW / 4), w4 % (KW / 4))) = dvs[it];
         }
     }
     wave_lds_fence();
@@ -635,7 +658,7 @@ __device__ __forceinline__ void enc_staged_body(
             if (l < KH) {
 #pragma unroll
                 for (int s = 0; s < KW / 4; s++) {
-                    const int4 v = *reinterpret_cast<const int4*>(wl + ((sub * KH + l) * PQ + s) * 16);
+                    const int4 v = *reinterpret_cast<const int4*>(wl + dq_addr(sub, l, s));
                     x[4 * s] = v.x; x[4 * s + 1] = v.y; x[4 * s + 2] = v.z; x[4 * s + 3] = v.w;
                 }
 #pragma unroll
@@ -669,7 +692,7 @@ __device__ __forceinline__ void enc_staged_body(
         }
         wave_lds_fence();
         if (l < W) {
-            short* res = reinterpret_cast<short*>(wl) + sub * (W * H);
+            short* res = reinterpret_cast<short*>(wl) + sub * (W * H + RPAD);
 #pragma unroll
             for (int r = 0; r < H; r++) res[r * W + l] = (short)round_shift_c<4>(y[ud ? H - 1 - r : r]);
         }
@@ -681,7 +704,7 @@ __device__ __forceinline__ void enc_staged_body(
         for (int it = 0; it < NIT; it++) {
             const int q = it * 64 + lane, w = q % CPBP;
             if (org[it] != 0xffffffffu) {
-                const uint32_t* rs = reinterpret_cast<const uint32_t*>(reinterpret_cast<const short*>(wl) + (size_t)q * PPC);
+                const uint32_t* rs = reinterpret_cast<const uint32_t*>(reinterpret_cast<const short*>(wl) + (size_t)q * PPC + (q / CPBP) * RPAD);
                 const uint32_t pw[4] = {pk[it].x, pk[it].y, pk[it].z, pk[it].w};
                 uint32_t ow[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -705,7 +728,7 @@ __device__ __forceinline__ void enc_staged_body(
         for (int it = 0; it < NCHI; it++) {
             const int q = it * 64 + lane;
             if ((NCH % 64 == 0 || q < NCH) && (first + (q * 16) / BB < nblocks)) {
-                const uint4* rs4 = reinterpret_cast<const uint4*>(reinterpret_cast<const short*>(wl) + (size_t)q * PP16);
+                const uint4* rs4 = reinterpret_cast<const uint4*>(reinterpret_cast<const short*>(wl) + (size_t)q * PP16 + ((q * 16) / BB) * RPAD);
                 const uint32_t pw[4] = {pk[it].x, pk[it].y, pk[it].z, pk[it].w};
                 uint32_t ow[4];
                 if constexpr (ES == 1) {

@@ -11,7 +11,6 @@ int g_device = -1;
 char g_devname[300] = "";
 int g_num_cu = 256;
 // tuning knobs (svt_hip_tune): fused 32x32 kernel occupancy / grid
-int g_tune_f32_min_waves = 1;
 int g_tune_f32_wg_per_cu = 0;
 int g_tune_f32_nt = 0;
 int g_tune_f32_qmode1 = 0;
@@ -25,7 +24,6 @@ int g_tune_ois_no_fold = 0;
 int g_tune_ois_no_nd = 0;
 int g_tune_dir_no_split = 0;
 int g_tune_dir_split_target = 4;         // workgroups per CU below which the directional kernels spread their angles over grid.y (swept 1 .. 16 on the 1080p search: 3-4 is the minimum for 8x8 and 16x16)
-int g_tune_no_me16 = 0;
 int g_tune_me_exact = 0;
 int g_tune_no_f32p = 0;
 int g_tune_no_inv_planes = 0;
@@ -110,7 +108,6 @@ extern "C" void svt_hip_shutdown(void) {
 }
 extern "C" int svt_hip_tune(const char* key, int value) {
     if (!key) return SVT_HIP_ERR_INVALID;
-    if (!strcmp(key, "f32_min_waves")) { g_tune_f32_min_waves = value; return SVT_HIP_OK; }
     if (!strcmp(key, "f32_wg_per_cu")) { g_tune_f32_wg_per_cu = value; return SVT_HIP_OK; }
     if (!strcmp(key, "f32_nt")) { g_tune_f32_nt = value; return SVT_HIP_OK; }
     if (!strcmp(key, "f32_qmode1")) { g_tune_f32_qmode1 = value; return SVT_HIP_OK; }
@@ -124,7 +121,6 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "ois_no_nd")) { g_tune_ois_no_nd = value; return SVT_HIP_OK; }
     if (!strcmp(key, "dir_no_split")) { g_tune_dir_no_split = value; return SVT_HIP_OK; }
     if (!strcmp(key, "dir_split_target")) { g_tune_dir_split_target = value > 0 ? value : 1; return SVT_HIP_OK; }
-    if (!strcmp(key, "no_me16")) { g_tune_no_me16 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "me_exact")) { g_tune_me_exact = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_f32p")) { g_tune_no_f32p = value; return SVT_HIP_OK; }
     if (!strcmp(key, "no_inv_planes")) { g_tune_no_inv_planes = value; return SVT_HIP_OK; }

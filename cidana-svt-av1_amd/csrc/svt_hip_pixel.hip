@@ -286,21 +286,16 @@ static int me_sb_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t s
     const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
     const size_t lds = 32 * 64 + (size_t)wpitch * win_h;
     if (lds > 60 * 1024) return set_err(SVT_HIP_ERR_INVALID, "search window needs %zu B of LDS (> 60 KiB)", lds);
-    if (!g_tune_no_me16) {      // 16 points per lane; widths that are not a multiple of 16 mask the tail of each row
-        if ((search_w & 15) == 0)
-            hipLaunchKernelGGL(me_sb_search16_kernel<false>, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
-                               src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
-                               x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offs, d_ref_offs, (uint32_t)nblocks);
-        else
-            hipLaunchKernelGGL(me_sb_search16_kernel<true>, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
-                               src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
-                               x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offs, d_ref_offs, (uint32_t)nblocks);
-        return launch_status("me_sb_search16");
-    }
-    hipLaunchKernelGGL(me_sb_search_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
-                       src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
-                       x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offs, d_ref_offs, (uint32_t)nblocks);
-    return launch_status("me_sb_search");
+    // 16 points per lane; widths that are not a multiple of 16 mask the tail of each row
+    if ((search_w & 15) == 0)
+        hipLaunchKernelGGL(me_sb_search16_kernel<false>, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
+                           src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
+                           x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offs, d_ref_offs, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL(me_sb_search16_kernel<true>, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src,
+                           src_stride, src_block_pitch, d_ref, ref_stride, ref_block_pitch, search_w, search_h, d_origins,
+                           x_origin, y_origin, d_best_sad, d_best_mv, wpitch, d_src_offs, d_ref_offs, (uint32_t)nblocks);
+    return launch_status("me_sb_search16");
 }
 
 extern "C" int svt_hip_me_sb_search_batch(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch,

@@ -320,8 +320,6 @@ extern "C" int svt_hip_fwd_quant_sad_batch(const uint8_t* d_src, const uint8_t* 
         if (d_sad) F32_LAUNCH_Q(true, 1, true, 1); else F32_LAUNCH_Q(false, 1, true, 1);
     } else if (!fastq) {
         if (d_sad) F32_LAUNCH_Q(true, 1, false, 1); else F32_LAUNCH_Q(false, 1, false, 1);
-    } else if (g_tune_f32_min_waves == 4) {
-        if (d_sad) F32_LAUNCH_Q(true, 4, false, 2); else F32_LAUNCH_Q(false, 4, false, 2);
     } else {
         if (d_sad) F32_LAUNCH_Q(true, 1, false, 2); else F32_LAUNCH_Q(false, 1, false, 2);
     }
@@ -530,59 +528,72 @@ extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int
         if (G.tx_size == SVT_TX_4X4 && g_tune_no_enc_staged && (!G.d_coeff || !G.d_offsets || G.d_recon != G.d_pred || G.recon_stride != G.pred_stride))
             return set_err(SVT_HIP_ERR_INVALID, "group %d: with no_enc_staged set, 4x4 groups take the two-stage path and need d_coeff, d_dqcoeff, d_offsets and in-place reconstruction", g);
     }
-    // ---- ONE launch for the whole call (enc_frame_kernel) when every group is one it covers: square sizes 4 .. 64 (any type),
-    // qcoeff + recon outputs, power-of-two quant_shift tables.  Measured (tools/bench_frame.py, tools/bench_c5.py): one 1080p
-    // picture 0.044 ms against 0.160 (13 launches on 8 streams) / 0.101 (those captured into a graph); one 4K 10-bit picture
-    // 5 390 against 3 990 pictures/s; a stack of 16 1080p pictures the same either way; a stack of 30 4K 10-bit pictures 5 270
-    // against 6 100 (the launch runs every size at the 64x64 body's register budget).  So: one launch up to 2^27 pixel passes
-    // per call, per-size launches above.  svt_hip_tune("frame_single_launch", 0 / 1) forces either; -1 (default) is this rule.
+    // ---- one launch per REGISTER CLASS (enc_frame_kernel, kernel_frame.h) when every group is one the fused bodies cover: any of the
+    // 19 sizes and their types, qcoeff + recon outputs, power-of-two quant_shift tables.  Measured (tools/bench_frame.py,
+    // tools/bench_c5.py): a 1080p picture as 13 per-size launches on 8 streams 0.160 ms, those captured into a graph 0.101, ONE
+    // launch at the 64x64 body's register budget (round 2) 0.044; by class see DESIGN 4.17.  A call above 2^27 pixel passes (a GOP
+    // of 4K pictures) takes the launches by register class.
     size_t call_pixels = 0;
     for (int g = 0; g < ngroups; g++)
         if (groups[g].nblocks) call_pixels += (size_t)groups[g].nblocks * kTxW[groups[g].tx_size] * kTxH[groups[g].tx_size];      // (validated above)
-    const bool want_single = g_tune_frame_single_launch > 0 || (g_tune_frame_single_launch < 0 && call_pixels <= ((size_t)1 << 27));
-    if (want_single && ngroups <= FRAME_MAX_GROUPS) {
+    // frame_single_launch: 1 one launch (class 3), 2 one launch per register class, 0 per-size launches, -1 (default): one launch up to
+    // 2^25 pixel passes per call (two 1080p pictures with five sizes; measured cross-over between 2 and 4, tools/bench_frame.py), class launches above
+    int mode = g_tune_frame_single_launch >= 0 ? g_tune_frame_single_launch : (call_pixels <= ((size_t)1 << 25) ? 1 : 2);
+    for (int g = 0; g < ngroups; g++)
+        if (mode == 1 && groups[g].nblocks && groups[g].tx_size > SVT_TX_64X64) mode = 2;      // the one-launch kernel holds the square sizes
+    if (mode > 0) {
         bool ok = true;
+        int per_class[4] = {0, 0, 0, 0};
         for (int g = 0; g < ngroups && ok; g++) {
             const svt_hip_frame_group& G = groups[g];
             if (G.nblocks == 0) continue;
-            ok = G.tx_size >= SVT_TX_4X4 && G.tx_size <= SVT_TX_64X64 && !G.d_coeff && G.d_recon != G.d_src &&      // (type / size validated above)
-                 (((uintptr_t)G.d_qcoeff) & 15) == 0;
+            ok = !G.d_coeff && G.d_recon != G.d_src && (((uintptr_t)G.d_qcoeff) & 15) == 0;      // (type / size validated above)
+            per_class[mode == 1 ? 3 : frame_class_of(G.tx_size)]++;
         }
         if ((is_16bit && bd != 10) || (!is_16bit && bd != 8)) ok = false;
-        FrameDesc fd;
-        memset(&fd, 0, sizeof(fd));
-        uint32_t total = 0;
+        for (int c = 0; c < 4; c++) ok = ok && per_class[c] <= FRAME_MAX_GROUPS;
+        FrameDesc fd[4];
+        uint32_t total[4] = {0, 0, 0, 0};
         if (ok) {
-            int order[FRAME_MAX_GROUPS];
+            memset(fd, 0, sizeof(fd));
+            int order[256];
             for (int i = 0; i < ngroups; i++) order[i] = i;
             for (int i = 1; i < ngroups; i++) {          // largest blocks first: the long workgroups start early
                 const int v = order[i];
+                const int pv = kTxW[groups[v].tx_size] * kTxH[groups[v].tx_size];
                 int j = i - 1;
-                while (j >= 0 && groups[order[j]].tx_size < groups[v].tx_size) { order[j + 1] = order[j]; j--; }
+                while (j >= 0 && kTxW[groups[order[j]].tx_size] * kTxH[groups[order[j]].tx_size] < pv) { order[j + 1] = order[j]; j--; }
                 order[j + 1] = v;
             }
             for (int k = 0; k < ngroups && ok; k++) {
                 const svt_hip_frame_group& G = groups[order[k]];
                 if (G.nblocks == 0) continue;
-                const int pels = kTxW[G.tx_size] * kTxH[G.tx_size];
-                FrameGroupDev& D = fd.g[fd.ngroups];
+                const int pels = kTxW[G.tx_size] * kTxH[G.tx_size], c = mode == 1 ? 3 : frame_class_of(G.tx_size);
+                FrameGroupDev& D = fd[c].g[fd[c].ngroups];
                 D.qp = make_qparams(zbin, round, quant, quant_shift, dequant, pels > 1024 ? 2 : (pels > 256 ? 1 : 0));
                 for (int i = 0; i < 2; i++) ok = ok && D.qp.quant_shift[i] >= 0 && D.qp.dequant[i] >= 0 && D.qp.round[i] >= 0;
                 ok = ok && D.qp.fast_ok;
                 D.src = G.d_src; D.pred = G.d_pred; D.recon = G.d_recon; D.qcoeff = G.d_qcoeff; D.eob = G.d_eob; D.xy = G.d_xy; D.iscan = G.d_iscan;
                 D.src_stride = G.src_stride; D.pred_stride = G.pred_stride; D.recon_stride = G.recon_stride; D.nblocks = G.nblocks; D.tx_size = G.tx_size; D.tx_type = G.tx_type;
-                // blocks per 256-thread workgroup of each body: 256 (4x4), 32 (8x8: 4 waves x 8), 16 (16x16: 4 x 4), 8 (32x32: 4 x 2), 4 (64x64: 2 x 2)
-                static const uint32_t per_wg[5] = {256, 32, 16, 8, 4};
-                total += (G.nblocks + per_wg[G.tx_size] - 1) / per_wg[G.tx_size];
-                D.wg_end = total;
-                fd.ngroups++;
+                const uint32_t per_wg = frame_blocks_per_wg(G.tx_size);
+                total[c] += (G.nblocks + per_wg - 1) / per_wg;
+                D.wg_end = total[c];
+                fd[c].ngroups++;
             }
         }
         if (ok) {
-            if (fd.ngroups == 0) return SVT_HIP_OK;
-            if (is_16bit) hipLaunchKernelGGL((enc_frame_kernel<uint16_t, 10>), dim3(total), dim3(256), 0, (hipStream_t)stream, fd);
-            else hipLaunchKernelGGL((enc_frame_kernel<uint8_t, 8>), dim3(total), dim3(256), 0, (hipStream_t)stream, fd);
-            return launch_status("enc_frame");
+            // (class launches: the 64x64 class first, the small sizes last)
+            hipStream_t hs = (hipStream_t)stream;
+#define FRAME_LAUNCH(C)                                                                                                                         \
+            if (fd[C].ngroups) {                                                                                                                \
+                if (is_16bit) hipLaunchKernelGGL((enc_frame_kernel<uint16_t, 10, C>), dim3(total[C]), dim3(256), 0, hs, fd[C]);                 \
+                else hipLaunchKernelGGL((enc_frame_kernel<uint8_t, 8, C>), dim3(total[C]), dim3(256), 0, hs, fd[C]);                            \
+                if (int rc = launch_status("enc_frame")) return rc;                                                                             \
+            }
+            if (fd[3].ngroups) return launch_enc_frame_one(&fd[3], total[3], is_16bit, hs);      // (svt_hip_frame.hip)
+            FRAME_LAUNCH(2) FRAME_LAUNCH(1) FRAME_LAUNCH(0)
+#undef FRAME_LAUNCH
+            return SVT_HIP_OK;
         }
     }
     if (int rc = t_fan.ensure()) return rc;

@@ -15,10 +15,10 @@ TX_OF_SIDE = {64: 4, 32: 3, 16: 2, 8: 1, 4: 0}          # square TxSize by side
 LUMA_SIZES = (64, 32, 16, 8, 4)
 
 
-def tile_origins(pw: int, ph: int, side: int):
-    """(xy, offsets): block origins x | y << 16 and element offsets y * pw + x of the full side x side tiles of a plane"""
+def tile_origins(pw: int, ph: int, side: int, side_h: int | None = None):
+    """(xy, offsets): block origins x | y << 16 and element offsets y * pw + x of the full side x side (or side x side_h) tiles of a plane"""
     xs = np.arange(0, pw - side + 1, side, dtype=np.uint32)
-    ys = np.arange(0, ph - side + 1, side, dtype=np.uint32)
+    ys = np.arange(0, ph - (side_h or side) + 1, side_h or side, dtype=np.uint32)
     xy = ((ys[:, None] << 16) | xs[None, :]).reshape(-1)
     offs = (ys[:, None] * np.uint32(pw) + xs[None, :]).reshape(-1)
     return xy.astype(np.uint32), offs.astype(np.uint32)
@@ -28,49 +28,55 @@ class FramePass:
     """Device-side state of every group of one or more passes over one picture: origin tables, scan tables, output
     buffers, and the ctypes group array for svt_hip_encode_recon_frame.  Keeps every tensor alive."""
 
-    def __init__(self, dsp, pkg, planes_src, planes_pred, luma_sizes=LUMA_SIZES, is_16bit=False, keep_coeff=False, tx_types=None):
-        """tx_types: {block side: transform type} (default DCT_DCT everywhere)"""
+    def __init__(self, dsp, pkg, planes_src, planes_pred, luma_sizes=LUMA_SIZES, is_16bit=False, keep_coeff=False, tx_types=None, rect_tx_sizes=()):
+        """tx_types: {block side: transform type} (default DCT_DCT everywhere); rect_tx_sizes: rectangular TxSize ids (5 .. 18) that
+        tile the luma plane too (DCT_DCT), e.g. pkg.TX_SIZE_NAMES.index("TX_16X8")"""
         import torch
         self.dsp, self.torch = dsp, torch
         self.groups = []
         dev = next(iter(planes_src.values())).device
-        for S in luma_sizes:
-            for name, src in planes_src.items():
+        passes = [(S, name, None) for S in luma_sizes for name in planes_src] + [(None, "Y", ts) for ts in rect_tx_sizes]
+        for S, name, rect in passes:
+            src = planes_src[name]
+            side_h = None
+            if rect is None:
                 side = S if name == "Y" else S // 2
                 if side < 4:
                     continue
                 ts = TX_OF_SIDE[side]
-                if src.dim() == 3:                # a stack of F pictures [F, H, W] (a GOP): every picture tiled on its own, one launch
-                    nf, ph, pw = src.shape
-                    if nf * ph > 0xffff:
-                        raise ValueError("a stack of pictures must stay below 65 536 rows (16-bit origins)")
-                    xy1, offs1 = tile_origins(pw, ph, side)
-                    rows = (np.arange(nf, dtype=np.uint32) * np.uint32(ph))[:, None]
-                    xy = (xy1[None, :] + (rows << 16)).reshape(-1).astype(np.uint32)
-                    offs = (offs1[None, :] + rows * np.uint32(pw)).reshape(-1).astype(np.uint32)
-                else:
-                    ph, pw = src.shape
-                    xy, offs = tile_origins(pw, ph, side)
-                n = xy.size
-                if n == 0:
-                    continue
-                tt = (tx_types or {}).get(side, 0)
-                _, iscan = pkg.tables.scan_tables(ts, tt)
-                nc = min(side, 32) ** 2
-                pred = planes_pred[name]
-                recon = pred.clone()              # samples outside the full tiles keep the prediction, as in-place reconstruction would
-                # 2-D planes may be views into padded picture buffers (PictureInput): their own row strides; the stack form is dense
-                sst = src.stride(0) if src.dim() == 2 else pw
-                pst = pred.stride(0) if pred.dim() == 2 else pw
-                g = {"name": name, "luma_size": S, "tx_size": ts, "tx_type": tt, "src": src, "src_stride": sst, "pred": pred, "pred_stride": pst,
-                     "recon": recon, "recon_stride": pw, "xy": torch.from_numpy(xy.view(np.int32)).to(dev),
-                     "offsets": torch.from_numpy(offs.view(np.int32)).to(dev) if ts == 0 else None,
-                     "iscan": torch.from_numpy(iscan).to(dev), "qcoeff": torch.empty((n, nc), dtype=torch.int32, device=dev),
-                     "eob": torch.zeros(n, dtype=torch.int16, device=dev), "pixels": n * side * side}
-                if keep_coeff:
-                    g["coeff"] = torch.empty((n, nc), dtype=torch.int32, device=dev)
-                    g["dqcoeff"] = torch.empty((n, nc), dtype=torch.int32, device=dev)
-                self.groups.append(g)
+            else:
+                ts, side, side_h = rect, pkg.TX_W[rect], pkg.TX_H[rect]
+            if src.dim() == 3:                # a stack of F pictures [F, H, W] (a GOP): every picture tiled on its own, one launch
+                nf, ph, pw = src.shape
+                if nf * ph > 0xffff:
+                    raise ValueError("a stack of pictures must stay below 65 536 rows (16-bit origins)")
+                xy1, offs1 = tile_origins(pw, ph, side, side_h)
+                rows = (np.arange(nf, dtype=np.uint32) * np.uint32(ph))[:, None]
+                xy = (xy1[None, :] + (rows << 16)).reshape(-1).astype(np.uint32)
+                offs = (offs1[None, :] + rows * np.uint32(pw)).reshape(-1).astype(np.uint32)
+            else:
+                ph, pw = src.shape
+                xy, offs = tile_origins(pw, ph, side, side_h)
+            n = xy.size
+            if n == 0:
+                continue
+            tt = (tx_types or {}).get(side, 0) if rect is None else 0
+            _, iscan = pkg.tables.scan_tables(ts, tt)
+            nc = min(side, 32) * min(side_h or side, 32)
+            pred = planes_pred[name]
+            recon = pred.clone()              # samples outside the full tiles keep the prediction, as in-place reconstruction would
+            # 2-D planes may be views into padded picture buffers (PictureInput): their own row strides; the stack form is dense
+            sst = src.stride(0) if src.dim() == 2 else pw
+            pst = pred.stride(0) if pred.dim() == 2 else pw
+            g = {"name": name, "luma_size": S if rect is None else f"{side}x{side_h}", "tx_size": ts, "tx_type": tt, "src": src, "src_stride": sst, "pred": pred, "pred_stride": pst,
+                 "recon": recon, "recon_stride": pw, "xy": torch.from_numpy(xy.view(np.int32)).to(dev),
+                 "offsets": torch.from_numpy(offs.view(np.int32)).to(dev) if ts == 0 else None,
+                 "iscan": torch.from_numpy(iscan).to(dev), "qcoeff": torch.empty((n, nc), dtype=torch.int32, device=dev),
+                 "eob": torch.zeros(n, dtype=torch.int16, device=dev), "pixels": n * side * (side_h or side)}
+            if keep_coeff:
+                g["coeff"] = torch.empty((n, nc), dtype=torch.int32, device=dev)
+                g["dqcoeff"] = torch.empty((n, nc), dtype=torch.int32, device=dev)
+            self.groups.append(g)
         self.array = dsp.make_frame_groups(self.groups)
         self.is_16bit = is_16bit
         self.pixels = sum(g["pixels"] for g in self.groups)

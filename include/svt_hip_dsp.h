@@ -79,10 +79,10 @@ const char *svt_hip_device_name(void);
 
 /* Performance-tuning / A-B knobs; they never change results, only which kernel variant runs
  * (process-wide, not thread-safe: set them before the worker threads start).  Keys:
- *   "f32_min_waves" (1|4: register cap of the fused 32x32 kernel), "f32_wg_per_cu" (persistent grid = CUs x
+ *   "f32_wg_per_cu" (persistent grid = CUs x
  *   this; 0 = one-shot grid), "f32_nt" (non-temporal stores), "f32_qmode1" (general 24-bit quantiser form),
  *   "no_staged", "no_f32p", "no_enc_staged", "no_inv_planes" (1 = take the general un-staged / two-kernel path),
- *   "no_qsad", "no_q2", "no_q16", "no_me16" (1 = take the first-generation search kernels), "me_exact" (1 = svt_hip_me_fullpel_search_batch always takes its general search-point-by-search-point kernel), "q2_su4" (1 = two-step window staging), "ois_no_fold" (1 = directional predictions through scratch),
+ *   "no_qsad", "no_q2", "no_q16" (1 = take the first-generation search kernels), "me_exact" (1 = svt_hip_me_fullpel_search_batch always takes its general search-point-by-search-point kernel), "q2_su4" (1 = two-step window staging), "ois_no_fold" (1 = directional predictions through scratch),
  *   "inv32_waves", "inv32_var" (probe variants of the inverse 32x32 kernel, tools/tune_inv32.py).
  * Unknown keys return SVT_HIP_ERR_INVALID. */
 int svt_hip_tune(const char *key, int value);

@@ -251,10 +251,14 @@ def test_me_sb_search_variants(dsp, sw, sh):
     ref = rng.integers(0, 256, size=(n, 64 + sh - 1, 64 + sw - 1 + 2), dtype=np.uint8)
     ref[0] = 9; src[0] = 7
     ref[1] = 255; src[1] = 0
+    # the 16-points-per-lane kernel (legacy result layout 8x8 | 16x16 | 32x32 | 64x64) against the search-point-by-search-point
+    # kernel in the reference's layout (svt_hip_tune("me_exact", 1)): two independent implementations
+    a = dsp.me_sb_search(dev(src), dev(ref), sw, sh)
     try:
-        _tune(dsp, "no_me16", 0); a = dsp.me_sb_search(dev(src), dev(ref), sw, sh)
-        _tune(dsp, "no_me16", 1); b = dsp.me_sb_search(dev(src), dev(ref), sw, sh)
+        _tune(dsp, "me_exact", 1); e = dsp.me_fullpel_search(dev(src), dev(ref), sw, sh, nsq=False)
     finally:
-        _tune(dsp, "no_me16", 0)
+        _tune(dsp, "me_exact", 0)
     torch.cuda.synchronize()
+    order = [21 + i for i in range(64)] + [5 + i for i in range(16)] + [1 + i for i in range(4)] + [0]     # legacy slot -> EbMeTierZeroPu index
+    b = tuple(t[:, order].contiguous() for t in e)
     assert _eq(a, b)

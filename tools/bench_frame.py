@@ -6,6 +6,7 @@ residual -> FwdTxfm2d -> quantise / dequantise -> InvTxfm2d + add on planes.  Th
   frame_graph  that call captured once into a HIP graph and replayed
   frame_one_launch / _graph  svt_hip_tune("frame_single_launch", 1): every group in ONE kernel launch (enc_frame_kernel)
   frame_gop16_per_frame  16 independent frames stacked into one call (13 launches for the GOP), time per frame
+  frame_class_launches / frame_gop*_class_launches  svt_hip_tune("frame_single_launch", 2): one launch per register class
 Bytes: 7 B/px kept outputs (src, pred u8 in; qcoeff i32 + recon u8 out) - SURVEY 8(d)'s fused figure; the 4x4 groups also
 write coeff / dqcoeff.  One JSON line per mode + a summary; also written to gpurun_out/frame_c4.json."""
 import json
@@ -87,7 +88,18 @@ assert fpg.pixels == NF * fp.pixels
 rows["frame_gop16_per_frame"] = timeit(lambda: fpg.run(qrow), iters=10) / NF
 assert dsp.lib.svt_hip_tune(b"frame_single_launch", 1) == 0
 rows["frame_gop16_one_launch_per_frame"] = timeit(lambda: fpg.run(qrow), iters=10) / NF
+assert dsp.lib.svt_hip_tune(b"frame_single_launch", 2) == 0          # one launch per register class (<= 16 | 32 | 64)
+rows["frame_gop16_class_launches_per_frame"] = timeit(lambda: fpg.run(qrow), iters=10) / NF
+rows["frame_class_launches"] = timeit(lambda: fp.run(qrow))
+for nf in (2, 4):                                                    # where the class launches start to pay
+    sub_s = {k: v[:nf] for k, v in srcg.items()}; sub_p = {k: v[:nf] for k, v in predg.items()}
+    fps = frames.FramePass(dsp, pkg, sub_s, sub_p)
+    for knob, tag in ((1, "one_launch"), (2, "class_launches")):
+        assert dsp.lib.svt_hip_tune(b"frame_single_launch", knob) == 0
+        rows[f"frame_gop{nf}_{tag}_per_frame"] = timeit(lambda: fps.run(qrow), iters=10) / nf
 assert dsp.lib.svt_hip_tune(b"frame_single_launch", -1) == 0
+rows["frame_default_policy"] = timeit(lambda: fp.run(qrow))
+rows["frame_gop16_default_policy_per_frame"] = timeit(lambda: fpg.run(qrow), iters=10) / NF
 if os.environ.get("FRAME_ONLY_GOP"):          # for rocprofv3: only the GOP call's kernels in the trace
     sys.exit(0)
 out = {"config": "configs[3]: one 1920x1080 yuv420p frame, luma sizes 64/32/16/8/4 + chroma at half the side, 8-bit, qindex 100",

@@ -31,7 +31,7 @@ times = {v: [] for v in variants}
 for rnd in range(8):
     for v in variants:
         nt, mw, wg = v
-        dsp.lib.svt_hip_tune(b"f32_nt", nt); dsp.lib.svt_hip_tune(b"f32_min_waves", mw); dsp.lib.svt_hip_tune(b"f32_wg_per_cu", wg)
+        dsp.lib.svt_hip_tune(b"f32_nt", nt); dsp.lib.svt_hip_tune(b"f32_wg_per_cu", wg)      # (the 128-register variant, min_waves 4, spilled to scratch and was removed)
         times[v].append(run(8))
 res = []
 for v in variants:
