@@ -737,7 +737,7 @@ class SvtHipDsp:
         self._check(self.lib.svt_hip_intra_neighbor_px(ctypes.addressof(pos), ctypes.addressof(blk)), "svt_hip_intra_neighbor_px")
         return blk.n_top_px, blk.n_topright_px, blk.n_left_px, blk.n_bottomleft_px
 
-    def build_intra_predictors(self, top_neigh, left_neigh, blocks, tx_size, bd=8, dst=None, dst_stride=None, dst_offsets=None):
+    def build_intra_predictors(self, top_neigh, left_neigh, blocks, tx_size, bd=8, dst=None, dst_stride=None, dst_offsets=None, order=None):
         """build_intra_predictors{,_high} on a batch (svt_hip_build_intra_predictors_batch).  top_neigh / left_neigh: uint8 or int16
         (uint16 values) [n, pitch] with element 0 = the corner sample; blocks: uint8 [n, 8] descriptors (IntraBlk layout).
         -> dst [n, h, w] (dense) unless dst / dst_offsets address a picture."""
@@ -750,11 +750,30 @@ class SvtHipDsp:
             dst_stride, pitch = w, w * h
         else:
             pitch = 0 if dst_offsets is not None else h * dst_stride
+        if order is not None:
+            self.lib.svt_hip_build_intra_predictors_ordered_batch.argtypes = [c_void_p, c_int32, c_size_t] + [c_void_p] * 3 + [c_int32, c_void_p, c_void_p,
+                                                                              c_int, c_int, c_int, c_size_t, c_void_p]
+            self._check(self.lib.svt_hip_build_intra_predictors_ordered_batch(self._p(dst), dst_stride, pitch, self._p(dst_offsets) if dst_offsets is not None else None,
+                                                                              self._p(top_neigh), self._p(left_neigh), top_neigh.shape[1], self._p(blocks),
+                                                                              self._p(order), tx_size, int(is16), bd, n, self._stream()),
+                        "svt_hip_build_intra_predictors_ordered_batch")
+            return dst
         self._check(self.lib.svt_hip_build_intra_predictors_batch(self._p(dst), dst_stride, pitch, self._p(dst_offsets) if dst_offsets is not None else None,
                                                                   self._p(top_neigh), self._p(left_neigh), top_neigh.shape[1], self._p(blocks),
                                                                   tx_size, int(is16), bd, n, self._stream()),
                     "svt_hip_build_intra_predictors_batch")
         return dst
+
+    def intra_order_blocks(self, blocks, tx_size):
+        """svt_hip_intra_order_blocks_batch: the batch's block indices sorted by predictor kind (device) -> int32 [n]"""
+        t = self.torch
+        n = blocks.shape[0]
+        order = t.empty(n, dtype=t.int32, device=blocks.device)
+        work = t.empty(32, dtype=t.int32, device=blocks.device)
+        self.lib.svt_hip_intra_order_blocks_batch.argtypes = [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p]
+        self._check(self.lib.svt_hip_intra_order_blocks_batch(self._p(blocks), tx_size, n, self._p(order), self._p(work), self._stream()),
+                    "svt_hip_intra_order_blocks_batch")
+        return order
 
     ME_PUS_ALL = 209
     FLAVOUR_C, FLAVOUR_AVX2 = 0, 1

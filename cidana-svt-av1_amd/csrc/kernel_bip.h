@@ -11,9 +11,18 @@
 // fences) is the same for every block whatever its mode; stages a block does not need are predicated off.  Output: 4 samples
 // per lane per step (one 4- or 8-byte store when the address allows).
 //
-// Write-bound like the other predictors (1-2 B out per pixel, ~2(W+H) samples in per block) but with per-block modes the
-// kernel cannot be specialised per mode the way intra_pred_kernel is; it is the encode-pass glue, not the search loop.
+// Round 3.  PMC on the first version (profiles/r02_pmc_c_bip.json): 1 400 VALU instructions per wave of four 16x16 blocks, 0.07 of
+// HBM - every wave ran every stage (a stage is predicated per lane, but the wave issues it if ONE of its blocks needs it) and the
+// per-pixel `switch` over the predictor kind was executed once per kind present in the wave.  Now:
+//   * the block size is a template parameter (loops unrolled, no run-time divisions);
+//   * svt_hip_intra_order_blocks_batch (bip_order_*_kernel below) sorts the batch's block indices by predictor kind on the
+//     device (count, scan of 13 bins, scatter) and the kernel walks the batch through that order: a wave's blocks then share
+//     a kind except at the 12 class boundaries;
+//   * stages 2 - 4 are skipped by the whole wave when none of its blocks is angled / up-sampled (a ballot), and a wave whose
+//     blocks share a kind runs that kind's own pixel loop - the `switch` is taken once per wave, on a scalar.
+// It stays the encode-pass glue, not the search loop; the dense per-mode kernels (kernel_intra.h) are the specialised form.
 #pragma once
+#include <type_traits>
 #include "kernel_intra.h"
 
 namespace svtdev {
@@ -71,18 +80,91 @@ __host__ __device__ constexpr int bip_lanes_per_block(int w, int h) {
     return l > 64 ? 64 : l;
 }
 
-template <typename PixT>
+// the predictor kind a block resolves to (stage 5 of bip_kernel; also the sort key of the ordering pass)
+__device__ __forceinline__ int bip_kind_of(const BipBlk& d, int w, int h, int& p_angle_out) {
+    const int mode = d.mode > 12 ? 12 : d.mode;
+    const int n_top = min((int)d.n_top_px, w), n_left = min((int)d.n_left_px, h);
+    const bool is_dr = mode >= 1 && mode <= 8;
+    int p_angle = 0;
+    bool need_left = true, need_above = true;
+    if (is_dr) {
+        const int delta = max(-3, min(3, (int)d.angle_delta));
+        const int ang[9] = {0, 90, 180, 45, 135, 113, 157, 203, 67};      // mode_to_angle_map (EbCodingUnit.h:129)
+        int a0 = 0;
+#pragma unroll
+        for (int i = 1; i < 9; i++) a0 = i == mode ? ang[i] : a0;
+        p_angle = a0 + 3 * delta;
+        need_above = p_angle < 180; need_left = p_angle > 90;
+    }
+    p_angle_out = p_angle;
+    const bool const_fill = (!need_above && n_left == 0) || (!need_left && n_top == 0);
+    if (const_fill) return IM_DC_128;
+    if (is_dr) return p_angle == 90 ? IM_V : (p_angle == 180 ? IM_H : (p_angle < 90 ? IM_Z1 : (p_angle < 180 ? IM_Z2 : IM_Z3)));
+    if (mode == 0) return n_left > 0 ? (n_top > 0 ? IM_DC : IM_DC_LEFT) : (n_top > 0 ? IM_DC_TOP : IM_DC_128);       // dc_pred[left][top], :3851
+    return mode == 9 ? IM_SMOOTH : (mode == 10 ? IM_SMOOTH_V : (mode == 11 ? IM_SMOOTH_H : IM_PAETH));
+}
+
+// ---- ordering pass: block indices sorted by kind (counting sort over IM_MODES = 13 bins; the order inside a bin is whatever the
+// atomics give - the prediction of a block does not depend on its place in the order) ------------------------------------------
+// (a workgroup takes BIP_ORDER_ITEMS blocks per lane: with one block per lane the 13 global counters took 13 atomics from each of
+// 4 096 workgroups of a 2^20-block batch - 50 us per pass, a third of the whole call)
+constexpr int BIP_ORDER_ITEMS = 16;
+__global__ __launch_bounds__(256) void bip_order_count_kernel(const BipBlk* __restrict__ blks, int w, int h, uint32_t* __restrict__ counters /* [16 count | 16 cursor] */,
+                                                              uint32_t nblocks) {
+    __shared__ uint32_t s_cnt[16];
+    if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (256u * BIP_ORDER_ITEMS);
+#pragma unroll 4
+    for (int k = 0; k < BIP_ORDER_ITEMS; k++) {
+        const uint32_t i = base + k * 256u + threadIdx.x;
+        if (i < nblocks) { int pa; atomicAdd(&s_cnt[bip_kind_of(blks[i], w, h, pa)], 1u); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && s_cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], s_cnt[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void bip_order_scatter_kernel(const BipBlk* __restrict__ blks, int w, int h, uint32_t* __restrict__ counters,
+                                                                uint32_t* __restrict__ order, uint32_t nblocks) {
+    __shared__ uint32_t s_cnt[16], s_base[16];
+    if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (256u * BIP_ORDER_ITEMS);
+    uint8_t kind[BIP_ORDER_ITEMS];
+    uint16_t local[BIP_ORDER_ITEMS];
+#pragma unroll
+    for (int k = 0; k < BIP_ORDER_ITEMS; k++) {
+        const uint32_t i = base + k * 256u + threadIdx.x;
+        kind[k] = 0; local[k] = 0;
+        if (i < nblocks) { int pa; kind[k] = (uint8_t)bip_kind_of(blks[i], w, h, pa); local[k] = (uint16_t)atomicAdd(&s_cnt[kind[k]], 1u); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && s_cnt[threadIdx.x]) {
+        uint32_t start = 0;                                   // bin start = sum of the counts of the bins before it
+        for (int k = 0; k < (int)threadIdx.x; k++) start += counters[k];
+        s_base[threadIdx.x] = start + atomicAdd(&counters[16 + threadIdx.x], s_cnt[threadIdx.x]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BIP_ORDER_ITEMS; k++) {
+        const uint32_t i = base + k * 256u + threadIdx.x;
+        if (i < nblocks) order[s_base[kind[k]] + local[k]] = i;
+    }
+}
+
+template <typename PixT, int W, int H>
 __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
     PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
     const PixT* __restrict__ top_all, const PixT* __restrict__ left_all, int32_t neigh_pitch, const BipBlk* __restrict__ blks,
-    int w, int h, int bd, uint32_t nblocks) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t s_edge[];          // [BIP_WAVES * blocks per wave][2][bip_edge_len]
-    const int LPB = bip_lanes_per_block(w, h), lsh = __builtin_ctz((uint32_t)LPB), bpw = 64 >> lsh, EL = bip_edge_len(w, h);
+    const uint32_t* __restrict__ order, int bd, uint32_t nblocks) {
+    constexpr int w = W, h = H;
+    constexpr int LPB = bip_lanes_per_block(W, H), bpw = 64 / LPB, EL = bip_edge_len(W, H);
+    constexpr int lsh = LPB == 4 ? 2 : (LPB == 8 ? 3 : (LPB == 16 ? 4 : (LPB == 32 ? 5 : 6)));
+    __shared__ __attribute__((aligned(16))) uint16_t s_edge[BIP_WAVES * bpw * 2 * EL];          // [wave][block of the wave][above | left][EL]
     const int wv = threadIdx.x >> 6, sub = (threadIdx.x & 63) >> lsh;
     const int lane = threadIdx.x & (LPB - 1);                 // lane inside the block's group
     const uint32_t blk_id = (blockIdx.x * BIP_WAVES + (uint32_t)wv) * (uint32_t)bpw + (uint32_t)sub;
     const bool live = blk_id < nblocks;
-    const uint32_t b = live ? blk_id : 0u;                    // a spare group replays block 0 without storing
+    const uint32_t b = live ? (order ? order[blk_id] : blk_id) : (order ? order[0] : 0u);      // a spare group replays a block without storing
     const BipBlk d = blks[b];
     const PixT* __restrict__ top = top_all + (size_t)b * neigh_pitch + 1;       // element 0 is the corner: top[-1]
     const PixT* __restrict__ left = left_all + (size_t)b * neigh_pitch + 1;
@@ -134,14 +216,17 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
     wave_lds_fence();
     const bool filt = is_dr && !d.disable_edge_filter && !const_fill;
     const bool angled = filt && p_angle != 90 && p_angle != 180;
+    const bool wave_angled = __builtin_amdgcn_ballot_w64(angled) != 0;      // stages 2 - 4 are skipped by a wave none of whose blocks needs them
     // ---- stage 2: corner filter (filter_intra_edge_corner, :3383) ----------------------------------------------------
+    if (wave_angled) {
     if (angled && need_above && need_left && w + h >= 24 && lane == 0) {
         const int s = ((int)L[0] * 5 + (int)A[-1] * 6 + (int)A[0] * 5 + 8) >> 4;
         A[-1] = (uint16_t)s; L[-1] = (uint16_t)s;
     }
     wave_lds_fence();
+    }
     // ---- stage 3: edge smoothing (av1_filter_intra_edge, :3539): sample 0 of the run is kept ---------------------------
-    {
+    if (wave_angled) {
         const int ab_le = need_above_left ? 1 : 0;
         const int sa = (angled && need_above && n_top > 0) ? bip_filter_strength(w, h, p_angle - 90, ft) : 0;
         const int sl = (angled && need_left && n_left > 0) ? bip_filter_strength(h, w, p_angle - 180, ft) : 0;
@@ -170,7 +255,7 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
     // ---- stage 4: 2x up-sampling (av1_upsample_intra_edge, :3597): p[-2 .. 2 sz - 2] from p[-1 .. sz - 1] ---------------
     const int up_a = (filt && need_above) ? bip_use_upsample(w, h, p_angle - 90, ft) : 0;
     const int up_l = (filt && need_left) ? bip_use_upsample(h, w, p_angle - 180, ft) : 0;
-    {
+    if (w + h <= 16 && __builtin_amdgcn_ballot_w64((up_a | up_l) != 0) != 0) {
         const int sza = w + (need_right ? h : 0), szl = h + (need_bottom ? w : 0);                 // <= 16 when up-sampling
         int ia[2][4], il[2][4];                                 // two rounds of LPB lanes: sz <= 16 <= 2 * LPB wherever the edge is up-sampled
         auto in_at = [](const uint16_t* p, int k, int sz) { return (int)p[k < 2 ? -1 : (k < sz + 2 ? k - 2 : sz - 1)]; };
@@ -198,8 +283,8 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
                 L[2 * i] = (uint16_t)il[t][2];
             }
         }
-    }
     wave_lds_fence();
+    }
     // ---- stage 5: prediction ---------------------------------------------------------------------------------------------
     // resolve to one of the predictor kinds
     int kind, dx = 1, dy = 1;
@@ -222,27 +307,45 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
     }
     const size_t boff = dst_offsets ? (size_t)dst_offsets[b] : (size_t)b * dst_block_pitch;
     PixT* __restrict__ out = dst + boff;
-    const int wq = w >> 2, items = wq * h;
-    const int wq_shift = __builtin_ctz((uint32_t)wq);
+    // A lane writes PPL = min(W, 16) samples of one row per step: one address, one 4 .. 32-byte store (16 bytes per lane is the store
+    // shape the HBM likes) and a quarter of the loop overhead of the first version's 4 samples per step.
+    constexpr int PPL = W >= 16 ? 16 : W, CPR = W / PPL, items = CPR * H;
     const int bl_s = (int)L[h - 1], tr_s = (int)A[w - 1], tl_s = (int)A[-1];
-    for (int q = lane; q < items; q += LPB) {
-        const int r = q >> wq_shift, c0 = (q & (wq - 1)) << 2;
-        int px[4];
+    // KC::value >= 0: every block of the wave has this kind - the switch below is resolved at compile time; -1: mixed wave
+    auto predict = [&](auto KC) {
+    constexpr int KU = decltype(KC)::value;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+    for (int q0 = 0; q0 < items; q0 += LPB) {
+        const int q = q0 + lane;
+        if (items % LPB != 0 && q >= items) break;
+        const int r = q / CPR, c0 = (q % CPR) * PPL;
+        const int kk = KU >= 0 ? KU : kind;
+        // the row's samples of the above edge as 16-bit pairs (aligned: c0 is a multiple of PPL, the edge arrays start 16-byte aligned)
+        uint32_t aw[PPL / 2];
+        if (KU < 0 || KU == IM_V || KU == IM_SMOOTH || KU == IM_SMOOTH_V || KU == IM_PAETH) {
+            const uint32_t* ap = reinterpret_cast<const uint32_t*>(A + c0);
+#pragma unroll
+            for (int k = 0; k < PPL / 2; k++) aw[k] = ap[k];
+        }
+        const int lr = (int)L[r < H ? r : 0];
+        const int whr = kSmWeights[h + r];
+        int px[PPL];
+#pragma unroll
+        for (int k = 0; k < PPL; k++) {
             const int c = c0 + k;
+            const int ac = (int)((aw[k >> 1] >> (16 * (k & 1))) & 0xffffu);
             int v;
-            switch (kind) {
-            case IM_V: v = A[c]; break;
-            case IM_H: v = L[r]; break;
+            switch (kk) {
+            case IM_V: v = ac; break;
+            case IM_H: v = lr; break;
             case IM_SMOOTH: {
-                const int wh = kSmWeights[h + r], ww = kSmWeights[w + c];
-                v = (wh * (int)A[c] + (256 - wh) * bl_s + ww * (int)L[r] + (256 - ww) * tr_s + 256) >> 9;
+                const int ww = kSmWeights[w + c];
+                v = (whr * ac + (256 - whr) * bl_s + ww * lr + (256 - ww) * tr_s + 256) >> 9;
             } break;
-            case IM_SMOOTH_V: { const int wh = kSmWeights[h + r]; v = (wh * (int)A[c] + (256 - wh) * bl_s + 128) >> 8; } break;
-            case IM_SMOOTH_H: { const int ww = kSmWeights[w + c]; v = (ww * (int)L[r] + (256 - ww) * tr_s + 128) >> 8; } break;
+            case IM_SMOOTH_V: v = (whr * ac + (256 - whr) * bl_s + 128) >> 8; break;
+            case IM_SMOOTH_H: { const int ww = kSmWeights[w + c]; v = (ww * lr + (256 - ww) * tr_s + 128) >> 8; } break;
             case IM_PAETH: {
-                const int t = A[c], l = L[r], pb = t + l - tl_s;
+                const int t = ac, l = lr, pb = t + l - tl_s;
                 const int pl = abs(pb - l), pt = abs(pb - t), ptl = abs(pb - tl_s);
                 v = (pl <= pt && pl <= ptl) ? l : (pt <= ptl ? t : tl_s);
             } break;
@@ -275,14 +378,42 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
         }
         if (live) {
             PixT* o = out + (size_t)r * dst_stride + c0;
-            if ((reinterpret_cast<uintptr_t>(o) & (4 * sizeof(PixT) - 1)) == 0) {
-                if (sizeof(PixT) == 1) *reinterpret_cast<uint32_t*>(o) = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)px[3] << 24);
-                else *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)px[0] | ((uint32_t)px[1] << 16), (uint32_t)px[2] | ((uint32_t)px[3] << 16));
+            constexpr int NB = PPL * (int)sizeof(PixT);          // 4 .. 32 bytes
+            uint32_t pw[NB / 4];
+#pragma unroll
+            for (int k = 0; k < NB / 4; k++) {
+                if (sizeof(PixT) == 1) pw[k] = (uint32_t)px[4 * k] | ((uint32_t)px[4 * k + 1] << 8) | ((uint32_t)px[4 * k + 2] << 16) | ((uint32_t)px[4 * k + 3] << 24);
+                else pw[k] = (uint32_t)px[2 * k] | ((uint32_t)px[2 * k + 1] << 16);
+            }
+            constexpr int AL = NB >= 16 ? 16 : NB;               // widest store unit
+            if ((reinterpret_cast<uintptr_t>(o) & (AL - 1)) == 0) {
+                if constexpr (NB == 4) *reinterpret_cast<uint32_t*>(o) = pw[0];
+                else if constexpr (NB == 8) *reinterpret_cast<uint2*>(o) = make_uint2(pw[0], pw[1]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < NB / 16; k++) reinterpret_cast<uint4*>(o)[k] = make_uint4(pw[4 * k], pw[4 * k + 1], pw[4 * k + 2], pw[4 * k + 3]);
+                }
+            } else if ((reinterpret_cast<uintptr_t>(o) & 3) == 0) {
+#pragma unroll
+                for (int k = 0; k < NB / 4; k++) reinterpret_cast<uint32_t*>(o)[k] = pw[k];
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; k++) o[k] = (PixT)px[k];
+                for (int k = 0; k < PPL; k++) o[k] = (PixT)px[k];
             }
         }
+    }
+    };
+    const int kind0 = __builtin_amdgcn_readfirstlane(kind);
+    if (__builtin_amdgcn_ballot_w64(kind != kind0) == 0) {
+        switch (kind0) {
+#define BIP_CASE(K) case K: predict(std::integral_constant<int, K>{}); break;
+        BIP_CASE(IM_DC) BIP_CASE(IM_V) BIP_CASE(IM_H) BIP_CASE(IM_SMOOTH) BIP_CASE(IM_SMOOTH_V) BIP_CASE(IM_SMOOTH_H) BIP_CASE(IM_PAETH)
+        BIP_CASE(IM_DC_TOP) BIP_CASE(IM_DC_LEFT) BIP_CASE(IM_DC_128) BIP_CASE(IM_Z1) BIP_CASE(IM_Z2)
+#undef BIP_CASE
+        default: predict(std::integral_constant<int, IM_Z3>{}); break;
+        }
+    } else {
+        predict(std::integral_constant<int, -1>{});
     }
 }
 

@@ -269,11 +269,21 @@ extern "C" int svt_hip_upsample_intra_edge_batch(void* d_edges, int32_t nb_pitch
 // (A) drop-in entry points: host pointers, one block, synchronous
 // ---- build_intra_predictors{,_high} for a batch (EbIntraPrediction.c:3667-4076), see kernel_bip.h ----
 static_assert(sizeof(svt_hip_intra_blk) == sizeof(BipBlk), "svt_hip_intra_blk layout");
-extern "C" int svt_hip_build_intra_predictors_batch(void* d_dst, int32_t dst_stride, size_t dst_block_pitch,
-                                                    const uint32_t* d_dst_offsets, const void* d_top_neigh,
-                                                    const void* d_left_neigh, int32_t neigh_pitch,
-                                                    const svt_hip_intra_blk* d_blocks, int tx_size, int is_16bit, int bd,
-                                                    size_t nblocks, void* stream) {
+template <int W, int H>
+static int bip_launch(void* d_dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* d_dst_offsets, const void* d_top_neigh,
+                      const void* d_left_neigh, int32_t neigh_pitch, const svt_hip_intra_blk* d_blocks, const uint32_t* d_order, int is_16bit,
+                      int bd, size_t nblocks, uint32_t grid, hipStream_t s) {
+    if (is_16bit)
+        hipLaunchKernelGGL((bip_kernel<uint16_t, W, H>), dim3(grid), dim3(64 * BIP_WAVES), 0, s, (uint16_t*)d_dst, dst_stride, dst_block_pitch, d_dst_offsets,
+                           (const uint16_t*)d_top_neigh, (const uint16_t*)d_left_neigh, neigh_pitch, (const BipBlk*)d_blocks, d_order, bd, (uint32_t)nblocks);
+    else
+        hipLaunchKernelGGL((bip_kernel<uint8_t, W, H>), dim3(grid), dim3(64 * BIP_WAVES), 0, s, (uint8_t*)d_dst, dst_stride, dst_block_pitch, d_dst_offsets,
+                           (const uint8_t*)d_top_neigh, (const uint8_t*)d_left_neigh, neigh_pitch, (const BipBlk*)d_blocks, d_order, bd, (uint32_t)nblocks);
+    return launch_status("build_intra_predictors");
+}
+static int bip_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* d_dst_offsets, const void* d_top_neigh,
+                    const void* d_left_neigh, int32_t neigh_pitch, const svt_hip_intra_blk* d_blocks, const uint32_t* d_order, int tx_size,
+                    int is_16bit, int bd, size_t nblocks, void* stream) {
     if (int rc = require_init()) return rc;
     if (nblocks == 0) return SVT_HIP_OK;
     if (!d_dst || !d_top_neigh || !d_left_neigh || !d_blocks) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
@@ -286,17 +296,43 @@ extern "C" int svt_hip_build_intra_predictors_batch(void* d_dst, int32_t dst_str
     const size_t per_wg = (size_t)BIP_WAVES * (64 / bip_lanes_per_block(w, h));       // blocks per workgroup
     const size_t grid = (nblocks + per_wg - 1) / per_wg;
     if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks for one launch");
-    const size_t lds = per_wg * 2 * (size_t)bip_edge_len(w, h) * sizeof(uint16_t);
     hipStream_t s = (hipStream_t)stream;
-    if (is_16bit)
-        hipLaunchKernelGGL(bip_kernel<uint16_t>, dim3((uint32_t)grid), dim3(64 * BIP_WAVES), lds, s, (uint16_t*)d_dst, dst_stride, dst_block_pitch,
-                           d_dst_offsets, (const uint16_t*)d_top_neigh, (const uint16_t*)d_left_neigh, neigh_pitch, (const BipBlk*)d_blocks, w, h,
-                           bd, (uint32_t)nblocks);
-    else
-        hipLaunchKernelGGL(bip_kernel<uint8_t>, dim3((uint32_t)grid), dim3(64 * BIP_WAVES), lds, s, (uint8_t*)d_dst, dst_stride, dst_block_pitch,
-                           d_dst_offsets, (const uint8_t*)d_top_neigh, (const uint8_t*)d_left_neigh, neigh_pitch, (const BipBlk*)d_blocks, w, h,
-                           bd, (uint32_t)nblocks);
-    return launch_status("build_intra_predictors");
+#define BIP_LAUNCH(W, H) bip_launch<W, H>(d_dst, dst_stride, dst_block_pitch, d_dst_offsets, d_top_neigh, d_left_neigh, neigh_pitch, d_blocks, d_order, is_16bit, bd, \
+                                          nblocks, (uint32_t)grid, s)
+    TX_SWITCH(tx_size, BIP_LAUNCH)
+#undef BIP_LAUNCH
+}
+extern "C" int svt_hip_build_intra_predictors_batch(void* d_dst, int32_t dst_stride, size_t dst_block_pitch,
+                                                    const uint32_t* d_dst_offsets, const void* d_top_neigh,
+                                                    const void* d_left_neigh, int32_t neigh_pitch,
+                                                    const svt_hip_intra_blk* d_blocks, int tx_size, int is_16bit, int bd,
+                                                    size_t nblocks, void* stream) {
+    return bip_impl(d_dst, dst_stride, dst_block_pitch, d_dst_offsets, d_top_neigh, d_left_neigh, neigh_pitch, d_blocks, nullptr, tx_size, is_16bit, bd,
+                    nblocks, stream);
+}
+extern "C" int svt_hip_build_intra_predictors_ordered_batch(void* d_dst, int32_t dst_stride, size_t dst_block_pitch,
+                                                            const uint32_t* d_dst_offsets, const void* d_top_neigh,
+                                                            const void* d_left_neigh, int32_t neigh_pitch,
+                                                            const svt_hip_intra_blk* d_blocks, const uint32_t* d_order, int tx_size,
+                                                            int is_16bit, int bd, size_t nblocks, void* stream) {
+    if (nblocks && !d_order) { if (int rc = require_init()) return rc; return set_err(SVT_HIP_ERR_INVALID, "NULL order"); }
+    return bip_impl(d_dst, dst_stride, dst_block_pitch, d_dst_offsets, d_top_neigh, d_left_neigh, neigh_pitch, d_blocks, d_order, tx_size, is_16bit, bd,
+                    nblocks, stream);
+}
+extern "C" int svt_hip_intra_order_blocks_batch(const svt_hip_intra_blk* d_blocks, int tx_size, size_t nblocks, uint32_t* d_order,
+                                                uint32_t* d_work, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (nblocks == 0) return SVT_HIP_OK;
+    if (!d_blocks || !d_order || !d_work) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    if (tx_size < 0 || tx_size >= SVT_TX_SIZES_ALL) return set_err(SVT_HIP_ERR_INVALID, "tx_size %d", tx_size);
+    if (nblocks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(d_work, 0, 32 * sizeof(uint32_t), s));
+    const dim3 grid((uint32_t)((nblocks + 256 * BIP_ORDER_ITEMS - 1) / (256 * BIP_ORDER_ITEMS)));
+    hipLaunchKernelGGL(bip_order_count_kernel, grid, dim3(256), 0, s, (const BipBlk*)d_blocks, kTxW[tx_size], kTxH[tx_size], d_work, (uint32_t)nblocks);
+    hipLaunchKernelGGL(bip_order_scatter_kernel, grid, dim3(256), 0, s, (const BipBlk*)d_blocks, kTxW[tx_size], kTxH[tx_size], d_work, d_order,
+                       (uint32_t)nblocks);
+    return launch_status("intra_order_blocks");
 }
 
 // ---- open-loop intra search ----

@@ -272,6 +272,18 @@ extern "C" int svt_hip_sad_search_planes_batch(const uint8_t* d_src_plane, uint3
                            width, height, search_area_width, search_area_height, d_best_sad, d_x, d_y, nblocks, stream);
 }
 
+// Row pitch of the reference window the motion-search kernels stage in LDS: whole 16-byte chunks + one chunk of slack for the
+// sliding reads, and == 64 (mod 128) so that the lanes of consecutive SEARCH ROWS fall on different halves of the 32 banks.  A
+// wave's b128 reads are served eight lanes at a time - four 16-point groups of one search row and four of the next - and with
+// the first pitch (144 B for a 64-wide area, == 16 mod 128) the second row's lanes landed on the first row's banks: 31 % of the
+// kernel's LDS cycles were bank conflicts (profiles/r03_a_pmc_me_sb.json); the 4-points-per-lane kernel's dword reads (16 lanes
+// per search row) collide the same way.
+static uint32_t me_window_pitch(uint32_t win_w) {
+    uint32_t p = ((win_w + 15) & ~15u) + 16;
+    while ((p & 127) != 64) p += 16;
+    return p;
+}
+
 static int me_sb_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t src_block_pitch, const uint32_t* d_src_offs,
                              const uint8_t* d_ref, uint32_t ref_stride, size_t ref_block_pitch, const uint32_t* d_ref_offs,
                              int search_w, int search_h, const int16_t* d_origins, int x_origin,
@@ -283,7 +295,7 @@ static int me_sb_search_impl(const uint8_t* d_src, uint32_t src_stride, size_t s
     if (search_w <= 0 || search_h <= 0 || search_w * search_h > 4096)
         return set_err(SVT_HIP_ERR_INVALID, "search area %dx%d (1..4096 points)", search_w, search_h);
     const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
-    const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+    const uint32_t wpitch = me_window_pitch(win_w);
     const size_t lds = 32 * 64 + (size_t)wpitch * win_h;
     if (lds > 60 * 1024) return set_err(SVT_HIP_ERR_INVALID, "search window needs %zu B of LDS (> 60 KiB)", lds);
     // 16 points per lane; widths that are not a multiple of 16 mask the tail of each row
@@ -380,7 +392,7 @@ extern "C" int svt_hip_me_fullpel_search_batch(const uint8_t* d_src, uint32_t sr
     if (!nsq && !g_tune_me_exact) {
         // square PUs: the 16-points-per-lane kernel, any width; the AVX2 flavour only re-labels the 32x32 keys
         const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
-        const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+        const uint32_t wpitch = me_window_pitch(win_w);
         const size_t lds = 32 * 64 + (size_t)wpitch * win_h;
         if (lds <= 60 * 1024) {
             const int w8q = flavour == SVT_HIP_FLAVOUR_AVX2 ? (search_w & ~7) : 0;
@@ -401,7 +413,7 @@ extern "C" int svt_hip_me_fullpel_search_batch(const uint8_t* d_src, uint32_t sr
         // all 209 PUs, widths where every point takes the reference's eight-point form: 4 points per lane, every shape folded
         // out of the packed 8x8 SADs (me_nsq4_kernel); other widths keep the exact kernel (single-point quirks)
         const uint32_t win_w = 64 + search_w - 1, win_h = 64 + search_h - 1;
-        const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+        const uint32_t wpitch = me_window_pitch(win_w);
         const size_t lds = 32 * 64 + (size_t)wpitch * win_h;
         if (lds <= 58 * 1024) {
             hipLaunchKernelGGL(me_nsq4_kernel, dim3((uint32_t)nblocks), dim3(ME_THREADS), lds, (hipStream_t)stream, d_src, src_stride,
@@ -456,7 +468,7 @@ extern "C" int svt_hip_me_fullpel_search_areas_batch(const uint8_t* d_src, uint3
         return set_err(SVT_HIP_ERR_INVALID, "search area bound %dx%d (1..4096 points)", max_search_w, max_search_h);
     if (nblocks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks");
     const uint32_t win_w = 64 + max_search_w - 1, win_h = 64 + max_search_h - 1;
-    const uint32_t wpitch = ((win_w + 15) & ~15u) + 16;
+    const uint32_t wpitch = me_window_pitch(win_w);
     size_t lds = 32 * 64 + (size_t)wpitch * win_h;
     uint32_t pair_off = 0;
     if (nsq) {                                            // (64x32_1, 32x16_5) pairs of the narrow single-point areas: <= 7 x max_h points

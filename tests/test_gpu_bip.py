@@ -126,3 +126,43 @@ def test_build_intra_predictors_argument_errors(dsp, pkg):
         dsp.build_intra_predictors(t[:, :100], t[:, :100], b, 4)          # 64x64 needs 129 samples per edge
     with pytest.raises(pkg.SvtHipError):
         dsp.build_intra_predictors(t, t, b, 0, bd=10)                      # 8-bit samples with bd 10
+
+
+@pytest.mark.parametrize("is16", [0, 1])
+def test_ordered_batch_equals_plain_batch_and_order_is_sorted_by_kind(dsp, is16):
+    """svt_hip_intra_order_blocks_batch: a permutation of the batch's block indices, grouped by predictor kind (so that a wave runs one
+    kind's code); svt_hip_build_intra_predictors_ordered_batch through it writes exactly what the plain call writes (every size)"""
+    rng = np.random.default_rng(91 + is16)
+    bd = 10 if is16 else 8
+    dt = np.uint16 if is16 else np.uint8
+    for tx in range(19):
+        w, h = TX_W[tx], TX_H[tx]
+        n = 3001
+        tops = rng.integers(0, 1 << bd, (n, 16 + 160)).astype(dt); lefts = rng.integers(0, 1 << bd, (n, 16 + 160)).astype(dt)
+        blks = np.zeros((n, 8), np.uint8)
+        blks[:, 0] = rng.integers(0, 13, n)
+        blks[:, 1] = (rng.integers(-3, 4, n) * ((blks[:, 0] >= 1) & (blks[:, 0] <= 8))).astype(np.int8).view(np.uint8)
+        blks[:, 2] = rng.integers(0, 2, n); blks[:, 3] = rng.integers(0, 5, n) == 0
+        blks[:, 4] = rng.choice([0, w], n); blks[:, 6] = rng.choice([0, h], n)
+        blks[:, 5] = np.where(blks[:, 4] == w, rng.choice([0, h], n), 0); blks[:, 7] = np.where(blks[:, 6] == h, rng.choice([0, w], n), 0)
+        d_blks = dev(blks)
+        T, L = neigh_rows(list(tops), is16), neigh_rows(list(lefts), is16)
+        plain = dsp.build_intra_predictors(T, L, d_blks, tx, bd=bd)
+        order = dsp.intra_order_blocks(d_blks, tx)
+        o = order.cpu().numpy()
+        assert sorted(o.tolist()) == list(range(n))
+        ordered = dsp.build_intra_predictors(T, L, d_blks, tx, bd=bd, order=order)
+        assert torch.equal(plain, ordered), tx
+        # grouped: the (coarse) kind of the blocks along the order changes at most 12 times
+        def kind(b):
+            m, ad, nt, nl = int(b[0]), int(np.int8(b[1])), int(b[4]), int(b[6])
+            if 1 <= m <= 8:
+                a = [0, 90, 180, 45, 135, 113, 157, 203, 67][m] + 3 * ad
+                if (a >= 180 and nl == 0) or (a <= 90 and nt == 0):
+                    return "c"
+                return "v" if a == 90 else ("h" if a == 180 else ("z1" if a < 90 else ("z2" if a < 180 else "z3")))
+            if m == 0:
+                return ("dc" if nt else "dl") if nl else ("dt" if nt else "c")
+            return "m%d" % m
+        ks = [kind(blks[i]) for i in o]
+        assert sum(1 for a, b in zip(ks, ks[1:]) if a != b) <= 12, tx

@@ -94,6 +94,20 @@ def workload(name, d):
         blk[:, 1] = ((torch.arange(n, device=dev) // 13) % 7 - 3).to(torch.int8).view(torch.uint8) * ((blk[:, 0] >= 1) & (blk[:, 0] <= 8)).to(torch.uint8)
         blk[:, 4] = 16; blk[:, 5] = 16; blk[:, 6] = 16; blk[:, 7] = 16
         out = torch.empty((n, 16, 16), dtype=torch.uint8, device=dev)
+        if hasattr(d.lib, "svt_hip_intra_order_blocks_batch"):          # this round: order the batch by predictor kind first (both timed)
+            def run():
+                order = d.intra_order_blocks(blk, 2)
+                return d.build_intra_predictors(top, left, blk, 2, dst=out, dst_stride=16, order=order)
+            return run, n, 330
+        return (lambda: d.build_intra_predictors(top, left, blk, 2, dst=out, dst_stride=16)), n, 330
+    if name == "bip_plain":
+        n = 1 << 20
+        top = torch.randint(0, 256, (n, 48), dtype=torch.uint8, device=dev, generator=g); left = torch.randint(0, 256, (n, 48), dtype=torch.uint8, device=dev, generator=g)
+        blk = torch.zeros((n, 8), dtype=torch.uint8, device=dev)
+        blk[:, 0] = torch.arange(n, device=dev) % 13
+        blk[:, 1] = ((torch.arange(n, device=dev) // 13) % 7 - 3).to(torch.int8).view(torch.uint8) * ((blk[:, 0] >= 1) & (blk[:, 0] <= 8)).to(torch.uint8)
+        blk[:, 4] = 16; blk[:, 5] = 16; blk[:, 6] = 16; blk[:, 7] = 16
+        out = torch.empty((n, 16, 16), dtype=torch.uint8, device=dev)
         return (lambda: d.build_intra_predictors(top, left, blk, 2, dst=out, dst_stride=16)), n, 330
     if name in ("me85", "me209"):
         n = 2040

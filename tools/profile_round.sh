@@ -7,12 +7,12 @@ out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 400 python3 bench.py > $out/bench.log 2>&1 && tail -1 $out/bench.log > $out/bench.json || { echo "bench failed"; exit 1; }
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/stats -o stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $out/stats.log 2>&1 || echo "stats pass failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/stats -o stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-probes > $out/stats.log 2>&1 || echo "stats pass failed"
 f=$(find $out/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats.csv
 i=0
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass -d $out/pmc_$i -o pmc --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/pmc_$i.log 2>&1 || echo "pmc pass $i failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass -d $out/pmc_$i -o pmc --output-format csv -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-probes > $out/pmc_$i.log 2>&1 || echo "pmc pass $i failed"
   f=$(find $out/pmc_$i -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $out/pmc_$(echo $pass | cut -d" " -f1).csv
 done
 python3 - "$tag" <<'PY'
@@ -26,7 +26,7 @@ for f in glob.glob(f"{out}/pmc_*.csv"):
 mean = {k: sum(v) / len(v) for k, v in agg.items()}
 blocks = 1 << 20
 res = {"round": int(tag[1:3]) if tag[:1] == "r" and tag[1:3].isdigit() else None, "tag": tag, "kernel": "fwd32_kernel<true,true,true,1,false,2> (headline fused chain)", "blocks": blocks,
-       "command": "rocprofv3 --kernel-trace --pmc <C> -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline (one pass per counter group)"}
+       "command": "rocprofv3 --kernel-trace --pmc <C> -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-probes (one pass per counter group)"}
 if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
     rd = 2 * mean["FETCH_SIZE"] * 1024; wr = mean["WRITE_SIZE"] * 1024
     res.update({"FETCH_SIZE_KB_per_launch": mean["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": mean["WRITE_SIZE"],
