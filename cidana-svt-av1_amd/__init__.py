@@ -108,6 +108,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
                                            c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]
     L.svt_hip_txb_init_levels_batch.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_uint32, c_uint32, c_size_t, c_void_p]
     L.svt_hip_encode_recon_frame.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.svt_hip_encode_recon_frame_ex.argtypes = [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     L.svt_hip_sad_planes_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_uint32, c_void_p,
                                            c_size_t, c_void_p]
     L.svt_hip_sad_x4d_batch.argtypes = [c_void_p, c_uint32, c_size_t, c_void_p, c_void_p, c_uint32, c_void_p, c_uint32, c_uint32,
@@ -643,6 +644,40 @@ class SvtHipDsp:
         self._check(self.lib.svt_hip_encode_recon_frame(group_array, len(group_array), 1 if is_16bit else 0, bd, tabs[0].ctypes.data,
                                                         tabs[1].ctypes.data, tabs[2].ctypes.data, tabs[3].ctypes.data, tabs[4].ctypes.data,
                                                         self._stream()), "svt_hip_encode_recon_frame")
+
+    class FrameCflGroup(ctypes.Structure):
+        _fields_ = [("d_luma_recon", c_void_p), ("luma_stride", c_uint32), ("d_pred_cb", c_void_p), ("pred_stride_cb", c_uint32),
+                    ("d_pred_cr", c_void_p), ("pred_stride_cr", c_uint32), ("d_xy", c_void_p), ("d_alpha_q3_cb", c_void_p),
+                    ("d_alpha_q3_cr", c_void_p), ("width", c_uint32), ("height", c_uint32), ("nblocks", c_uint32)]
+
+    class FrameLevels(ctypes.Structure):
+        _fields_ = [("d_levels_buf", c_void_p), ("levels_block_pitch", ctypes.c_size_t)]
+
+    def make_frame_cfl_groups(self, groups):
+        """groups: list of dicts with tensors luma_recon, pred_cb, pred_cr (planes), xy, alpha_cb, alpha_cr (int32 per block), the
+        strides luma_stride / cb_stride / cr_stride and the chroma block's width, height"""
+        arr = (self.FrameCflGroup * max(len(groups), 1))()
+        for i, g in enumerate(groups):
+            arr[i] = self.FrameCflGroup(self._p(g["luma_recon"]), g["luma_stride"], self._p(g["pred_cb"]), g["cb_stride"], self._p(g["pred_cr"]),
+                                        g["cr_stride"], self._p(g["xy"]), self._p(g["alpha_cb"]), self._p(g["alpha_cr"]), g["width"], g["height"],
+                                        g["xy"].numel())
+        return arr
+
+    def make_frame_levels(self, level_bufs):
+        """level_bufs: one uint8 [nblocks, pitch] tensor (or None) per group of the call"""
+        arr = (self.FrameLevels * max(len(level_bufs), 1))()
+        for i, b in enumerate(level_bufs):
+            arr[i] = self.FrameLevels(self._p(b) if b is not None else None, b.shape[1] if b is not None else 0)
+        return arr
+
+    def encode_recon_frame_ex(self, group_array, qrow, first_chroma_group=0, cfl_array=None, ncfl=0, levels_array=None, is_16bit=False, bd=8):
+        """svt_hip_encode_recon_frame_ex: groups [0, first_chroma_group) -> chroma-from-luma prediction of the cfl groups -> the other
+        groups -> av1_txb_init_levels of every group with a level buffer, all enqueued on the current stream"""
+        tabs = [_np16(qrow[k]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
+        self._check(self.lib.svt_hip_encode_recon_frame_ex(group_array, len(group_array), first_chroma_group, cfl_array, ncfl, levels_array,
+                                                           1 if is_16bit else 0, bd, tabs[0].ctypes.data, tabs[1].ctypes.data,
+                                                           tabs[2].ctypes.data, tabs[3].ctypes.data, tabs[4].ctypes.data, self._stream()),
+                    "svt_hip_encode_recon_frame_ex")
 
     # -- hierarchical ME: one level for all SBs, clipping on the device ----------------------------
     class HmeParams(ctypes.Structure):

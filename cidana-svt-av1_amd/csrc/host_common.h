@@ -63,6 +63,7 @@ int launch_enc_frame_one(const svtdev::FrameDesc* fd, uint32_t total_wgs, int is
 extern const int kTxW[SVT_TX_SIZES_ALL];
 extern const int kTxH[SVT_TX_SIZES_ALL];
 bool txfm_allowed(int tx_size, int tx_type);
+int frame_groups_check(const svt_hip_frame_group* groups, int ngroups);      // svt_hip_txfm.hip
 
 #define TX_SWITCH(tx_size, CALL)                                                                  \
     switch (tx_size) {                                                                            \

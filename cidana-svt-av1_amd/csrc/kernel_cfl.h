@@ -167,18 +167,9 @@ __global__ __launch_bounds__(256) void cfl_predict_kernel(const int16_t* __restr
 // dword of the buffer (W + 4 is a multiple of 4, so a dword never straddles a row) from one 16-byte load.
 // ---------------------------------------------------------------------------
 template <bool WIDE>
-__global__ __launch_bounds__(256) void txb_init_levels_kernel(const int32_t* __restrict__ coeff, size_t coeff_block_pitch,
-                                                              uint8_t* __restrict__ levels_buf, size_t levels_block_pitch,
-                                                              uint32_t w, uint32_t h, uint32_t lpb, uint32_t ndw, uint32_t row_magic,
-                                                              uint32_t nblocks) {
-    const uint32_t lsh = __builtin_ctz(lpb);
-    const uint32_t slots = 256u >> lsh;
-    const uint32_t blk = blockIdx.x * slots + (threadIdx.x >> lsh);
-    if (blk >= nblocks) return;
-    const uint32_t l = threadIdx.x & (lpb - 1);
+__device__ __forceinline__ void txb_levels_body(const int32_t* __restrict__ cb, uint32_t* __restrict__ ob, uint32_t w, uint32_t h, uint32_t l,
+                                                uint32_t lpb, uint32_t ndw, uint32_t row_magic) {
     const uint32_t dpr = (w + 4) >> 2;                       // dwords per row
-    const int32_t* cb = coeff + (size_t)blk * coeff_block_pitch;
-    uint32_t* ob = reinterpret_cast<uint32_t*>(levels_buf + (size_t)blk * levels_block_pitch);
     auto dword = [&](uint32_t d) -> uint32_t {
         const uint32_t r = __umulhi(d, row_magic), cq = d - r * dpr;          // d / dpr, d % dpr
         uint32_t out = 0;
@@ -209,6 +200,138 @@ __global__ __launch_bounds__(256) void txb_init_levels_kernel(const int32_t* __r
         }
     } else {
         for (uint32_t d = l; d < ndw; d += lpb) ob[d] = dword(d);
+    }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void txb_init_levels_kernel(const int32_t* __restrict__ coeff, size_t coeff_block_pitch,
+                                                              uint8_t* __restrict__ levels_buf, size_t levels_block_pitch,
+                                                              uint32_t w, uint32_t h, uint32_t lpb, uint32_t ndw, uint32_t row_magic,
+                                                              uint32_t nblocks) {
+    const uint32_t lsh = __builtin_ctz(lpb);
+    const uint32_t slots = 256u >> lsh;
+    const uint32_t blk = blockIdx.x * slots + (threadIdx.x >> lsh);
+    if (blk >= nblocks) return;
+    txb_levels_body<WIDE>(coeff + (size_t)blk * coeff_block_pitch, reinterpret_cast<uint32_t*>(levels_buf + (size_t)blk * levels_block_pitch), w, h,
+                          threadIdx.x & (lpb - 1), lpb, ndw, row_magic);
+}
+
+// ---------------------------------------------------------------------------
+// The two pieces of the encode pass that sit beside the transform chain, at picture scale (svt_hip_encode_recon_frame_ex):
+// one launch covers every group of a call, the group table rides in the kernel arguments (as enc_frame_kernel's).
+//
+// levels_frame_kernel  av1_txb_init_levels of every block's quantised coefficients, straight from the dense qcoeff output of the
+//                      encode launch that precedes it in the stream.
+// cfl_frame_kernel     the chroma-from-luma step between a picture's luma and chroma encode passes (Av1EncodeLoop,
+//                      EbCodingLoop.c:736-846): cfl_luma_subsampling_420 of the luma RECONSTRUCTION under the chroma block,
+//                      subtract_average, then cfl_predict on the Cb and the Cr prediction in place.  The Q3 values never leave
+//                      the registers (the reference keeps them in pred_buf_q3 between its four calls).
+// ---------------------------------------------------------------------------
+constexpr int LEVELS_MAX_GROUPS = 48;
+struct LevelsGroupDev {
+    const int32_t* coeff; uint8_t* levels;
+    uint32_t levels_pitch, w, h, lpb, ndw, row_magic, nblocks;
+    uint32_t wg_end;                 // bit 31: 16-byte stores (buffer and pitch 16-byte aligned)
+};
+struct LevelsFrameDesc { int32_t ngroups; LevelsGroupDev g[LEVELS_MAX_GROUPS]; };
+static_assert(sizeof(LevelsFrameDesc) <= 4000, "kernel arguments");
+
+__global__ __launch_bounds__(256) void levels_frame_kernel(const LevelsFrameDesc fd) {
+    int gi = 0;
+    uint32_t start = 0;
+#pragma unroll 1
+    for (int i = 0; i < fd.ngroups; i++) {
+        const uint32_t e = fd.g[i].wg_end & 0x7fffffffu;
+        if (blockIdx.x >= e) { gi = i + 1; start = e; }
+    }
+    if (gi >= fd.ngroups) return;
+    const LevelsGroupDev& G = fd.g[gi];
+    const uint32_t lsh = __builtin_ctz(G.lpb);
+    const uint32_t blk = (blockIdx.x - start) * (256u >> lsh) + (threadIdx.x >> lsh);
+    if (blk >= G.nblocks) return;
+    const int32_t* cb = G.coeff + (size_t)blk * (G.w * G.h);
+    uint32_t* ob = reinterpret_cast<uint32_t*>(G.levels + (size_t)blk * G.levels_pitch);
+    if (G.wg_end >> 31) txb_levels_body<true>(cb, ob, G.w, G.h, threadIdx.x & (G.lpb - 1), G.lpb, G.ndw, G.row_magic);
+    else txb_levels_body<false>(cb, ob, G.w, G.h, threadIdx.x & (G.lpb - 1), G.lpb, G.ndw, G.row_magic);
+}
+
+constexpr int CFL_MAX_GROUPS = 16;      // the chroma transform sizes 4 .. 32 in both dimensions
+struct CflGroupDev {
+    const void* luma; void* cb; void* cr;
+    const uint32_t* xy; const int32_t* alpha_cb; const int32_t* alpha_cr;
+    uint32_t luma_stride, cb_stride, cr_stride, nblocks, w, h, lpb, wg_end;
+    int32_t round_offset, num_pel_log2;
+};
+struct CflFrameDesc { int32_t ngroups; CflGroupDev g[CFL_MAX_GROUPS]; };
+
+template <typename PixT>
+__global__ __launch_bounds__(256) void cfl_frame_kernel(const CflFrameDesc fd, int hi) {
+    int gi = 0;
+    uint32_t start = 0;
+#pragma unroll 1
+    for (int i = 0; i < fd.ngroups; i++) {
+        if (blockIdx.x >= fd.g[i].wg_end) { gi = i + 1; start = fd.g[i].wg_end; }
+    }
+    if (gi >= fd.ngroups) return;
+    const CflGroupDev& G = fd.g[gi];
+    const uint32_t lpb = G.lpb, w = G.w, h = G.h;
+    const uint32_t lsh = __builtin_ctz(lpb);
+    const uint32_t blk = (blockIdx.x - start) * (256u >> lsh) + (threadIdx.x >> lsh), l = threadIdx.x & (lpb - 1);
+    const bool valid = blk < G.nblocks;
+    const uint32_t cs = w < 8 ? 4u : 8u;                    // chroma samples per chunk
+    const uint32_t cpr_sh = w == 32 ? 2u : (w == 16 ? 1u : 0u);
+    const uint32_t nchunks = (w / cs) * h;
+    const uint32_t q = valid ? G.xy[blk] : 0u;
+    const uint32_t bx = q & 0xffffu, by = q >> 16;
+    int v[2][8];
+    int sum = 0;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const uint32_t c = l + p * lpb;
+        const bool on = valid && c < nchunks;
+        const uint32_t row = on ? c >> cpr_sh : 0u, col = on ? (c & ((1u << cpr_sh) - 1)) * cs : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[p][i] = 0;
+        if (on) {
+            const PixT* s = reinterpret_cast<const PixT*>(G.luma) + (size_t)(2 * (by + row)) * G.luma_stride + 2 * (bx + col);
+            PixT r0[16], r1[16];
+            if (cs == 8) { cfl_ld<16 * sizeof(PixT)>(r0, s); cfl_ld<16 * sizeof(PixT)>(r1, s + G.luma_stride); }
+            else { cfl_ld<8 * sizeof(PixT)>(r0, s); cfl_ld<8 * sizeof(PixT)>(r1, s + G.luma_stride); }
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (i < (int)cs) v[p][i] = (int)(int16_t)(uint16_t)(((int)r0[2 * i] + r0[2 * i + 1] + r1[2 * i] + r1[2 * i + 1]) << 1);
+#pragma unroll
+            for (int i = 0; i < 8; i++) sum += v[p][i];
+        }
+    }
+    for (uint32_t m = lpb >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, (int)m, 64);
+    const int avg = (int)(int16_t)((sum + G.round_offset) >> G.num_pel_log2);
+    if (!valid) return;
+    const int a_cb = G.alpha_cb[blk], a_cr = G.alpha_cr[blk];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const uint32_t c = l + p * lpb;
+        if (c >= nchunks) continue;
+        const uint32_t row = c >> cpr_sh, col = (c & ((1u << cpr_sh) - 1)) * cs;
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            PixT* pp = reinterpret_cast<PixT*>(pl ? G.cr : G.cb) + (size_t)(by + row) * (pl ? G.cr_stride : G.cb_stride) + bx + col;
+            const int a = pl ? a_cr : a_cb;
+            PixT pv[8], ov[8];
+            if (cs == 8) cfl_ld<8 * sizeof(PixT)>(pv, pp);
+            else if constexpr (sizeof(PixT) == 2) cfl_ld<8>(pv, pp); else __builtin_memcpy(pv, pp, 4);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (i < (int)cs) {
+                    const int q6 = a * (int)(int16_t)(v[p][i] - avg);
+                    const int mag = ((q6 < 0 ? -q6 : q6) + 32) >> 6;
+                    int o = (int)(int16_t)pv[i] + (q6 < 0 ? -mag : mag);
+                    o = o < 0 ? 0 : (o > hi ? hi : o);
+                    ov[i] = (PixT)o;
+                }
+            }
+            if (cs == 8) cfl_st<8 * sizeof(PixT)>(pp, ov); else cfl_st<4 * sizeof(PixT)>(pp, ov);
+        }
     }
 }
 

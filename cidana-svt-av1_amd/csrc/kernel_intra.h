@@ -276,6 +276,15 @@ struct DirMulti {
 // a full 16-B segment per lane and throw most of it away (the open-loop search's 8x8 pass spent half its VALU there).
 // TAB: zone 2 with the host's per-angle tables (DirMulti::z2_w2 / z2_ol); a separate instantiation so that the dense-output kernels
 // keep their own code (with both paths in one kernel the 32x32 single-angle form ran 15 % slower).
+// LDS pair dwords between the staged edges of consecutive blocks of a workgroup.  Lanes of `lpb` rows read a window of about lpb
+// consecutive dwords of their block's edge, and a half wave (32 lanes, one LDS pass) holds 32 / lpb blocks: a stride that is
+// lpb modulo 32 puts those windows on disjoint banks (2 * estride alone is 0 or 16 modulo 32: the open-loop search's 8x8 pass,
+// 8 lanes per block, measured 50 % of its LDS cycles in bank conflicts).  Even, so that the 8-byte staging stores stay aligned.
+__host__ __device__ inline int dir_slot_stride(int estride, uint32_t lpb) {
+    const int base = 2 * estride;
+    return lpb < 32u ? base + (int)(((uint32_t)lpb - (uint32_t)base) & 31u) : base;
+}
+
 template <typename PixT, int MODE, int NPX, bool TAB = false>
 __global__ __launch_bounds__(256) void intra_dir_kernel(
     PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
     const uint32_t j = (uint32_t)(item & (per_block - 1));
     const int r = (int)(j >> lr_shift), c0 = (int)(j & (uint32_t)(lanes_per_row - 1)) * ppl;
     const int estride = (n_pad + 10) & ~7;                                 // pair dwords per staged edge (+ 3: the last group of four may pass n_pad)
-    uint32_t* sa = sm + (size_t)slot * 2 * estride;                        // above edge of this lane's block
+    uint32_t* sa = sm + (size_t)slot * dir_slot_stride(estride, lpb);                      // above edge of this lane's block
     uint32_t* sl = sa + estride;
     const bool live = item < total;
     const uint32_t blk = live ? (uint32_t)(item >> pb_shift) : 0u;
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
     // zone 2, one angle per launch, no up-sampling: the left-edge terms of column c - weight pair and 4 * ((-dy (c + 1)) >> 6) - are
     // the same in every row; 64 lanes tabulate them once per workgroup behind the staged edges (DirMulti documents the terms)
     const bool z2_lds_tab = MODE == IM_Z2 && !TAB && multi.n == 0 && (up_above | up_left) == 0;
-    uint32_t* tabw = sm + (size_t)(256u >> __builtin_ctz(lpb)) * 2 * estride;
+    uint32_t* tabw = sm + (size_t)(256u >> __builtin_ctz(lpb)) * dir_slot_stride(estride, lpb);
     if (z2_lds_tab && threadIdx.x < 64) {
         const int ys = -dy * ((int)threadIdx.x + 1);
         const uint32_t sh = ((uint32_t)ys & 63u) >> 1;

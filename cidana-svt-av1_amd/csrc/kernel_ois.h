@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void ois_gather_kernel(const uint8_t* __restri
     if (threadIdx.x < 16) s_sum[threadIdx.x] = 0;
     __syncthreads();
     const bool valid = blk < nblocks;
-    uint32_t x = 0, y = 0;
+    uint32_t x = 0, y = 0, av_dc = 0, lv_dc = 0;
     if (valid) { const uint32_t q = xy[blk]; x = q & 0xffffu; y = q >> 16; }
     if (valid) {
         const uint8_t* src = pic + (size_t)y * stride + x;
@@ -41,13 +41,21 @@ __global__ __launch_bounds__(256) void ois_gather_kernel(const uint8_t* __restri
         uint8_t* lb = left + (size_t)blk * nb_pitch + OIS_NB_ORIGIN;
         ab[l] = (uint8_t)av;
         lb[l] = (uint8_t)lv;
+        av_dc = av; lv_dc = lv;
         if (l == 0) {
             const uint8_t tl = (x != 0 && y != 0) ? src[-(ptrdiff_t)stride - 1] : (uint8_t)128;
             ab[-1] = tl; lb[-1] = tl;
             ab[-2] = 0; lb[-2] = 0;          // position -2 is staged with the rest (it only matters with up-sampling, which the open loop never has)
         }
-        // DC sum over the first bsize samples of each available edge (a block's lanes may span two waves: LDS)
-        if (l < bsize) atomicAdd(&s_sum[slot], (y != 0 ? (int)av : 0) + (x != 0 ? (int)lv : 0));
+    }
+    // DC sum over the first bsize samples of each available edge: summed inside the wave first (DPP), one LDS atomic per (block,
+    // wave) - a block's lanes span two waves only at 64x64.  (One atomic per lane on the block's word serialised the whole wave:
+    // 70 % of this kernel's LDS cycles were bank conflicts.)  Every lane takes part in the DPP steps; dead lanes add 0.
+    {
+        const uint32_t part = (valid && l < bsize) ? (y != 0 ? av_dc : 0u) + (x != 0 ? lv_dc : 0u) : 0u;
+        const uint32_t glanes = lpb < 64u ? lpb : 64u;
+        const uint32_t sum = group_sum_rt(part, glanes);
+        if (valid && (l & (glanes - 1)) == 0) atomicAdd(&s_sum[slot], (int)sum);
     }
     __syncthreads();
     if (valid && l == 0) {

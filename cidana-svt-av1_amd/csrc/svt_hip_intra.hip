@@ -112,6 +112,98 @@ extern "C" int svt_hip_txb_init_levels_batch(const int32_t* d_coeff, size_t coef
     return launch_status("txb_init_levels");
 }
 
+// ---- the frame call with its chroma-from-luma step and level maps (header: svt_hip_encode_recon_frame_ex) ----
+static int frame_levels_launch(const svt_hip_frame_group* groups, const svt_hip_frame_levels* levels, int ngroups, hipStream_t s) {
+    LevelsFrameDesc fd;
+    memset(&fd, 0, sizeof(fd));
+    uint32_t total = 0;
+    auto flush = [&]() -> int {
+        if (!fd.ngroups) return SVT_HIP_OK;
+        hipLaunchKernelGGL(levels_frame_kernel, dim3(total), dim3(256), 0, s, fd);
+        fd.ngroups = 0; total = 0;
+        return launch_status("levels_frame");
+    };
+    for (int g = 0; g < ngroups; g++) {
+        const svt_hip_frame_group& G = groups[g];
+        const svt_hip_frame_levels& L = levels[g];
+        if (!G.nblocks || !L.d_levels_buf) continue;
+        if (fd.ngroups == LEVELS_MAX_GROUPS) if (int rc = flush()) return rc;
+        LevelsGroupDev& D = fd.g[fd.ngroups];
+        // get_txb_wide / get_txb_high: the packed coefficient block (a 64-sample side keeps its 32 low-frequency columns / rows)
+        const uint32_t w = (uint32_t)(kTxW[G.tx_size] > 32 ? 32 : kTxW[G.tx_size]), h = (uint32_t)(kTxH[G.tx_size] > 32 ? 32 : kTxH[G.tx_size]);
+        const uint32_t bytes = (w + 4) * (h + 6) + 16, ndw = bytes >> 2, dpr = (w + 4) >> 2;
+        const bool wide = (L.levels_block_pitch & 15) == 0 && ((uintptr_t)L.d_levels_buf & 15) == 0;
+        const uint32_t items = wide ? (ndw + 3) / 4 : ndw;
+        uint32_t lpb = 1;
+        while (lpb < items && lpb < 256) lpb <<= 1;
+        D.coeff = G.d_qcoeff; D.levels = L.d_levels_buf; D.levels_pitch = (uint32_t)L.levels_block_pitch; D.w = w; D.h = h; D.lpb = lpb; D.ndw = ndw;
+        D.row_magic = (uint32_t)(0x100000000ull / dpr) + 1u; D.nblocks = G.nblocks;
+        const uint32_t slots = 256 / lpb;
+        total += (G.nblocks + slots - 1) / slots;
+        D.wg_end = total | (wide ? 0x80000000u : 0u);
+        fd.ngroups++;
+    }
+    return flush();
+}
+
+extern "C" int svt_hip_encode_recon_frame_ex(const svt_hip_frame_group* groups, int ngroups, int first_chroma_group,
+                                             const svt_hip_frame_cfl_group* cfl, int ncfl, const svt_hip_frame_levels* levels,
+                                             int is_16bit, int bd, const int16_t* zbin, const int16_t* round, const int16_t* quant,
+                                             const int16_t* quant_shift, const int16_t* dequant, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (ngroups < 0 || ncfl < 0 || (ngroups && !groups) || (ncfl && !cfl)) return set_err(SVT_HIP_ERR_INVALID, "group lists");
+    if (ngroups > 256) return set_err(SVT_HIP_ERR_INVALID, "more than 256 groups in one call");
+    if (ncfl > CFL_MAX_GROUPS) return set_err(SVT_HIP_ERR_INVALID, "%d chroma-from-luma groups (at most %d: one per chroma transform size)", ncfl, CFL_MAX_GROUPS);
+    if (ncfl && (first_chroma_group < 0 || first_chroma_group > ngroups)) return set_err(SVT_HIP_ERR_INVALID, "first_chroma_group %d of %d", first_chroma_group, ngroups);
+    if ((is_16bit && bd != 8 && bd != 10 && bd != 12) || (!is_16bit && bd != 8)) return set_err(SVT_HIP_ERR_INVALID, "bit depth %d", bd);
+    // everything is validated before anything is enqueued
+    if (int rc = frame_groups_check(groups, ngroups)) return rc;
+    CflFrameDesc cd;
+    memset(&cd, 0, sizeof(cd));
+    uint32_t cfl_total = 0;
+    for (int g = 0; g < ncfl; g++) {
+        const svt_hip_frame_cfl_group& C = cfl[g];
+        if (C.nblocks == 0) continue;
+        if (!C.d_luma_recon || !C.d_pred_cb || !C.d_pred_cr || !C.d_xy || !C.d_alpha_q3_cb || !C.d_alpha_q3_cr)
+            return set_err(SVT_HIP_ERR_INVALID, "chroma-from-luma group %d: NULL member", g);
+        if (!cfl_dim_ok(C.width) || !cfl_dim_ok(C.height)) return set_err(SVT_HIP_ERR_INVALID, "chroma-from-luma group %d: chroma block %ux%u", g, C.width, C.height);
+        if (C.luma_stride < 2 * C.width || C.pred_stride_cb < C.width || C.pred_stride_cr < C.width)
+            return set_err(SVT_HIP_ERR_INVALID, "chroma-from-luma group %d: stride smaller than the block", g);
+        CflGroupDev& D = cd.g[cd.ngroups++];
+        const uint32_t nchunks = (C.width / (C.width < 8 ? 4 : 8)) * C.height;
+        D.lpb = nchunks < 64 ? nchunks : 64;
+        D.luma = C.d_luma_recon; D.cb = C.d_pred_cb; D.cr = C.d_pred_cr; D.xy = C.d_xy; D.alpha_cb = C.d_alpha_q3_cb; D.alpha_cr = C.d_alpha_q3_cr;
+        D.luma_stride = C.luma_stride; D.cb_stride = C.pred_stride_cb; D.cr_stride = C.pred_stride_cr; D.nblocks = C.nblocks; D.w = C.width; D.h = C.height;
+        D.round_offset = (int32_t)(C.width * C.height / 2);
+        D.num_pel_log2 = __builtin_ctz(C.width) + __builtin_ctz(C.height);
+        const uint32_t slots = 256 / D.lpb;
+        cfl_total += (C.nblocks + slots - 1) / slots;
+        D.wg_end = cfl_total;
+    }
+    if (levels)
+        for (int g = 0; g < ngroups; g++) {
+            const svt_hip_frame_levels& L = levels[g];
+            if (!groups[g].nblocks || !L.d_levels_buf) continue;
+            const uint32_t w = (uint32_t)(kTxW[groups[g].tx_size] > 32 ? 32 : kTxW[groups[g].tx_size]), h = (uint32_t)(kTxH[groups[g].tx_size] > 32 ? 32 : kTxH[groups[g].tx_size]);
+            const size_t bytes = (size_t)(w + 4) * (h + 6) + 16;
+            if (L.levels_block_pitch < bytes || (L.levels_block_pitch & 3) || ((uintptr_t)L.d_levels_buf & 3) || L.levels_block_pitch > 0xffffffffu)
+                return set_err(SVT_HIP_ERR_INVALID, "group %d: levels buffer %zu B per block (need >= %zu, multiple of 4, 4-byte aligned)", g, L.levels_block_pitch, bytes);
+        }
+    hipStream_t s = (hipStream_t)stream;
+    // stream order carries the dependencies: luma reconstruction -> chroma-from-luma prediction -> chroma encode -> level maps
+    const int n_first = cd.ngroups ? first_chroma_group : ngroups;
+    if (int rc = svt_hip_encode_recon_frame(groups, n_first, is_16bit, bd, zbin, round, quant, quant_shift, dequant, stream)) return rc;
+    if (cd.ngroups) {
+        const int hi = (1 << bd) - 1;
+        if (is_16bit) hipLaunchKernelGGL((cfl_frame_kernel<uint16_t>), dim3(cfl_total), dim3(256), 0, s, cd, hi);
+        else hipLaunchKernelGGL((cfl_frame_kernel<uint8_t>), dim3(cfl_total), dim3(256), 0, s, cd, hi);
+        if (int rc = launch_status("cfl_frame")) return rc;
+        if (int rc = svt_hip_encode_recon_frame(groups + n_first, ngroups - n_first, is_16bit, bd, zbin, round, quant, quant_shift, dequant, stream)) return rc;
+    }
+    if (levels) return frame_levels_launch(groups, levels, ngroups, s);
+    return SVT_HIP_OK;
+}
+
 static bool intra_size_ok(int bw, int bh) {
     auto ok1 = [](int v) { return v == 4 || v == 8 || v == 16 || v == 32 || v == 64; };
     if (!ok1(bw) || !ok1(bh)) return false;
@@ -170,7 +262,7 @@ static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pit
         const int up = upsample_above > upsample_left ? upsample_above : upsample_left;
         const int n_pad = (lim_a > lim_l ? lim_a : lim_l) + ((16 / es) << up) + 3;
         const size_t slots = per_block >= 256 ? 1 : 256 / per_block;
-        const size_t shmem = slots * 2 * (size_t)((n_pad + 10) & ~7) * 4 + 2 * 64 * 4;   // pair dwords + zone 2's column table (see the kernel)
+        const size_t shmem = slots * (size_t)dir_slot_stride((n_pad + 10) & ~7, (uint32_t)(per_block >= 256 ? 256 : per_block)) * 4 + 2 * 64 * 4;   // pair dwords + zone 2's column table (see the kernel)
         DirMulti dm;
         if (multi) dm = *multi; else dm.n = 0;
         dm.z2_tab = 0;

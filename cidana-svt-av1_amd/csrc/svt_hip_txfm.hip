@@ -511,14 +511,12 @@ extern "C" int svt_hip_fwd_quant_planes_batch(const void* d_src, uint32_t src_st
 namespace {
 }  // namespace
 
-extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int ngroups, int is_16bit, int bd,
-                                          const int16_t* zbin, const int16_t* round, const int16_t* quant,
-                                          const int16_t* quant_shift, const int16_t* dequant, void* stream) {
-    if (int rc = require_init()) return rc;
+// argument checks of a frame call's groups (also used by svt_hip_encode_recon_frame_ex before it enqueues its first phase)
+int svthost::frame_groups_check(const svt_hip_frame_group* groups, int ngroups) {
     if (ngroups == 0) return SVT_HIP_OK;
     if (!groups || ngroups < 0) return set_err(SVT_HIP_ERR_INVALID, "NULL group list");
     if (ngroups > 256) return set_err(SVT_HIP_ERR_INVALID, "more than 256 groups in one call");
-    for (int g = 0; g < ngroups; g++) {            // validate everything before anything is enqueued
+    for (int g = 0; g < ngroups; g++) {
         const svt_hip_frame_group& G = groups[g];
         if (G.nblocks == 0) continue;
         if (!G.d_src || !G.d_pred || !G.d_recon || !G.d_xy || !G.d_iscan || !G.d_qcoeff || !G.d_eob)
@@ -528,6 +526,15 @@ extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int
         if (G.tx_size == SVT_TX_4X4 && g_tune_no_enc_staged && (!G.d_coeff || !G.d_offsets || G.d_recon != G.d_pred || G.recon_stride != G.pred_stride))
             return set_err(SVT_HIP_ERR_INVALID, "group %d: with no_enc_staged set, 4x4 groups take the two-stage path and need d_coeff, d_dqcoeff, d_offsets and in-place reconstruction", g);
     }
+    return SVT_HIP_OK;
+}
+
+extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int ngroups, int is_16bit, int bd,
+                                          const int16_t* zbin, const int16_t* round, const int16_t* quant,
+                                          const int16_t* quant_shift, const int16_t* dequant, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (ngroups == 0) return SVT_HIP_OK;
+    if (int rc = frame_groups_check(groups, ngroups)) return rc;            // validate everything before anything is enqueued
     // ---- one launch per REGISTER CLASS (enc_frame_kernel, kernel_frame.h) when every group is one the fused bodies cover: any of the
     // 19 sizes and their types, qcoeff + recon outputs, power-of-two quant_shift tables.  Measured (tools/bench_frame.py,
     // tools/bench_c5.py): a 1080p picture as 13 per-size launches on 8 streams 0.160 ms, those captured into a graph 0.101, ONE
@@ -538,7 +545,10 @@ extern "C" int svt_hip_encode_recon_frame(const svt_hip_frame_group* groups, int
         if (groups[g].nblocks) call_pixels += (size_t)groups[g].nblocks * kTxW[groups[g].tx_size] * kTxH[groups[g].tx_size];      // (validated above)
     // frame_single_launch: 1 one launch (class 3), 2 one launch per register class, 0 per-size launches, -1 (default): one launch up to
     // 2^25 pixel passes per call (two 1080p pictures with five sizes; measured cross-over between 2 and 4, tools/bench_frame.py), class launches above
-    int mode = g_tune_frame_single_launch >= 0 ? g_tune_frame_single_launch : (call_pixels <= ((size_t)1 << 25) ? 1 : 2);
+    // ... and per-size launches on the fan-out streams above 2^28 (a GOP of 4K pictures: every size fills the GPU on its own at its
+    // own kernel's occupancy; configs[4], 30 pictures per call, tools/bench_c5.py: 6 162 pictures/s against 5 756 by class and 4 888 in one launch)
+    int mode = g_tune_frame_single_launch >= 0 ? g_tune_frame_single_launch
+                                               : (call_pixels <= ((size_t)1 << 25) ? 1 : (call_pixels <= ((size_t)1 << 28) ? 2 : 0));
     for (int g = 0; g < ngroups; g++)
         if (mode == 1 && groups[g].nblocks && groups[g].tx_size > SVT_TX_64X64) mode = 2;      // the one-launch kernel holds the square sizes
     if (mode > 0) {

@@ -77,7 +77,10 @@ class FramePass:
                 g["coeff"] = torch.empty((n, nc), dtype=torch.int32, device=dev)
                 g["dqcoeff"] = torch.empty((n, nc), dtype=torch.int32, device=dev)
             self.groups.append(g)
+        self.groups.sort(key=lambda g: g["name"] != "Y")      # luma groups first (stable): svt_hip_encode_recon_frame_ex's two phases
+        self.n_luma = sum(g["name"] == "Y" for g in self.groups)
         self.array = dsp.make_frame_groups(self.groups)
+        self.cfl_groups, self.cfl_array, self.levels_array = [], None, None
         self.is_16bit = is_16bit
         self.pixels = sum(g["pixels"] for g in self.groups)
         self.blocks = sum(g["xy"].numel() for g in self.groups)
@@ -85,6 +88,39 @@ class FramePass:
     def run(self, qrow):
         """every group in one call (concurrent on the library's internal streams)"""
         self.dsp.encode_recon_frame(self.array, qrow, is_16bit=self.is_16bit, bd=10 if self.is_16bit else 8)
+
+    def add_levels(self, fill=None):
+        """one padded level buffer per block of every group (av1_txb_init_levels' levels_buf), 16-byte-aligned pitch"""
+        t = self.torch
+        for g in self.groups:
+            w, h = min(self._side(g)[0], 32), min(self._side(g)[1], 32)
+            pitch = ((w + 4) * (h + 6) + 16 + 15) // 16 * 16
+            n = g["xy"].numel()
+            g["levels"] = t.empty((n, pitch), dtype=t.uint8, device=g["xy"].device) if fill is None else \
+                t.full((n, pitch), fill, dtype=t.uint8, device=g["xy"].device)
+        self.levels_array = self.dsp.make_frame_levels([g["levels"] for g in self.groups])
+
+    def _side(self, g):
+        from . import TX_W, TX_H
+        return TX_W[g["tx_size"]], TX_H[g["tx_size"]]
+
+    def add_cfl(self, alpha_cb, alpha_cr, xy=None):
+        """chroma-from-luma prediction for the chroma blocks of a pass with ONE luma size: alpha_* int32 per chroma block (of xy, default:
+        every block of the Cb group); the luma reconstruction is the Y group's, the chroma predictions are predicted in place"""
+        ys = [g for g in self.groups if g["name"] == "Y"]
+        cs = [g for g in self.groups if g["name"] != "Y"]
+        if len(ys) != 1 or len(cs) != 2 or ys[0]["recon"].dim() != 2:
+            raise ValueError("add_cfl takes a pass with one luma size over one 4:2:0 picture")
+        cw, ch = self._side(cs[0])
+        self.cfl_groups = [{"luma_recon": ys[0]["recon"], "luma_stride": ys[0]["recon_stride"], "pred_cb": cs[0]["pred"], "cb_stride": cs[0]["pred_stride"],
+                            "pred_cr": cs[1]["pred"], "cr_stride": cs[1]["pred_stride"], "xy": cs[0]["xy"] if xy is None else xy,
+                            "alpha_cb": alpha_cb, "alpha_cr": alpha_cr, "width": cw, "height": ch}]
+        self.cfl_array = self.dsp.make_frame_cfl_groups(self.cfl_groups)
+
+    def run_ex(self, qrow):
+        """luma groups -> chroma-from-luma prediction (add_cfl) -> chroma groups -> level maps (add_levels): one call"""
+        self.dsp.encode_recon_frame_ex(self.array, qrow, self.n_luma, self.cfl_array, len(self.cfl_groups), self.levels_array,
+                                       is_16bit=self.is_16bit, bd=10 if self.is_16bit else 8)
 
     def run_sequential(self, qrow):
         """the same groups, one entry-point call after the other on the caller's stream (what round 1 measured; the wrappers

@@ -234,6 +234,39 @@ int svt_hip_encode_recon_frame(const svt_hip_frame_group *groups, int ngroups, i
                                const int16_t *zbin, const int16_t *round, const int16_t *quant,
                                const int16_t *quant_shift, const int16_t *dequant, void *stream);
 
+/* The frame call with the two encode-pass pieces that sit beside the transform chain:
+ *
+ *   chroma from luma  (Av1EncodeLoop, EbCodingLoop.c:736-846; 16-bit :1198-1250).  For a chroma block predicted with
+ *       UV_CFL_PRED the reference, after the luma transform block's reconstruction, calls cfl_luma_subsampling_420_{lbd,hbd}
+ *       on the luma RECONSTRUCTION, subtract_average, and cfl_predict_{lbd,hbd} on the Cb and the Cr prediction IN PLACE with
+ *       the block's two alphas; the chroma residual / transform / quantisation then runs on that prediction.  Here: groups
+ *       [0, first_chroma_group) are encoded first (the luma groups), then ONE launch does the three steps for every block of
+ *       every cfl group (Q3 values stay in registers), then groups [first_chroma_group, ngroups) are encoded.  With ncfl == 0
+ *       the split is ignored and all groups go out together.
+ *   av1_txb_init_levels  (EbRateDistortionCost.c:125-150, called per coded block by the coefficient cost / entropy stage,
+ *       :450) of every group's quantised coefficients: levels[g] (NULL, or one entry per group; an entry with a NULL buffer
+ *       skips its group) names one whole padded level buffer per block, (w + 4) * (h + 6) + 16 bytes with w, h the packed
+ *       coefficient block's sides (min(.., 32)), as in svt_hip_txb_init_levels_batch.  ONE launch after the encode launches.
+ *
+ * Everything is enqueued on `stream`, in the order above (stream order carries the dependencies); arguments are validated
+ * before the first launch. */
+typedef struct svt_hip_frame_cfl_group {
+    const void *d_luma_recon; uint32_t luma_stride;     /* the plane the luma groups reconstruct into; samples as the groups' */
+    void *d_pred_cb; uint32_t pred_stride_cb;           /* chroma prediction planes (the chroma groups' d_pred): the DC prediction */
+    void *d_pred_cr; uint32_t pred_stride_cr;           /* on entry, the chroma-from-luma prediction on return */
+    const uint32_t *d_xy;                               /* chroma block origins x | y << 16; the luma area starts at (2x, 2y) */
+    const int32_t *d_alpha_q3_cb, *d_alpha_q3_cr;       /* cfl_idx_to_alpha(.., CFL_PRED_U / CFL_PRED_V) per block */
+    uint32_t width, height;                             /* chroma block (tx_width_uv x tx_height_uv): 4 .. 32 */
+    uint32_t nblocks;
+} svt_hip_frame_cfl_group;
+typedef struct svt_hip_frame_levels {
+    uint8_t *d_levels_buf; size_t levels_block_pitch;   /* >= (w + 4) * (h + 6) + 16, a multiple of 4; 16-byte alignment is faster */
+} svt_hip_frame_levels;
+int svt_hip_encode_recon_frame_ex(const svt_hip_frame_group *groups, int ngroups, int first_chroma_group,
+                                  const svt_hip_frame_cfl_group *cfl, int ncfl, const svt_hip_frame_levels *levels,
+                                  int is_16bit, int bd, const int16_t *zbin, const int16_t *round, const int16_t *quant,
+                                  const int16_t *quant_shift, const int16_t *dequant, void *stream);
+
 /* BASELINE.json configs[1]: FwdTxfm2d + quantize on a batch of int16 residual blocks
  * (dense W*H per block) — av1_estimate_transform + av1_quantize_inv_quantize
  * (EbFullLoop.c:763, 780).  TX_32X32 8-bit runs the tuned fused kernel. */
