@@ -33,6 +33,7 @@ extern int g_tune_no_q2p;
 extern int g_tune_no_q16;
 extern int g_tune_q2_su4;
 extern int g_tune_ois_no_fold;
+extern int g_tune_ois_no_dir3;
 extern int g_tune_ois_no_nd;
 extern int g_tune_dir_no_split, g_tune_dir_split_target;
 extern int g_tune_me_exact;

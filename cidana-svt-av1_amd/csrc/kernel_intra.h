@@ -271,6 +271,19 @@ struct DirMulti {
     uint32_t z2_w2[20][16];
     int32_t z2_ol[20][16];
 };
+// the same without zone 2's tables (zones 1 and 3 of ois_dir3_kernel: the kernel-argument block is 4 KiB)
+struct DirMultiLite {
+    int n, chunk;
+    int16_t dx[20], dy[20];
+    uint8_t slot[20];
+    size_t batch_pitch;
+    const uint8_t* sad_pic;
+    uint32_t sad_stride;
+    const uint32_t* sad_xy;
+    uint32_t* sad_dist;
+    uint32_t sad_ncand;
+    int z2_tab;
+};
 
 // NPX = samples per lane = min(bw, 16 B worth): a compile-time constant so that narrow blocks (bw 4 / 8) do not compute
 // a full 16-B segment per lane and throw most of it away (the open-loop search's 8x8 pass spent half its VALU there).
@@ -285,11 +298,13 @@ __host__ __device__ inline int dir_slot_stride(int estride, uint32_t lpb) {
     return lpb < 32u ? base + (int)(((uint32_t)lpb - (uint32_t)base) & 31u) : base;
 }
 
-template <typename PixT, int MODE, int NPX, bool TAB = false>
-__global__ __launch_bounds__(256) void intra_dir_kernel(
+// (the body is a device function so that ois_dir3_kernel below can run the three zones of one candidate list in ONE launch; MT is
+// DirMulti or DirMultiLite, ypart the angle chunk this workgroup takes)
+template <typename PixT, int MODE, int NPX, bool TAB, typename MT>
+__device__ __forceinline__ void intra_dir_body(
     PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
     const PixT* __restrict__ above_all, const PixT* __restrict__ left_all, int32_t nb_pitch, int bw, int bh,
-    int up_above, int up_left, int dx, int dy, int lim_a, int lim_l, int n_pad, int bd, uint32_t nblocks, const DirMulti multi) {
+    int up_above, int up_left, int dx, int dy, int lim_a, int lim_l, int n_pad, int bd, uint32_t nblocks, const MT& multi, const uint32_t ypart) {
     // interpolated values of in-range samples are in range; 16-bit input may carry out-of-range
     // samples, which clip_pixel_highbd (EbIntraPrediction.c:3394-3506) would clip: keep that
     const uint32_t maxv = (1u << bd) - 1;
@@ -507,9 +522,43 @@ __global__ __launch_bounds__(256) void intra_dir_kernel(
     };
     if (multi.n == 0) emit(dx, dy, dst, 0, 0);
     else {
-        const int k0 = (int)blockIdx.y * multi.chunk, k1 = min(multi.n, k0 + multi.chunk);
+        const int k0 = (int)ypart * multi.chunk, k1 = min(multi.n, k0 + multi.chunk);
         for (int k = k0; k < k1; k++) emit(multi.dx[k], multi.dy[k], dst + (size_t)multi.slot[k] * multi.batch_pitch, (int)multi.slot[k], k);
     }
+}
+
+template <typename PixT, int MODE, int NPX, bool TAB = false>
+__global__ __launch_bounds__(256) void intra_dir_kernel(
+    PixT* __restrict__ dst, int32_t dst_stride, size_t dst_block_pitch, const uint32_t* __restrict__ dst_offsets,
+    const PixT* __restrict__ above_all, const PixT* __restrict__ left_all, int32_t nb_pitch, int bw, int bh,
+    int up_above, int up_left, int dx, int dy, int lim_a, int lim_l, int n_pad, int bd, uint32_t nblocks, const DirMulti multi) {
+    intra_dir_body<PixT, MODE, NPX, TAB>(dst, dst_stride, dst_block_pitch, dst_offsets, above_all, left_all, nb_pitch, bw, bh, up_above, up_left, dx, dy,
+                                         lim_a, lim_l, n_pad, bd, nblocks, multi, blockIdx.y);
+}
+
+// The open-loop intra search's directional candidates of ALL THREE zones in one launch (8-bit SAD mode, square blocks of one lane per
+// row: 8x8, 16x16): blockIdx.y walks zone 1's angle chunks, then zone 2's, then zone 3's.  As three launches each zone was one
+// residency round of latency-bound waves (12 / 21 / 11 us per 1080p picture at 8x8, the VALU busy for 6 / 14 / 6 of them,
+// profiles/r03_ois8_pmc_after.json): one launch lets the zones fill each other's stalls and drops two launch boundaries.
+struct DirOis3 {
+    DirMultiLite z1, z3;
+    DirMulti z2;
+    uint32_t y_end[2];           // zone 1 takes blockIdx.y in [0, y_end[0]), zone 2 [y_end[0], y_end[1]), zone 3 the rest
+};
+static_assert(sizeof(DirOis3) <= 3900, "kernel arguments");
+template <int NPX>
+__global__ __launch_bounds__(256) void ois_dir3_kernel(const uint8_t* __restrict__ above_all, const uint8_t* __restrict__ left_all, int32_t nb_pitch,
+                                                       int bsize, int lim, int n_pad, uint32_t nblocks, const DirOis3 m) {
+    const uint32_t y = blockIdx.y;
+    if (y < m.y_end[0])
+        intra_dir_body<uint8_t, IM_Z1, NPX, false>(nullptr, bsize, 0, nullptr, above_all, left_all, nb_pitch, bsize, bsize, 0, 0, 1, 1, lim, lim, n_pad, 8,
+                                                   nblocks, m.z1, y);
+    else if (y < m.y_end[1])
+        intra_dir_body<uint8_t, IM_Z2, NPX, true>(nullptr, bsize, 0, nullptr, above_all, left_all, nb_pitch, bsize, bsize, 0, 0, 1, 1, lim, lim, n_pad, 8,
+                                                  nblocks, m.z2, y - m.y_end[0]);
+    else
+        intra_dir_body<uint8_t, IM_Z3, NPX, false>(nullptr, bsize, 0, nullptr, above_all, left_all, nb_pitch, bsize, bsize, 0, 0, 1, 1, lim, lim, n_pad, 8,
+                                                   nblocks, m.z3, y - m.y_end[1]);
 }
 
 // av1_filter_intra_edge(_high) (:3539) — out-of-place on the device: every output

@@ -447,6 +447,53 @@ static int ois_dr_derivative(int angle) {
     return 0;
 }
 
+// the directional candidates of the three zones in ONE launch (ois_dir3_kernel): 8x8 / 16x16 SAD mode
+static int ois_dir3_launch(const uint8_t* d_above, const uint8_t* d_left, size_t pitch, uint32_t bsize, size_t nblocks, const DirMulti zone[3],
+                           hipStream_t s) {
+    const size_t per_block = bsize;                              // one lane per row
+    const size_t grid = (per_block * nblocks + 255) / 256;
+    const int lim = NB_ORIGIN + (int)(2 * bsize - 1), n_pad = lim + 16 + 3;
+    const size_t slots = 256 / per_block;
+    const size_t shmem = slots * (size_t)dir_slot_stride((n_pad + 10) & ~7, (uint32_t)per_block) * 4 + 2 * 64 * 4;
+    DirOis3 m;
+    memset(&m, 0, sizeof(m));
+    auto lite = [](DirMultiLite& d, const DirMulti& z) {
+        d.n = z.n; memcpy(d.dx, z.dx, sizeof(d.dx)); memcpy(d.dy, z.dy, sizeof(d.dy)); memcpy(d.slot, z.slot, sizeof(d.slot));
+        d.batch_pitch = 0; d.sad_pic = z.sad_pic; d.sad_stride = z.sad_stride; d.sad_xy = z.sad_xy; d.sad_dist = z.sad_dist; d.sad_ncand = z.sad_ncand; d.z2_tab = 0;
+    };
+    lite(m.z1, zone[0]); lite(m.z3, zone[2]);
+    m.z2 = zone[1];
+    m.z2.z2_tab = 1;
+    for (int a = 0; a < m.z2.n; a++)
+        for (int k = 0; k < 16; k++) {
+            const int ys = -(int)m.z2.dy[a] * (k + 1);
+            const uint32_t sh = ((uint32_t)ys & 63u) >> 1;
+            m.z2.z2_w2[a][k] = (32u - sh) | (sh << 16);
+            m.z2.z2_ol[a][k] = 4 * (ys >> 6);
+        }
+    // angles per workgroup, per zone: as separate launches each zone wants dir_split_target (4) workgroups per CU before it stops
+    // spreading its angles over grid.y; with the three zones in one launch the sum counts - swept 1 .. 8 on the 1080p search
+    // (gpurun_out r03_f): 1 is best for 8x8 (0.0526 against 0.0567 ms at 4) and 16x16 (0.0443 against 0.0471)
+    const int nz[3] = {m.z1.n, m.z2.n, m.z3.n};
+    int chunk[3];
+    uint32_t gy[3];
+    const size_t want = (size_t)g_num_cu;
+    for (int z = 0; z < 3; z++) {
+        size_t parts = (g_tune_dir_no_split || grid >= want) ? 1 : (want + grid - 1) / grid;
+        if (parts > (size_t)(nz[z] ? nz[z] : 1)) parts = (size_t)(nz[z] ? nz[z] : 1);
+        chunk[z] = nz[z] ? (int)((nz[z] + parts - 1) / parts) : 1;
+        gy[z] = nz[z] ? (uint32_t)((nz[z] + chunk[z] - 1) / chunk[z]) : 0;
+    }
+    m.z1.chunk = chunk[0]; m.z2.chunk = chunk[1]; m.z3.chunk = chunk[2];
+    m.y_end[0] = gy[0]; m.y_end[1] = gy[0] + gy[1];
+    const uint32_t gyt = gy[0] + gy[1] + gy[2];
+    if (bsize == 8)
+        hipLaunchKernelGGL(ois_dir3_kernel<8>, dim3((uint32_t)grid, gyt), dim3(256), shmem, s, d_above, d_left, (int32_t)pitch, (int)bsize, lim, n_pad, (uint32_t)nblocks, m);
+    else
+        hipLaunchKernelGGL(ois_dir3_kernel<16>, dim3((uint32_t)grid, gyt), dim3(256), shmem, s, d_above, d_left, (int32_t)pitch, (int)bsize, lim, n_pad, (uint32_t)nblocks, m);
+    return launch_status("ois_dir3");
+}
+
 extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, uint32_t width, uint32_t height,
                                         const uint32_t* d_xy, uint32_t bsize, const uint8_t* modes, const int8_t* angle_deltas,
                                         int ncand, uint32_t* d_distortion, int8_t* d_best_index, void* d_work,
@@ -514,9 +561,11 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
                     z.n = 0; z.batch_pitch = 0;
                     z.sad_pic = d_pic; z.sad_stride = stride; z.sad_xy = d_xy; z.sad_dist = d_distortion; z.sad_ncand = (uint32_t)ncand;
                 }
+                bool flushed = false;                             // a zone with more than 20 angles went out on its own
                 auto flush = [&](int zi) -> int {
                     DirMulti& z = zone[zi];
                     if (!z.n) return SVT_HIP_OK;
+                    flushed = true;
                     const int rc = intra_pred_impl(d_distortion /* unused in SAD mode */, (int32_t)bsize, (size_t)bsize * bsize, nullptr, d_above, d_left,
                                                    (int32_t)pitch, SVT_INTRA_Z1 + zi, (int)bsize, (int)bsize, 0, 0, 1, 1, 0, 8, nblocks, stream, &z);
                     z.n = 0;
@@ -533,7 +582,10 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
                     z.slot[z.n] = (uint8_t)c;
                     z.n++;
                 }
-                for (int zi = 0; zi < 3; zi++) if (int rc = flush(zi)) return rc;
+                if (!flushed && !g_tune_ois_no_dir3 && (zone[0].n > 0) + (zone[1].n > 0) + (zone[2].n > 0) >= 2) {
+                    if (int rc = ois_dir3_launch(d_above, d_left, pitch, bsize, nblocks, zone, st)) return rc;
+                } else
+                    for (int zi = 0; zi < 3; zi++) if (int rc = flush(zi)) return rc;
             }
             const uint32_t cs = bsize < 16 ? 8 : 16, lpb = bsize * bsize / cs;
             const uint32_t nd_slots = 256 / lpb;

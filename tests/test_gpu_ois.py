@@ -96,6 +96,29 @@ def test_ois_fold_variant(dsp, bsize):
 
 
 @pytest.mark.parametrize("bsize", [8, 16])
+def test_ois_three_zones_in_one_launch_variant(dsp, bsize):
+    """ois_dir3_kernel (the three directional zones of the list in one launch, default) == one launch per zone; also a list whose
+    directional candidates all lie in one zone (stays on the per-zone kernel) against the oracle-pinned default"""
+    rng = np.random.default_rng(900 + bsize)
+    W, H, pad = 416, 240, 16
+    buf = rng.integers(0, 256, size=(H + 2 * pad, W + 2 * pad), dtype=np.uint8)
+    blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
+    modes, deltas = dsp.ois_candidates(bsize)
+    plane = dev(buf)
+    lists = [(modes, deltas), (np.array([0, 3, 3, 8, 8, 1], np.uint8), np.array([0, -2, 1, 0, 3, 0], np.int8)),      # zone 1 only (+ DC, V)
+             (np.array([4, 7, 2, 12], np.uint8), np.array([1, -3, 0, 0], np.int8))]                                 # zones 2 and 3
+    for m, d in lists:
+        out = []
+        try:
+            for v in (0, 1):
+                assert dsp.lib.svt_hip_tune(b"ois_no_dir3", v) == 0
+                out.append(dsp.ois_search(plane[pad:, pad:], W + 2 * pad, W, H, _xy(blocks), bsize, m, d))
+        finally:
+            dsp.lib.svt_hip_tune(b"ois_no_dir3", 0)
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("bsize", [8, 16])
 def test_ois_directional_angles_split_over_grid_variant(dsp, bsize):
     """small batches spread the directional angles of a zone over grid.y (dir_no_split = 0) == every workgroup walks all angles"""
     rng = np.random.default_rng(300 + bsize)
