@@ -100,6 +100,18 @@ for nf in (2, 4):                                                    # where the
 assert dsp.lib.svt_hip_tune(b"frame_single_launch", -1) == 0
 rows["frame_default_policy"] = timeit(lambda: fp.run(qrow))
 rows["frame_gop16_default_policy_per_frame"] = timeit(lambda: fpg.run(qrow), iters=10) / NF
+# the frame call with its chroma-from-luma step and level maps (svt_hip_encode_recon_frame_ex), one luma size (16; chroma 8x8):
+# every chroma block predicted from luma, a level map for every block
+ex = {}
+for what in ("plain", "cfl", "levels", "cfl+levels"):
+    fx = frames.FramePass(dsp, pkg, src, {k: v.clone() for k, v in pred.items()}, luma_sizes=(16,))
+    if "cfl" in what:
+        n = fx.groups[1]["xy"].numel()
+        fx.add_cfl(torch.randint(-16, 17, (n,), dtype=torch.int32, device=dev, generator=g), torch.randint(-16, 17, (n,), dtype=torch.int32, device=dev, generator=g))
+    if "levels" in what:
+        fx.add_levels()
+    ex[what] = round(timeit(lambda: fx.run_ex(qrow)), 4)
+rows_ex = {"ms_luma16_pass": ex, "pixel_passes": fx.pixels, "blocks": fx.blocks}
 if os.environ.get("FRAME_ONLY_GOP"):          # for rocprofv3: only the GOP call's kernels in the trace
     sys.exit(0)
 out = {"config": "configs[3]: one 1920x1080 yuv420p frame, luma sizes 64/32/16/8/4 + chroma at half the side, 8-bit, qindex 100",
@@ -107,7 +119,7 @@ out = {"config": "configs[3]: one 1920x1080 yuv420p frame, luma sizes 64/32/16/8
        "ms_per_frame": {k: round(v, 4) for k, v in rows.items()},
        "GBps_at_7B_per_px": {k: round(7 * fp.pixels / v / 1e6, 1) for k, v in rows.items()},
        "frac_of_8TBps": {k: round(7 * fp.pixels / v / 1e6 / 8000, 4) for k, v in rows.items()},
-       "per_luma_size_frame_call": per_size, "device": dsp.device_name()}
+       "per_luma_size_frame_call": per_size, "frame_ex": rows_ex, "device": dsp.device_name()}
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "frame_c4.json"), "w"), indent=1)

@@ -254,6 +254,11 @@ if want("bip"):
     out = torch.empty((n, 16, 16), dtype=torch.uint8, device=dev)
     ms = timeit(lambda: dsp.build_intra_predictors(top, left, blk, 2, dst=out, dst_stride=16))
     rec("build_intra_predictors_16x16_u8(mixed modes)", n, 256 + 2 * 33 + 8, ms)
+
+    def ordered():
+        order = dsp.intra_order_blocks(blk, 2)
+        return dsp.build_intra_predictors(top, left, blk, 2, dst=out, dst_stride=16, order=order)
+    rec("build_intra_predictors_16x16_u8(mixed modes, ordered by kind on the device: ordering included)", n, 256 + 2 * 33 + 8, timeit(ordered))
     del top, left, blk, out
 if want("hme"):
     # HME level 0 on a 1/16-resolution 4K picture pair (960x540, 16x16 SBs... the level's own SB size), every SB, one launch

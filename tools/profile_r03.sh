@@ -10,5 +10,5 @@ bash tools/pmc_r02.sh $tag enc8 enc16 me_sb bip ois8 > $out/pmc_kernels.log 2>&1
 timeout -k 10 300 python3 tools/bench_frame.py > $out/bench_frame.log 2>&1 && cp gpurun_out/frame_c4.json $out/frame_c4.json
 timeout -k 10 300 python3 tools/bench_c5.py --frames 240 --json-out $out/c5_240frames_1gpu.json > $out/c5_240.log 2>&1
 timeout -k 10 300 python3 tools/bench_c5.py --frames 240 --stack 30 --json-out $out/c5_240frames_1gpu_stack30.json > $out/c5_240_stack30.log 2>&1
-timeout -k 10 500 python3 tools/bench_kernels.py > $out/bench_kernels.log 2>&1
+timeout -k 10 500 python3 tools/bench_kernels.py > $out/bench_kernels.log 2>&1 && cp gpurun_out/kernels.json $out/kernels.json
 ls $out | head -50
