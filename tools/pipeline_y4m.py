@@ -220,10 +220,12 @@ def main():
     n, dt, dg = results[-1]
     assert results[0][2] == dg, "the two passes disagree"
     print(json.dumps({"file": os.path.basename(path), "picture": f"{p.W}x{p.H}", "frames": n, "seconds": round(dt, 4), "frames_per_s": round(n / dt, 1),
-                      "ms_per_frame": round(1e3 * dt / n, 3), "hip_graph": bool(a.graph), "stages": "input + decimation, OIS (4 sizes), HME 0/1/2, ME 209 PUs 64x64 area, encode pass (5 sizes, YUV)",
+                      "ms_per_frame": round(1e3 * dt / n, 3), "hip_graph": bool(a.graph), "stages": "input + decimation, OIS (4 sizes), HME 0/1/2, ME set-up + 209 PUs per-SB areas, encode pass (5 sizes, YUV)",
                       "last_frame_digest": dg, "device": dsp.device_name()}), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump({"frames": n, "seconds": dt, "frames_per_s": n / dt, "digest": dg}, open(os.path.join(ROOT, "gpurun_out", "pipeline.json"), "w"), indent=1)
+    json.dump({"picture": f"{p.W}x{p.H}", "bd": a.bd, "frames": n, "seconds": dt, "frames_per_s": n / dt, "ms_per_frame": 1e3 * dt / n, "hip_graph": bool(a.graph),
+               "stages": "input + decimation, OIS (4 sizes), HME 0/1/2 (2 x 2 regions), ME set-up (svt_hip_me_setup_batch) + 209 PUs per-SB areas, encode pass (5 sizes, YUV)",
+               "digest": dg, "device": dsp.device_name()}, open(os.path.join(ROOT, "gpurun_out", "pipeline.json"), "w"), indent=1)
     if tmp:
         os.remove(path); os.rmdir(tmp)
 
