@@ -35,15 +35,17 @@ struct BipBlk {                 // == svt_hip_intra_blk
 };
 static_assert(sizeof(BipBlk) == 8, "descriptor layout");
 
-// dr_intra_derivative (EbIntraPrediction.c:299; AV1 spec 7.11.2.4): defined at the 27 angles the prediction can take
-__device__ __forceinline__ int bip_dr_derivative(int angle) {
-    constexpr uint16_t v[27] = {1023, 547, 372, 273, 215, 178, 151, 132, 116, 102, 90, 80, 71, 64, 57, 51, 45, 40, 35, 31, 27, 23, 19, 15, 11, 7, 3};
-    constexpr uint8_t a[27] = {3, 6, 9, 14, 17, 20, 23, 26, 29, 32, 36, 39, 42, 45, 48, 51, 54, 58, 61, 64, 67, 70, 73, 76, 81, 84, 87};
-    int r = 1;
-#pragma unroll
-    for (int i = 0; i < 27; i++) r = a[i] == angle ? (int)v[i] : r;
-    return r;
-}
+// dr_intra_derivative (EbIntraPrediction.c:299; AV1 spec 7.11.2.4): defined at the 27 angles the prediction can take (1 elsewhere, as
+// nothing reads it there).  A table in constant memory, one load per lane: as a chain of 27 compare-and-select pairs it cost the
+// wave 54 VALU instructions per call, two calls for zone 2 - a quarter of an angled wave's instructions for a per-BLOCK value.  The
+// load is issued when the descriptor arrives and is first needed in the pixel stage.
+__device__ __constant__ uint16_t kBipDrDerivative[92] = {
+    1, 1, 1, 1023, 1, 1, 547, 1, 1, 372, 1, 1, 1, 1, 273, 1, 1, 215, 1, 1, 178, 1, 1,
+    151, 1, 1, 132, 1, 1, 116, 1, 1, 102, 1, 1, 1, 90, 1, 1, 80, 1, 1, 71, 1, 1, 64,
+    1, 1, 57, 1, 1, 51, 1, 1, 45, 1, 1, 1, 40, 1, 1, 35, 1, 1, 31, 1, 1, 27, 1,
+    1, 23, 1, 1, 19, 1, 1, 15, 1, 1, 1, 1, 11, 1, 1, 7, 1, 1, 3, 1, 1, 1, 1,
+};
+__device__ __forceinline__ int bip_dr_derivative(int angle) { return (int)kBipDrDerivative[min(max(angle, 0), 91)]; }
 // intra_edge_filter_strength (:225-268)
 __device__ __forceinline__ int bip_filter_strength(int bs0, int bs1, int delta, int type) {
     const int d = abs(delta), wh = bs0 + bs1;
@@ -160,16 +162,35 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
     constexpr int LPB = bip_lanes_per_block(W, H), bpw = 64 / LPB, EL = bip_edge_len(W, H);
     constexpr int lsh = LPB == 4 ? 2 : (LPB == 8 ? 3 : (LPB == 16 ? 4 : (LPB == 32 ? 5 : 6)));
     __shared__ __attribute__((aligned(16))) uint16_t s_edge[BIP_WAVES * bpw * 2 * EL];          // [wave][block of the wave][above | left][EL]
+    // the directional pixel loops read the edges in PAIR form (dword i = edge[i] | edge[i + 1] << 16, kernel_intra.h): built once per
+    // block after the edge stages, clamped at the last valid sample - a pixel is then one ds_read_b32 + one v_dot2_u32_u16 and the
+    // reference's "base >= max_base -> edge[max_base]" falls out of the same interpolation ((32 e + 16) >> 5 == e)
+    __shared__ __attribute__((aligned(16))) uint32_t s_pair[BIP_WAVES * bpw * 2 * EL];
     const int wv = threadIdx.x >> 6, sub = (threadIdx.x & 63) >> lsh;
     const int lane = threadIdx.x & (LPB - 1);                 // lane inside the block's group
     const uint32_t blk_id = (blockIdx.x * BIP_WAVES + (uint32_t)wv) * (uint32_t)bpw + (uint32_t)sub;
     const bool live = blk_id < nblocks;
     const uint32_t b = live ? (order ? order[blk_id] : blk_id) : (order ? order[0] : 0u);      // a spare group replays a block without storing
-    const BipBlk d = blks[b];
     const PixT* __restrict__ top = top_all + (size_t)b * neigh_pitch + 1;       // element 0 is the corner: top[-1]
     const PixT* __restrict__ left = left_all + (size_t)b * neigh_pitch + 1;
+    // Every global load of the block is issued here, side by side: the descriptor AND the raw w + h samples of both edges (the row
+    // of a block holds them whatever is "available": neigh_pitch >= 1 + 2 max(w, h)).  Which of them count, and what replaces the
+    // others, is applied in LDS below - the first version loaded the descriptor, then the samples it selected (top[min(i, avail - 1)]):
+    // two dependent round trips to HBM in a kernel whose waves do little else than wait for them.
+    constexpr int NR = (W + H + LPB - 1) / LPB;               // rounds of LPB lanes over w + h samples (<= 3)
+    int raw_t[NR], raw_l[NR];
+#pragma unroll
+    for (int t = 0; t < NR; t++) {
+        const int i = lane + t * LPB;
+        raw_t[t] = i < W + H ? (int)top[i] : 0;
+        raw_l[t] = i < W + H ? (int)left[i] : 0;
+    }
+    const int top_m1 = (int)top[-1], top_0 = (int)top[0], left_0 = (int)left[0];
+    const BipBlk d = blks[b];
     uint16_t* A = s_edge + (size_t)((wv * bpw + sub) * 2) * EL + 16;
     uint16_t* L = A + EL;
+    uint32_t* PA = s_pair + (size_t)((wv * bpw + sub) * 2) * EL + 16;
+    uint32_t* PL = PA + EL;
     const int maxv = (1 << bd) - 1, base = 128 << (bd - 8);
 
     const int mode = d.mode > 12 ? 12 : d.mode;
@@ -195,21 +216,36 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
         need_above_left = mode == 12;
         need_right = false; need_bottom = false;
     }
+    // dx / dy of the angled kinds (one table load each, in flight while the edge stages run): zone 1 dx(p), zone 2 dx(180 - p) and
+    // dy(p - 90), zone 3 dy(270 - p); every other argument reads 1
+    const int dx = bip_dr_derivative(p_angle < 90 ? p_angle : 180 - p_angle), dy = bip_dr_derivative(p_angle < 180 ? p_angle - 90 : 270 - p_angle);
     const bool const_fill = (!need_above && n_left == 0) || (!need_left && n_top == 0);
-    const int const_val = need_left ? (n_top > 0 ? (int)top[0] : base + 1) : (n_left > 0 ? (int)left[0] : base - 1);
+    const int const_val = need_left ? (n_top > 0 ? top_0 : base + 1) : (n_left > 0 ? left_0 : base - 1);
 
     // ---- stage 1: edge extension (:3747-3800) -----------------------------------------------------------------
+    // raw samples to LDS, then: a missing edge takes its default, samples past the available run the last available one (that
+    // position is never written in the second phase, so it needs no buffer of its own)
+#pragma unroll
+    for (int t = 0; t < NR; t++) {
+        const int i = lane + t * LPB;
+        if (i < W + H) { A[i] = (uint16_t)raw_t[t]; L[i] = (uint16_t)raw_l[t]; }
+    }
+    wave_lds_fence();
     {
         const int need_l = need_left ? h + (need_bottom ? w : 0) : 0;
         const int avail_l = (need_bottom && n_bl > 0) ? h + n_bl : n_left;
-        const int def_l = n_top > 0 ? (int)top[0] : base + 1;
-        for (int i = lane; i < need_l; i += LPB) L[i] = (uint16_t)(n_left > 0 ? (int)left[min(i, avail_l - 1)] : def_l);
+        const int def_l = n_top > 0 ? top_0 : base + 1;
         const int need_a = need_above ? w + (need_right ? h : 0) : 0;
         const int avail_a = (need_right && n_tr > 0) ? n_top + n_tr : n_top;
-        const int def_a = n_left > 0 ? (int)left[0] : base - 1;
-        for (int i = lane; i < need_a; i += LPB) A[i] = (uint16_t)(n_top > 0 ? (int)top[min(i, avail_a - 1)] : def_a);
+        const int def_a = n_left > 0 ? left_0 : base - 1;
+#pragma unroll
+        for (int t = 0; t < NR; t++) {
+            const int i = lane + t * LPB;
+            if (i < need_l) { if (n_left == 0) L[i] = (uint16_t)def_l; else if (i >= avail_l) L[i] = L[avail_l - 1]; }
+            if (i < need_a) { if (n_top == 0) A[i] = (uint16_t)def_a; else if (i >= avail_a) A[i] = A[avail_a - 1]; }
+        }
         if (lane == 0 && need_above_left) {
-            const int c = (n_top > 0 && n_left > 0) ? (int)top[-1] : (n_top > 0 ? (int)top[0] : (n_left > 0 ? (int)left[0] : base));
+            const int c = (n_top > 0 && n_left > 0) ? top_m1 : (n_top > 0 ? top_0 : (n_left > 0 ? left_0 : base));
             A[-1] = (uint16_t)c; L[-1] = (uint16_t)c;
         }
     }
@@ -287,16 +323,23 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
     }
     // ---- stage 5: prediction ---------------------------------------------------------------------------------------------
     // resolve to one of the predictor kinds
-    int kind, dx = 1, dy = 1;
+    int kind;
     if (const_fill) kind = IM_DC_128;
-    else if (is_dr) {
-        if (p_angle == 90) kind = IM_V;
-        else if (p_angle == 180) kind = IM_H;
-        else if (p_angle < 90) { kind = IM_Z1; dx = bip_dr_derivative(p_angle); }
-        else if (p_angle < 180) { kind = IM_Z2; dx = bip_dr_derivative(180 - p_angle); dy = bip_dr_derivative(p_angle - 90); }
-        else { kind = IM_Z3; dy = bip_dr_derivative(270 - p_angle); }
-    } else if (mode == 0) kind = n_left > 0 ? (n_top > 0 ? IM_DC : IM_DC_LEFT) : (n_top > 0 ? IM_DC_TOP : IM_DC_128);       // dc_pred[left][top], :3851
+    else if (is_dr) kind = p_angle == 90 ? IM_V : (p_angle == 180 ? IM_H : (p_angle < 90 ? IM_Z1 : (p_angle < 180 ? IM_Z2 : IM_Z3))); else if (mode == 0) kind = n_left > 0 ? (n_top > 0 ? IM_DC : IM_DC_LEFT) : (n_top > 0 ? IM_DC_TOP : IM_DC_128);       // dc_pred[left][top], :3851
     else kind = mode == 9 ? IM_SMOOTH : (mode == 10 ? IM_SMOOTH_V : (mode == 11 ? IM_SMOOTH_H : IM_PAETH));
+    // pair form of the edges for the angled kinds (the wave skips it when none of its blocks is one)
+    const bool is_z = kind == IM_Z1 || kind == IM_Z2 || kind == IM_Z3;
+    // last valid staged sample of each edge: without up-sampling [-1, need - 1], with it [-2, 2 need - 2] (av1_upsample_intra_edge);
+    // for zone 1 / 3 that is max_base = (w + h - 1) << up
+    const int need_a_n = need_above ? w + (need_right ? h : 0) : 0, need_l_n = need_left ? h + (need_bottom ? w : 0) : 0;
+    const int last_a = up_a ? 2 * need_a_n - 2 : need_a_n - 1, last_l = up_l ? 2 * need_l_n - 2 : need_l_n - 1;
+    if (__builtin_amdgcn_ballot_w64(is_z) != 0) {
+        if (is_z) {
+            for (int i = lane - 2; i <= last_a; i += LPB) PA[i] = (uint32_t)A[i] | ((uint32_t)A[min(i + 1, last_a)] << 16);
+            for (int i = lane - 2; i <= last_l; i += LPB) PL[i] = (uint32_t)L[i] | ((uint32_t)L[min(i + 1, last_l)] << 16);
+        }
+        wave_lds_fence();
+    }
     int dc = const_fill ? const_val : base;
     if (kind == IM_DC || kind == IM_DC_TOP || kind == IM_DC_LEFT) {
         const int na = kind != IM_DC_LEFT ? w : 0, nl = kind != IM_DC_TOP ? h : 0;
@@ -329,6 +372,10 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
         }
         const int lr = (int)L[r < H ? r : 0];
         const int whr = kSmWeights[h + r];
+        // zone 1 / 2: the row's position on the above edge and its weight pair
+        const int z_x = (kk == IM_Z2 ? -dx : dx) * (r + 1);
+        const int z_b = z_x >> (6 - up_a);
+        const uint32_t z_sh = (uint32_t)(((z_x * (1 << up_a)) & 0x3f) >> 1), z_w = z_sh * 0xffffu + 32u;
         int px[PPL];
 #pragma unroll
         for (int k = 0; k < PPL; k++) {
@@ -349,28 +396,24 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
                 const int pl = abs(pb - l), pt = abs(pb - t), ptl = abs(pb - tl_s);
                 v = (pl <= pt && pl <= ptl) ? l : (pt <= ptl ? t : tl_s);
             } break;
-            case IM_Z1: {     // av1_dr_prediction_z1 (:370 / :3394)
-                const int max_base = (w + h - 1) << up_a;
-                const int x = dx * (r + 1), bs = (x >> (6 - up_a)) + (c << up_a), sh = ((x << up_a) & 0x3f) >> 1;
-                v = bs < max_base ? ((int)A[bs] * (32 - sh) + (int)A[bs + 1] * sh + 16) >> 5 : (int)A[max_base];
-                v = min(v, maxv);
+            case IM_Z1: {     // av1_dr_prediction_z1 (:370 / :3394): base >= max_base reads the pair (e, e) at max_base
+                v = (int)dir_lerp2(PA[min(z_b + (c << up_a), last_a)], z_w);
+                if (sizeof(PixT) == 2) v = min(v, maxv);
             } break;
             case IM_Z3: {     // av1_dr_prediction_z3 (:447 / :3475)
-                const int max_base = (w + h - 1) << up_l;
-                const int y = dy * (c + 1), bs = (y >> (6 - up_l)) + (r << up_l), sh = ((y << up_l) & 0x3f) >> 1;
-                v = bs < max_base ? ((int)L[bs] * (32 - sh) + (int)L[bs + 1] * sh + 16) >> 5 : (int)L[max_base];
-                v = min(v, maxv);
+                const int y = dy * (c + 1), bs = (y >> (6 - up_l)) + (r << up_l);
+                const uint32_t sh = (uint32_t)(((y << up_l) & 0x3f) >> 1);
+                v = (int)dir_lerp2(PL[min(bs, last_l)], sh * 0xffffu + 32u);          // (32 - sh) | sh << 16
+                if (sizeof(PixT) == 2) v = min(v, maxv);
             } break;
             case IM_Z2: {     // av1_dr_prediction_z2 (:405 / :3431)
-                const int x = -dx * (r + 1), base1 = (x >> (6 - up_a)) + (c << up_a);
-                if (base1 >= -(1 << up_a)) {
-                    const int sh = ((x * (1 << up_a)) & 0x3f) >> 1;
-                    v = ((int)A[base1] * (32 - sh) + (int)A[base1 + 1] * sh + 16) >> 5;
-                } else {
-                    const int y = (r << 6) - dy * (c + 1), base2 = y >> (6 - up_l), sh = ((y * (1 << up_l)) & 0x3f) >> 1;
-                    v = ((int)L[base2] * (32 - sh) + (int)L[base2 + 1] * sh + 16) >> 5;
-                }
-                v = min(v, maxv);
+                const int base1 = z_b + (c << up_a);
+                const bool ab = base1 >= -(1 << up_a);
+                const int y = (r << 6) - dy * (c + 1), base2 = y >> (6 - up_l);
+                const uint32_t sh2 = (uint32_t)(((y * (1 << up_l)) & 0x3f) >> 1);
+                const uint32_t* pp = ab ? PA + base1 : PL + base2;
+                v = (int)dir_lerp2(*pp, ab ? z_w : sh2 * 0xffffu + 32u);
+                if (sizeof(PixT) == 2) v = min(v, maxv);
             } break;
             default: v = dc; break;          // IM_DC, IM_DC_TOP, IM_DC_LEFT, IM_DC_128 and the constant fill
             }
