@@ -800,12 +800,15 @@ class SvtHipDsp:
         return dst
 
     def intra_order_blocks(self, blocks, tx_size):
-        """svt_hip_intra_order_blocks_batch: the batch's block indices sorted by predictor kind (device) -> int32 [n]"""
+        """svt_hip_intra_order_blocks_batch: the batch's block indices grouped by predictor kind inside tiles of 4 096 blocks (device)
+        -> int32 [n]"""
         t = self.torch
         n = blocks.shape[0]
         order = t.empty(n, dtype=t.int32, device=blocks.device)
-        work = t.empty(32, dtype=t.int32, device=blocks.device)
         self.lib.svt_hip_intra_order_blocks_batch.argtypes = [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p]
+        work = getattr(self, "_order_work", None)             # unused by the library since round 3 (older builds: 32 counters)
+        if work is None or work.device != blocks.device:
+            work = self._order_work = t.empty(32, dtype=t.int32, device=blocks.device)
         self._check(self.lib.svt_hip_intra_order_blocks_batch(self._p(blocks), tx_size, n, self._p(order), self._p(work), self._stream()),
                     "svt_hip_intra_order_blocks_batch")
         return order

@@ -106,50 +106,47 @@ __device__ __forceinline__ int bip_kind_of(const BipBlk& d, int w, int h, int& p
     return mode == 9 ? IM_SMOOTH : (mode == 10 ? IM_SMOOTH_V : (mode == 11 ? IM_SMOOTH_H : IM_PAETH));
 }
 
-// ---- ordering pass: block indices sorted by kind (counting sort over IM_MODES = 13 bins; the order inside a bin is whatever the
-// atomics give - the prediction of a block does not depend on its place in the order) ------------------------------------------
-// (a workgroup takes BIP_ORDER_ITEMS blocks per lane: with one block per lane the 13 global counters took 13 atomics from each of
-// 4 096 workgroups of a 2^20-block batch - 50 us per pass, a third of the whole call)
-constexpr int BIP_ORDER_ITEMS = 16;
-__global__ __launch_bounds__(256) void bip_order_count_kernel(const BipBlk* __restrict__ blks, int w, int h, uint32_t* __restrict__ counters /* [16 count | 16 cursor] */,
-                                                              uint32_t nblocks) {
-    __shared__ uint32_t s_cnt[16];
-    if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * (256u * BIP_ORDER_ITEMS);
-#pragma unroll 4
-    for (int k = 0; k < BIP_ORDER_ITEMS; k++) {
-        const uint32_t i = base + k * 256u + threadIdx.x;
-        if (i < nblocks) { int pa; atomicAdd(&s_cnt[bip_kind_of(blks[i], w, h, pa)], 1u); }
-    }
-    __syncthreads();
-    if (threadIdx.x < 16 && s_cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], s_cnt[threadIdx.x]);
-}
-__global__ __launch_bounds__(256) void bip_order_scatter_kernel(const BipBlk* __restrict__ blks, int w, int h, uint32_t* __restrict__ counters,
-                                                                uint32_t* __restrict__ order, uint32_t nblocks) {
+// ---- ordering pass: block indices grouped by kind inside TILES of BIP_ORDER_TILE consecutive blocks (a counting sort over the
+// IM_MODES = 13 bins in LDS; the order inside a bin is whatever the atomics give - the prediction of a block does not depend on its
+// place in the order).  One kernel, no global counters: the first version sorted the whole batch (count kernel + scatter kernel, 17 +
+// 20 us per 2^20 blocks, each a single residency round of 256 workgroups waiting on 13 contended global atomics); a wave only needs
+// ITS four blocks to share a kind, and a tile of 4 096 blocks holds ~ 315 of each, so the waves of a tile are uniform except at its
+// (at most 12) kind boundaries - 1.2 % of the waves; a mixed wave runs every kind it holds, several times a uniform wave's cost
+// (tiles of 1 024 blocks measured no faster than the global sort for that reason).  1 024 threads per workgroup: 256 workgroups of
+// 16 waves keep enough loads in flight.
+constexpr int BIP_ORDER_ITEMS = 4;
+constexpr int BIP_ORDER_THREADS = 1024;
+constexpr int BIP_ORDER_TILE = BIP_ORDER_THREADS * BIP_ORDER_ITEMS;
+__global__ __launch_bounds__(BIP_ORDER_THREADS) void bip_order_tile_kernel(const BipBlk* __restrict__ blks, int w, int h, uint32_t* __restrict__ order, uint32_t nblocks) {
     __shared__ uint32_t s_cnt[16], s_base[16];
     if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * (256u * BIP_ORDER_ITEMS);
-    uint8_t kind[BIP_ORDER_ITEMS];
-    uint16_t local[BIP_ORDER_ITEMS];
+    const uint32_t base = blockIdx.x * (uint32_t)BIP_ORDER_TILE;
+    BipBlk d[BIP_ORDER_ITEMS];
+#pragma unroll
+    for (int k = 0; k < BIP_ORDER_ITEMS; k++) {                 // the tile's descriptors, coalesced, all loads in flight together
+        const uint32_t i = base + k * (uint32_t)BIP_ORDER_THREADS + threadIdx.x;
+        d[k] = blks[i < nblocks ? i : 0u];
+    }
+    uint32_t kind[BIP_ORDER_ITEMS], local[BIP_ORDER_ITEMS];
 #pragma unroll
     for (int k = 0; k < BIP_ORDER_ITEMS; k++) {
-        const uint32_t i = base + k * 256u + threadIdx.x;
-        kind[k] = 0; local[k] = 0;
-        if (i < nblocks) { int pa; kind[k] = (uint8_t)bip_kind_of(blks[i], w, h, pa); local[k] = (uint16_t)atomicAdd(&s_cnt[kind[k]], 1u); }
+        const uint32_t i = base + k * (uint32_t)BIP_ORDER_THREADS + threadIdx.x;
+        int pa;
+        kind[k] = (uint32_t)bip_kind_of(d[k], w, h, pa);
+        local[k] = i < nblocks ? atomicAdd(&s_cnt[kind[k]], 1u) : 0u;
     }
     __syncthreads();
-    if (threadIdx.x < 16 && s_cnt[threadIdx.x]) {
-        uint32_t start = 0;                                   // bin start = sum of the counts of the bins before it
-        for (int k = 0; k < (int)threadIdx.x; k++) start += counters[k];
-        s_base[threadIdx.x] = start + atomicAdd(&counters[16 + threadIdx.x], s_cnt[threadIdx.x]);
+    if (threadIdx.x < 16) {
+        uint32_t start = 0;                                     // bin start = the counts of the bins before it
+        for (int k = 0; k < (int)threadIdx.x; k++) start += s_cnt[k];
+        s_base[threadIdx.x] = start;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < BIP_ORDER_ITEMS; k++) {
-        const uint32_t i = base + k * 256u + threadIdx.x;
-        if (i < nblocks) order[s_base[kind[k]] + local[k]] = i;
+        const uint32_t i = base + k * (uint32_t)BIP_ORDER_THREADS + threadIdx.x;
+        if (i < nblocks) order[base + s_base[kind[k]] + local[k]] = i;
     }
 }
 
@@ -289,8 +286,10 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
     }
     wave_lds_fence();
     // ---- stage 4: 2x up-sampling (av1_upsample_intra_edge, :3597): p[-2 .. 2 sz - 2] from p[-1 .. sz - 1] ---------------
-    const int up_a = (filt && need_above) ? bip_use_upsample(w, h, p_angle - 90, ft) : 0;
-    const int up_l = (filt && need_left) ? bip_use_upsample(h, w, p_angle - 180, ft) : 0;
+    // (use_intra_edge_upsample is 0 for every block with w + h > 16: there the shifts below are compile-time constants)
+    constexpr bool CAN_UP = W + H <= 16;
+    const int up_a = (CAN_UP && filt && need_above) ? bip_use_upsample(w, h, p_angle - 90, ft) : 0;
+    const int up_l = (CAN_UP && filt && need_left) ? bip_use_upsample(h, w, p_angle - 180, ft) : 0;
     if (w + h <= 16 && __builtin_amdgcn_ballot_w64((up_a | up_l) != 0) != 0) {
         const int sza = w + (need_right ? h : 0), szl = h + (need_bottom ? w : 0);                 // <= 16 when up-sampling
         int ia[2][4], il[2][4];                                 // two rounds of LPB lanes: sz <= 16 <= 2 * LPB wherever the edge is up-sampled
@@ -334,10 +333,10 @@ __global__ __launch_bounds__(64 * BIP_WAVES) void bip_kernel(
     const int need_a_n = need_above ? w + (need_right ? h : 0) : 0, need_l_n = need_left ? h + (need_bottom ? w : 0) : 0;
     const int last_a = up_a ? 2 * need_a_n - 2 : need_a_n - 1, last_l = up_l ? 2 * need_l_n - 2 : need_l_n - 1;
     if (__builtin_amdgcn_ballot_w64(is_z) != 0) {
-        if (is_z) {
+        if (is_z && kind != IM_Z3)
             for (int i = lane - 2; i <= last_a; i += LPB) PA[i] = (uint32_t)A[i] | ((uint32_t)A[min(i + 1, last_a)] << 16);
+        if (is_z && kind != IM_Z1)
             for (int i = lane - 2; i <= last_l; i += LPB) PL[i] = (uint32_t)L[i] | ((uint32_t)L[min(i + 1, last_l)] << 16);
-        }
         wave_lds_fence();
     }
     int dc = const_fill ? const_val : base;

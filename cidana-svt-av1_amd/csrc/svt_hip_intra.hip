@@ -415,15 +415,14 @@ extern "C" int svt_hip_intra_order_blocks_batch(const svt_hip_intra_blk* d_block
                                                 uint32_t* d_work, void* stream) {
     if (int rc = require_init()) return rc;
     if (nblocks == 0) return SVT_HIP_OK;
-    if (!d_blocks || !d_order || !d_work) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
+    static_assert(BIP_ORDER_TILE == SVT_HIP_INTRA_ORDER_TILE, "header constant");
+    (void)d_work;                                             // (the first version's global counters; unused)
+    if (!d_blocks || !d_order) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
     if (tx_size < 0 || tx_size >= SVT_TX_SIZES_ALL) return set_err(SVT_HIP_ERR_INVALID, "tx_size %d", tx_size);
     if (nblocks > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "too many blocks");
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(d_work, 0, 32 * sizeof(uint32_t), s));
-    const dim3 grid((uint32_t)((nblocks + 256 * BIP_ORDER_ITEMS - 1) / (256 * BIP_ORDER_ITEMS)));
-    hipLaunchKernelGGL(bip_order_count_kernel, grid, dim3(256), 0, s, (const BipBlk*)d_blocks, kTxW[tx_size], kTxH[tx_size], d_work, (uint32_t)nblocks);
-    hipLaunchKernelGGL(bip_order_scatter_kernel, grid, dim3(256), 0, s, (const BipBlk*)d_blocks, kTxW[tx_size], kTxH[tx_size], d_work, d_order,
-                       (uint32_t)nblocks);
+    const dim3 grid((uint32_t)((nblocks + BIP_ORDER_TILE - 1) / BIP_ORDER_TILE));
+    hipLaunchKernelGGL(bip_order_tile_kernel, grid, dim3(BIP_ORDER_THREADS), 0, s, (const BipBlk*)d_blocks, kTxW[tx_size], kTxH[tx_size], d_order, (uint32_t)nblocks);
     return launch_status("intra_order_blocks");
 }
 

@@ -649,10 +649,13 @@ int svt_hip_build_intra_predictors_batch(void *d_dst, int32_t dst_stride, size_t
                                          const void *d_left_neigh, int32_t neigh_pitch,
                                          const svt_hip_intra_blk *d_blocks, int tx_size, int is_16bit, int bd,
                                          size_t nblocks, void *stream);
-/* The same walked through an ORDER of the batch (d_order[i] = block index): svt_hip_intra_order_blocks_batch sorts the block
+/* The same walked through an ORDER of the batch (d_order[i] = block index): svt_hip_intra_order_blocks_batch groups the block
  * indices by the predictor kind each descriptor resolves to (DC variants, V, H, SMOOTH*, PAETH, the three directional zones),
- * on the device, so that the lanes of a wave run one kind's code (mixed kinds in a wave are correct, just slower: a wave runs
- * every kind it holds).  d_order: uint32[nblocks]; d_work: 32 uint32 of scratch counters.  Results do not depend on the order. */
+ * on the device, inside tiles of SVT_HIP_INTRA_ORDER_TILE consecutive blocks (entries [t * TILE, (t + 1) * TILE) of d_order are a
+ * permutation of those block indices, kinds contiguous), so that the lanes of a wave run one kind's code (mixed kinds in a wave
+ * are correct, just slower: a wave runs every kind it holds).  d_order: uint32[nblocks]; d_work: unused (may be NULL; the first
+ * version's counters).  Results do not depend on the order. */
+#define SVT_HIP_INTRA_ORDER_TILE 4096
 int svt_hip_intra_order_blocks_batch(const svt_hip_intra_blk *d_blocks, int tx_size, size_t nblocks, uint32_t *d_order,
                                      uint32_t *d_work, void *stream);
 int svt_hip_build_intra_predictors_ordered_batch(void *d_dst, int32_t dst_stride, size_t dst_block_pitch,

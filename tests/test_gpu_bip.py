@@ -130,14 +130,14 @@ def test_build_intra_predictors_argument_errors(dsp, pkg):
 
 @pytest.mark.parametrize("is16", [0, 1])
 def test_ordered_batch_equals_plain_batch_and_order_is_sorted_by_kind(dsp, is16):
-    """svt_hip_intra_order_blocks_batch: a permutation of the batch's block indices, grouped by predictor kind (so that a wave runs one
-    kind's code); svt_hip_build_intra_predictors_ordered_batch through it writes exactly what the plain call writes (every size)"""
+    """svt_hip_intra_order_blocks_batch: a permutation of the batch's block indices, grouped by predictor kind inside tiles of 4 096 blocks (so that a
+    wave runs one kind's code); svt_hip_build_intra_predictors_ordered_batch through it writes exactly what the plain call writes (every size)"""
     rng = np.random.default_rng(91 + is16)
     bd = 10 if is16 else 8
     dt = np.uint16 if is16 else np.uint8
     for tx in range(19):
         w, h = TX_W[tx], TX_H[tx]
-        n = 3001
+        n = 3001 if tx % 5 else 9001
         tops = rng.integers(0, 1 << bd, (n, 16 + 160)).astype(dt); lefts = rng.integers(0, 1 << bd, (n, 16 + 160)).astype(dt)
         blks = np.zeros((n, 8), np.uint8)
         blks[:, 0] = rng.integers(0, 13, n)
@@ -164,5 +164,10 @@ def test_ordered_batch_equals_plain_batch_and_order_is_sorted_by_kind(dsp, is16)
             if m == 0:
                 return ("dc" if nt else "dl") if nl else ("dt" if nt else "c")
             return "m%d" % m
-        ks = [kind(blks[i]) for i in o]
-        assert sum(1 for a, b in zip(ks, ks[1:]) if a != b) <= 12, tx
+        # grouped inside tiles of SVT_HIP_INTRA_ORDER_TILE blocks: every tile is a permutation of its own indices and the (coarse)
+        # kind of the blocks along it changes at most 12 times
+        for t0 in range(0, n, 4096):
+            tile = o[t0:t0 + 4096]
+            assert sorted(tile.tolist()) == list(range(t0, min(n, t0 + 4096))), (tx, t0)
+            ks = [kind(blks[i]) for i in tile]
+            assert sum(1 for a, b in zip(ks, ks[1:]) if a != b) <= 12, (tx, t0)
