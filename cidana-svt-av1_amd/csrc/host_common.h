@@ -34,6 +34,7 @@ extern int g_tune_no_q16;
 extern int g_tune_q2_su4;
 extern int g_tune_ois_no_fold;
 extern int g_tune_ois_no_dir3;
+extern int g_tune_ois_no_nd_multi;
 extern int g_tune_ois_no_nd;
 extern int g_tune_dir_no_split, g_tune_dir_split_target;
 extern int g_tune_me_exact;
@@ -133,6 +134,8 @@ struct FanOut {
         if (ready) return SVT_HIP_OK;
         HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
         for (int i = 0; i < kFanStreams; i++) {
+            // (plain streams: creating stream 0 with hipStreamCreateWithPriority(.., greatest) made svt_hip_ois_search_frame FOUR times
+            // slower on this runtime - 0.55 against 0.13 ms per 1080p picture, A/B on one box)
             HIP_TRY(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&join[i], hipEventDisableTiming));
         }

@@ -17,16 +17,16 @@ namespace svtdev {
 
 constexpr int OIS_NB_ORIGIN = 16;      // == NB_ORIGIN of kernel_intra.h (position p of an edge at index 16 + p)
 
-__global__ __launch_bounds__(256) void ois_gather_kernel(const uint8_t* __restrict__ pic, uint32_t stride, uint32_t width,
-                                                         uint32_t height, const uint32_t* __restrict__ xy, uint32_t bsize,
-                                                         uint8_t* __restrict__ above, uint8_t* __restrict__ left, uint32_t nb_pitch,
-                                                         uint8_t* __restrict__ dc, uint32_t nblocks) {
+__device__ __forceinline__ void ois_gather_body(const uint8_t* __restrict__ pic, uint32_t stride, uint32_t width,
+                                                uint32_t height, const uint32_t* __restrict__ xy, uint32_t bsize,
+                                                uint8_t* __restrict__ above, uint8_t* __restrict__ left, uint32_t nb_pitch,
+                                                uint8_t* __restrict__ dc, uint32_t nblocks, const uint32_t bid) {
     __shared__ int s_sum[16];
     const uint32_t lpb = 2 * bsize;                      // 16 .. 128 lanes per block
     const uint32_t lsh = __builtin_ctz(lpb);
     const uint32_t slot = threadIdx.x >> lsh, l = threadIdx.x & (lpb - 1);
     const uint32_t slots = 256u >> lsh;
-    const uint32_t blk = blockIdx.x * slots + slot;
+    const uint32_t blk = bid * slots + slot;
     if (threadIdx.x < 16) s_sum[threadIdx.x] = 0;
     __syncthreads();
     const bool valid = blk < nblocks;
@@ -67,6 +67,31 @@ __global__ __launch_bounds__(256) void ois_gather_kernel(const uint8_t* __restri
         else v = 128;
         dc[blk] = (uint8_t)v;
     }
+}
+__global__ __launch_bounds__(256) void ois_gather_kernel(const uint8_t* __restrict__ pic, uint32_t stride, uint32_t width,
+                                                         uint32_t height, const uint32_t* __restrict__ xy, uint32_t bsize,
+                                                         uint8_t* __restrict__ above, uint8_t* __restrict__ left, uint32_t nb_pitch,
+                                                         uint8_t* __restrict__ dc, uint32_t nblocks) {
+    ois_gather_body(pic, stride, width, height, xy, bsize, above, left, nb_pitch, dc, nblocks, blockIdx.x);
+}
+// the gathers of every block size of a picture in one launch (svt_hip_ois_search_frame)
+constexpr int OIS_GATHER_MAX_GROUPS = 4;
+struct OisGatherGroup {
+    const uint32_t* xy; uint8_t* above; uint8_t* left; uint8_t* dc;
+    uint32_t bsize, nb_pitch, nblocks, wg_end;
+};
+struct OisGatherMulti { int32_t ngroups; OisGatherGroup g[OIS_GATHER_MAX_GROUPS]; };
+__global__ __launch_bounds__(256) void ois_gather_multi_kernel(const uint8_t* __restrict__ pic, uint32_t stride, uint32_t width, uint32_t height,
+                                                               const OisGatherMulti m) {
+    int gi = 0;
+    uint32_t start = 0;
+#pragma unroll 1
+    for (int i = 0; i < m.ngroups; i++) {
+        if (blockIdx.x >= m.g[i].wg_end) { gi = i + 1; start = m.g[i].wg_end; }
+    }
+    if (gi >= m.ngroups) return;
+    const OisGatherGroup& G = m.g[gi];
+    ois_gather_body(pic, stride, width, height, G.xy, G.bsize, G.above, G.left, G.nb_pitch, G.dc, G.nblocks, blockIdx.x - start);
 }
 
 // One launch for ALL candidates: pred_all holds ncand dense prediction batches back to back (a candidate whose bit
@@ -168,16 +193,18 @@ __device__ constexpr uint8_t kOisSmWeights[128] = {          // sm_weight_arrays
     65, 61, 57, 54, 50, 47, 44, 41, 38, 35, 32, 29, 27, 25, 22, 20,
     18, 16, 15, 13, 12, 10, 9, 8, 7, 6, 6, 5, 5, 4, 4, 4};
 
+// (a device body: ois_nd_kernel runs it for one block size, ois_nd_multi_kernel for every size of a picture in one launch; `bid` is
+// the workgroup's index inside its group, `kinds` a reference into the kernel arguments)
 template <int CS>            // pixels per lane: 8 (8x8 blocks) or 16
-__global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__ pic, uint32_t stride, uint32_t width, uint32_t height,
-                                                     const uint32_t* __restrict__ xy, uint32_t bsize, OisKinds kinds, uint32_t* dist,
-                                                     int8_t* __restrict__ best_index, uint32_t ncand, uint32_t nblocks) {
+__device__ __forceinline__ void ois_nd_body(const uint8_t* __restrict__ pic, uint32_t stride, uint32_t width, uint32_t height,
+                                            const uint32_t* __restrict__ xy, uint32_t bsize, const OisKinds& kinds, uint32_t* dist,
+                                            int8_t* __restrict__ best_index, uint32_t ncand, uint32_t nblocks, const uint32_t bid) {
     extern __shared__ uint32_t s_dist[];                  // [slots][ncand] (+ [4][ncand] wave partials and 4 DC partials for 64x64)
     const uint32_t lpb = bsize * bsize / CS;              // 8, 16, 64, 256
     const uint32_t lsh = __builtin_ctz(lpb);
     const uint32_t slots = 256u >> lsh;
     const uint32_t slot = threadIdx.x >> lsh, l = threadIdx.x & (lpb - 1);
-    const uint32_t blk = blockIdx.x * slots + slot;
+    const uint32_t blk = bid * slots + slot;
     const bool valid = blk < nblocks;
     const uint32_t q = xy[valid ? blk : 0];
     const uint32_t x = q & 0xffffu, y = q >> 16;
@@ -188,7 +215,7 @@ __global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__
     // ---- the sums the directional kernels left in dist (kind OIS_K_FOLDED): the workgroup's contiguous run of rows in one coalesced
     // pass, issued before everything else.  (Fetching them one candidate at a time inside the loop below was a chain of up to 38
     // dependent global loads per wave - two thirds of this kernel's time on the 8x8 list.)  The loop overwrites the other entries.
-    const uint32_t first = blockIdx.x * slots;
+    const uint32_t first = bid * slots;
     const uint32_t nb_here = first < nblocks ? (nblocks - first < slots ? nblocks - first : slots) : 0;
     if (kinds.k[OIS_MAX_CAND + 2])                         // host: set when the list has a folded candidate
         for (uint32_t i = threadIdx.x; i < nb_here * ncand; i += 256) s_dist[i] = dist[(size_t)first * ncand + i];
@@ -199,10 +226,18 @@ __global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__
         av[2] = av[3] = 0;
         __builtin_memcpy(av, sblk - (ptrdiff_t)stride + col, CS);
     } else {
-        uint8_t t[16];
+        // (a block that reaches past the picture, or no row above: never the encoder's own blocks.  A rolled byte loop: unrolled, its
+        // sixteen conditional loads and their 64-bit addresses set the whole kernel's register count - 132 VGPRs, 3 waves per SIMD)
 #pragma unroll
-        for (int k = 0; k < 16; k++) t[k] = (k < CS && has_a && x + col + k < width) ? sblk[(ptrdiff_t)(col + k) - (ptrdiff_t)stride] : (uint8_t)127;
-        __builtin_memcpy(av, t, 16);
+        for (int j = 0; j < 4; j++) {
+            uint32_t wv = j < CS / 4 ? 0x7f7f7f7fu : 0u;
+            if (j < CS / 4 && has_a) {
+#pragma unroll 1
+                for (uint32_t b = 0; b < 4; b++)
+                    if (x + col + 4 * j + b < width) wv = (wv & ~(0xffu << (8 * b))) | ((uint32_t)sblk[(ptrdiff_t)(col + 4 * j + b) - (ptrdiff_t)stride] << (8 * b));
+            }
+            av[j] = wv;
+        }
     }
     auto left_at = [&](uint32_t r) { return (has_l && y + r < height) ? (int)sblk[(size_t)r * stride - 1] : 129; };
     auto above_at = [&](uint32_t c) { return (has_a && x + c < width) ? (int)sblk[(ptrdiff_t)c - (ptrdiff_t)stride] : 127; };
@@ -227,8 +262,14 @@ __global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__
     __builtin_memcpy(wwv, kOisSmWeights + bsize + col, CS);
     if (lpb <= 64) __syncthreads();                        // the copy above before this loop's stores (64x64: the barrier above)
     // ---- candidates -------------------------------------------------------------------------------------------------------------
+#pragma unroll 1
     for (uint32_t i = 0; i < kinds.n_nd; i++) {
         const uint32_t kind = kinds.nd_kind[i], c = kinds.nd_c[i];       // uniform (kernel arguments)
+        // the packed above samples and column weights are re-read as "changed" every round: left to itself the compiler unpacks all
+        // 16 + 16 of them (and their complements) once, outside this loop, and the 16-pixel form then needs 122 VGPRs - 4 waves per
+        // SIMD in a kernel that is one wave's latency chain
+#pragma unroll
+        for (int q = 0; q < CS / 4; q++) asm volatile("" : "+v"(av[q]), "+v"(wwv[q]));
         uint32_t pv[4] = {0, 0, 0, 0};
         if (kind == OIS_K_DC) { pv[0] = pv[1] = pv[2] = pv[3] = (uint32_t)dcv * 0x01010101u; }
         else if (kind == OIS_K_V) { pv[0] = av[0]; pv[1] = av[1]; pv[2] = av[2]; pv[3] = av[3]; }
@@ -281,6 +322,37 @@ __global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__
         }
         best_index[first + threadIdx.x] = (int8_t)bi;
     }
+}
+
+template <int CS>
+__global__ __launch_bounds__(256) void ois_nd_kernel(const uint8_t* __restrict__ pic, uint32_t stride, uint32_t width, uint32_t height,
+                                                     const uint32_t* __restrict__ xy, uint32_t bsize, OisKinds kinds, uint32_t* dist,
+                                                     int8_t* __restrict__ best_index, uint32_t ncand, uint32_t nblocks) {
+    ois_nd_body<CS>(pic, stride, width, height, xy, bsize, kinds, dist, best_index, ncand, nblocks, blockIdx.x);
+}
+
+// The non-directional launches of EVERY block size of a picture in one (svt_hip_ois_search_frame): as four launches the 32x32 and
+// 64x64 lists (five candidates, ~ 500 workgroups, one wave's latency chain: ~ 20 us each) neither hid behind the 8x8 / 16x16 chains on
+// a side stream (those fill the GPU; the call cost the SUM of its groups) nor amortised anything.  Group table in the kernel arguments.
+constexpr int OIS_ND_MAX_GROUPS = 4;
+struct OisNdGroup {
+    const uint32_t* xy; uint32_t* dist; int8_t* best_index;
+    uint32_t bsize, ncand, nblocks, wg_end;
+    OisKinds kinds;
+};
+struct OisNdMulti { int32_t ngroups; OisNdGroup g[OIS_ND_MAX_GROUPS]; };
+__global__ __launch_bounds__(256) void ois_nd_multi_kernel(const uint8_t* __restrict__ pic, uint32_t stride, uint32_t width, uint32_t height,
+                                                           const OisNdMulti m) {
+    int gi = 0;
+    uint32_t start = 0;
+#pragma unroll 1
+    for (int i = 0; i < m.ngroups; i++) {
+        if (blockIdx.x >= m.g[i].wg_end) { gi = i + 1; start = m.g[i].wg_end; }
+    }
+    if (gi >= m.ngroups) return;
+    const OisNdGroup& G = m.g[gi];
+    if (G.bsize < 16) ois_nd_body<8>(pic, stride, width, height, G.xy, G.bsize, G.kinds, G.dist, G.best_index, G.ncand, G.nblocks, blockIdx.x - start);
+    else ois_nd_body<16>(pic, stride, width, height, G.xy, G.bsize, G.kinds, G.dist, G.best_index, G.ncand, G.nblocks, blockIdx.x - start);
 }
 
 }  // namespace svtdev

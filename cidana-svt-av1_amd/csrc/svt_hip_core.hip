@@ -22,6 +22,7 @@ int g_tune_no_q16 = 0;
 int g_tune_q2_su4 = 0;
 int g_tune_ois_no_fold = 0;
 int g_tune_ois_no_dir3 = 0;
+int g_tune_ois_no_nd_multi = 0;
 int g_tune_ois_no_nd = 0;
 int g_tune_dir_no_split = 0;
 int g_tune_dir_split_target = 4;         // workgroups per CU below which the directional kernels spread their angles over grid.y (swept 1 .. 16 on the 1080p search: 3-4 is the minimum for 8x8 and 16x16)
@@ -120,6 +121,7 @@ extern "C" int svt_hip_tune(const char* key, int value) {
     if (!strcmp(key, "q2_su4")) { g_tune_q2_su4 = value; return SVT_HIP_OK; }
     if (!strcmp(key, "ois_no_fold")) { g_tune_ois_no_fold = value; return SVT_HIP_OK; }
     if (!strcmp(key, "ois_no_dir3")) { g_tune_ois_no_dir3 = value; return SVT_HIP_OK; }
+    if (!strcmp(key, "ois_no_nd_multi")) { g_tune_ois_no_nd_multi = value; return SVT_HIP_OK; }
     if (!strcmp(key, "ois_no_nd")) { g_tune_ois_no_nd = value; return SVT_HIP_OK; }
     if (!strcmp(key, "dir_no_split")) { g_tune_dir_no_split = value; return SVT_HIP_OK; }
     if (!strcmp(key, "dir_split_target")) { g_tune_dir_split_target = value > 0 ? value : 1; return SVT_HIP_OK; }

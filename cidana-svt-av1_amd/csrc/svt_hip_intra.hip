@@ -493,10 +493,16 @@ static int ois_dir3_launch(const uint8_t* d_above, const uint8_t* d_left, size_t
     return launch_status("ois_dir3");
 }
 
-extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, uint32_t width, uint32_t height,
-                                        const uint32_t* d_xy, uint32_t bsize, const uint8_t* modes, const int8_t* angle_deltas,
-                                        int ncand, uint32_t* d_distortion, int8_t* d_best_index, void* d_work,
-                                        size_t work_bytes, size_t nblocks, void* stream) {
+// `defer` (svt_hip_ois_search_frame): the non-directional launch of the group is not enqueued but described in *defer (nblocks != 0),
+// so that the caller can run every group's in ONE launch (ois_nd_multi_kernel) after the chains it depends on
+static int ois_search_impl(const uint8_t* d_pic, uint32_t stride, uint32_t width, uint32_t height,
+                           const uint32_t* d_xy, uint32_t bsize, const uint8_t* modes, const int8_t* angle_deltas,
+                           int ncand, uint32_t* d_distortion, int8_t* d_best_index, void* d_work,
+                           size_t work_bytes, size_t nblocks, void* stream, OisNdGroup* defer, int phase = 0, OisGatherGroup* gather = nullptr) {
+    // phase 0: everything; 1: enqueue nothing, describe the group's neighbour gather in *gather (nblocks != 0) if it takes the fused
+    // path; 2: the gather has been done by the caller (fused path), enqueue the rest
+    if (defer) defer->nblocks = 0;
+    if (gather) gather->nblocks = 0;
     if (int rc = require_init()) return rc;
     if (nblocks == 0) return SVT_HIP_OK;
     if (!d_pic || !d_xy || !d_distortion || !d_best_index || !d_work || !modes || !angle_deltas) return set_err(SVT_HIP_ERR_INVALID, "NULL buffer");
@@ -552,9 +558,16 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
                 uint8_t* d_dc = d_left + ois_align(nblocks * pitch);
                 // (no clearing of the neighbour arrays: the directional kernels stage positions [-2, 2 * bsize) only, all written by the gather)
                 const uint32_t slots = 256 / (2 * bsize);
-                hipLaunchKernelGGL(ois_gather_kernel, dim3((uint32_t)((nblocks + slots - 1) / slots)), dim3(256), 0, st, d_pic, stride, width,
-                                   height, d_xy, bsize, d_above, d_left, (uint32_t)pitch, d_dc, (uint32_t)nblocks);
-                if (int rc = launch_status("ois_gather")) return rc;
+                if (phase == 1) {
+                    gather->xy = d_xy; gather->above = d_above; gather->left = d_left; gather->dc = d_dc; gather->bsize = bsize;
+                    gather->nb_pitch = (uint32_t)pitch; gather->nblocks = (uint32_t)nblocks; gather->wg_end = (uint32_t)((nblocks + slots - 1) / slots);
+                    return SVT_HIP_OK;
+                }
+                if (phase == 0) {
+                    hipLaunchKernelGGL(ois_gather_kernel, dim3((uint32_t)((nblocks + slots - 1) / slots)), dim3(256), 0, st, d_pic, stride, width,
+                                       height, d_xy, bsize, d_above, d_left, (uint32_t)pitch, d_dc, (uint32_t)nblocks);
+                    if (int rc = launch_status("ois_gather")) return rc;
+                }
                 DirMulti zone[3];
                 for (auto& z : zone) {
                     z.n = 0; z.batch_pitch = 0;
@@ -586,10 +599,16 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
                 } else
                     for (int zi = 0; zi < 3; zi++) if (int rc = flush(zi)) return rc;
             }
+            if (phase == 1) return SVT_HIP_OK;
             const uint32_t cs = bsize < 16 ? 8 : 16, lpb = bsize * bsize / cs;
             const uint32_t nd_slots = 256 / lpb;
             const uint32_t nd_grid = (uint32_t)((nblocks + nd_slots - 1) / nd_slots);
             const size_t shmem = (((size_t)nd_slots + (lpb > 64 ? 4 : 0)) * (size_t)ncand + 4) * sizeof(uint32_t);
+            if (defer) {
+                defer->xy = d_xy; defer->dist = d_distortion; defer->best_index = d_best_index; defer->bsize = bsize; defer->ncand = (uint32_t)ncand;
+                defer->nblocks = (uint32_t)nblocks; defer->wg_end = nd_grid /* the caller turns it into a running end */; defer->kinds = kinds;
+                return SVT_HIP_OK;
+            }
             if (cs == 8)
                 hipLaunchKernelGGL(ois_nd_kernel<8>, dim3(nd_grid), dim3(256), shmem, st, d_pic, stride, width, height, d_xy, bsize, kinds, d_distortion,
                                    d_best_index, (uint32_t)ncand, (uint32_t)nblocks);
@@ -599,6 +618,7 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
             return launch_status("ois_nd");
         }
     }
+    if (phase == 1) return SVT_HIP_OK;                    // (the general path below gathers for itself, in phase 2)
     uint8_t* d_above = (uint8_t*)w;
     uint8_t* d_left = d_above + ois_align(nblocks * pitch);
     uint8_t* d_dc = d_left + ois_align(nblocks * pitch);
@@ -671,46 +691,91 @@ extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, u
     return launch_status("ois_sad");
 }
 
+extern "C" int svt_hip_ois_search_batch(const uint8_t* d_pic, uint32_t stride, uint32_t width, uint32_t height,
+                                        const uint32_t* d_xy, uint32_t bsize, const uint8_t* modes, const int8_t* angle_deltas,
+                                        int ncand, uint32_t* d_distortion, int8_t* d_best_index, void* d_work,
+                                        size_t work_bytes, size_t nblocks, void* stream) {
+    return ois_search_impl(d_pic, stride, width, height, d_xy, bsize, modes, angle_deltas, ncand, d_distortion, d_best_index, d_work, work_bytes,
+                           nblocks, stream, nullptr);
+}
+
 extern "C" int svt_hip_ois_search_frame(const uint8_t* d_pic, uint32_t stride, uint32_t width, uint32_t height,
                                         const svt_hip_ois_group* groups, int ngroups, void* stream) {
     if (int rc = require_init()) return rc;
     if (ngroups == 0) return SVT_HIP_OK;
     if (!groups || ngroups < 0 || ngroups > 64) return set_err(SVT_HIP_ERR_INVALID, "group list");
-    // Groups whose list has a directional candidate are a chain of VALU-bound launches that fill the GPU: they run one after the
-    // other on the caller's stream (spreading them over streams measured SLOWER: 0.198 against 0.175 ms per 1080p picture - fork /
-    // join events and no idle units to win).  Groups without one (every 32x32 / 64x64 list) are ONE small latency-bound launch
-    // each (~20 us for ~500 workgroups): those go to one side stream and hide behind the chain.
-    static const int mode_angle[9] = {0, 90, 180, 45, 135, 113, 157, 203, 67};
-    auto light = [&](const svt_hip_ois_group& G) {
-        for (int c = 0; c < G.ncand; c++)
-            if (G.modes[c] >= 1 && G.modes[c] <= 8) {
-                const int a = mode_angle[G.modes[c]] + 3 * G.angle_deltas[c];
-                if (a != 90 && a != 180) return false;
-            }
-        return true;
-    };
-    int nlight = 0, nheavy = 0;
-    for (int g = 0; g < ngroups; g++)
-        if (groups[g].nblocks && groups[g].modes && groups[g].angle_deltas) { if (light(groups[g])) nlight++; else nheavy++; }
+    // Every group's chain (neighbour gather, the three directional zones in one launch) goes out on the caller's stream, one after
+    // the other - each fills the GPU - and the non-directional launch of EVERY group, which also takes each block's best index,
+    // follows as ONE launch (ois_nd_multi_kernel).  Round 2 ran the single-launch groups (every 32x32 / 64x64 list) on a side stream;
+    // they did not hide behind the chains (the call cost 0.134 ms per 1080p picture against 0.140 for the four groups in sequence:
+    // the chains leave no free units), so the side stream, its fork / join events and two ~ 20 us latency-bound launches are gone.
+    // (svt_hip_tune("ois_no_nd_multi", 1): one non-directional launch per group, on the caller's stream.)
     hipStream_t s = (hipStream_t)stream;
-    const bool side = nlight > 0 && nheavy > 0;
-    if (side) {
-        if (int rc = t_fan.ensure()) return rc;
-        HIP_TRY(hipEventRecord(t_fan.fork, s));
-        HIP_TRY(hipStreamWaitEvent(t_fan.s[0], t_fan.fork, 0));
+    OisNdMulti m;
+    memset(&m, 0, sizeof(m));
+    uint32_t total = 0;
+    size_t shmem = 0;
+    auto flush = [&]() -> int {
+        if (!m.ngroups) return SVT_HIP_OK;
+        // largest blocks first: their workgroups are the longest latency chains (64x64: one block per workgroup, two barriers)
+        for (int i = 1; i < m.ngroups; i++) {
+            const OisNdGroup v = m.g[i];
+            int j = i - 1;
+            while (j >= 0 && m.g[j].bsize < v.bsize) { m.g[j + 1] = m.g[j]; j--; }
+            m.g[j + 1] = v;
+        }
+        total = 0;
+        for (int i = 0; i < m.ngroups; i++) { total += m.g[i].wg_end; m.g[i].wg_end = total; }
+        hipLaunchKernelGGL(ois_nd_multi_kernel, dim3(total), dim3(256), shmem, s, d_pic, stride, width, height, m);
+        m.ngroups = 0; total = 0; shmem = 0;
+        return launch_status("ois_nd_multi");
+    };
+    // the neighbour gathers of the groups that have directional candidates: one launch, first (arguments are validated here, before
+    // anything is enqueued)
+    const bool multi = !g_tune_ois_no_nd_multi;
+    {
+        OisGatherMulti gm;
+        memset(&gm, 0, sizeof(gm));
+        uint32_t gtotal = 0;
+        auto gflush = [&]() -> int {
+            if (!gm.ngroups) return SVT_HIP_OK;
+            hipLaunchKernelGGL(ois_gather_multi_kernel, dim3(gtotal), dim3(256), 0, s, d_pic, stride, width, height, gm);
+            gm.ngroups = 0; gtotal = 0;
+            return launch_status("ois_gather_multi");
+        };
+        for (int g = 0; g < ngroups && multi; g++) {
+            const svt_hip_ois_group& G = groups[g];
+            if (G.nblocks == 0) continue;
+            OisGatherGroup gd;
+            if (int rc = ois_search_impl(d_pic, stride, width, height, G.d_xy, G.bsize, G.modes, G.angle_deltas, G.ncand, G.d_distortion, G.d_best_index,
+                                         G.d_work, G.work_bytes, G.nblocks, stream, nullptr, 1, &gd)) {
+                return gm.ngroups ? (gflush(), rc) : rc;
+            }
+            if (gd.nblocks == 0) continue;
+            if (gm.ngroups == OIS_GATHER_MAX_GROUPS) if (int rc = gflush()) return rc;
+            gtotal += gd.wg_end;
+            gd.wg_end = gtotal;
+            gm.g[gm.ngroups++] = gd;
+        }
+        if (int rc = gflush()) return rc;
     }
-    int rc = SVT_HIP_OK;
-    for (int g = 0; g < ngroups && rc == SVT_HIP_OK; g++) {
+    for (int g = 0; g < ngroups; g++) {
         const svt_hip_ois_group& G = groups[g];
         if (G.nblocks == 0) continue;
-        const bool on_side = side && G.modes && G.angle_deltas && light(G);
-        rc = svt_hip_ois_search_batch(d_pic, stride, width, height, G.d_xy, G.bsize, G.modes, G.angle_deltas, G.ncand, G.d_distortion,
-                                      G.d_best_index, G.d_work, G.work_bytes, G.nblocks, on_side ? t_fan.s[0] : s);
+        OisNdGroup d;
+        if (int rc = ois_search_impl(d_pic, stride, width, height, G.d_xy, G.bsize, G.modes, G.angle_deltas, G.ncand, G.d_distortion, G.d_best_index,
+                                     G.d_work, G.work_bytes, G.nblocks, stream, multi ? &d : nullptr, multi ? 2 : 0)) {
+            (void)flush();                      // what was enqueued for the earlier groups stays complete
+            return rc;
+        }
+        if (g_tune_ois_no_nd_multi || d.nblocks == 0) continue;
+        if (m.ngroups == OIS_ND_MAX_GROUPS) if (int rc = flush()) return rc;
+        const uint32_t cs = d.bsize < 16 ? 8 : 16, lpb = d.bsize * d.bsize / cs, nd_slots = 256 / lpb;
+        const size_t sh = (((size_t)nd_slots + (lpb > 64 ? 4 : 0)) * (size_t)d.ncand + 4) * sizeof(uint32_t);
+        shmem = sh > shmem ? sh : shmem;
+        m.g[m.ngroups++] = d;                   // (wg_end = the group's own workgroup count until flush() orders the groups)
     }
-    // always join, also after an error: the caller's stream (or capture) must not be left with a dangling branch
-    if (side && (hipEventRecord(t_fan.join[0], t_fan.s[0]) != hipSuccess || hipStreamWaitEvent(s, t_fan.join[0], 0) != hipSuccess))
-        if (rc == SVT_HIP_OK) rc = set_err(SVT_HIP_ERR_RUNTIME, "stream join failed");
-    return rc;
+    return flush();
 }
 
 // one intra block: stage [lo, hi) of above / left around the origin, predict, copy the block back

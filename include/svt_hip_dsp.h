@@ -84,6 +84,7 @@ const char *svt_hip_device_name(void);
  *   "no_staged", "no_f32p", "no_enc_staged", "no_inv_planes" (1 = take the general un-staged / two-kernel path),
  *   "no_qsad", "no_q2", "no_q16" (1 = take the first-generation search kernels), "me_exact" (1 = svt_hip_me_fullpel_search_batch always takes its general search-point-by-search-point kernel), "q2_su4" (1 = two-step window staging), "ois_no_fold" (1 = directional predictions through scratch),
  *   "ois_no_dir3" (1 = the open-loop search's three directional zones as three launches instead of one),
+ *   "ois_no_nd_multi" (1 = svt_hip_ois_search_frame: one non-directional launch per block size instead of one for the picture),
  *   "frame_single_launch" (svt_hip_encode_recon_frame: 0 = per-size launches, 1 = one launch, 2 = one launch per register class, -1 = by call size),
  *   "inv32_waves", "inv32_var" (probe variants of the inverse 32x32 kernel, tools/tune_inv32.py).
  * Unknown keys return SVT_HIP_ERR_INVALID. */

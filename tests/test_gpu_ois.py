@@ -185,8 +185,8 @@ def test_ois_argument_errors(dsp):
 
 
 def test_ois_search_frame_equals_per_size_calls(dsp):
-    """svt_hip_ois_search_frame (the four block sizes of a picture concurrently on internal streams) == one
-    svt_hip_ois_search_batch per size"""
+    """svt_hip_ois_search_frame (the block sizes of a picture in one call: every group's chain, then ONE non-directional launch for
+    all of them) == one svt_hip_ois_search_batch per size"""
     rng = np.random.default_rng(2024)
     W, H = 384, 256
     buf = rng.integers(0, 256, size=(H, W + 16), dtype=np.uint8)
@@ -198,7 +198,15 @@ def test_ois_search_frame_equals_per_size_calls(dsp):
         xy = _xy(blocks)
         groups.append((xy, bsize, modes, deltas))
         single.append(dsp.ois_search(plane, W + 16, W, H, xy, bsize, modes, deltas))
-    outs = dsp.ois_search_frame(plane, W + 16, W, H, groups)
-    torch.cuda.synchronize()
-    for (d1, b1), (d2, b2) in zip(single, outs):
-        assert torch.equal(d1, d2) and torch.equal(b1, b2)
+    # six groups (more than one merged non-directional launch holds) and, second, one non-directional launch per group
+    groups6 = groups + [groups[1], groups[3]]
+    single6 = single + [single[1], single[3]]
+    try:
+        for knob in (0, 1):
+            assert dsp.lib.svt_hip_tune(b"ois_no_nd_multi", knob) == 0
+            outs = dsp.ois_search_frame(plane, W + 16, W, H, groups6)
+            torch.cuda.synchronize()
+            for (d1, b1), (d2, b2) in zip(single6, outs):
+                assert torch.equal(d1, d2) and torch.equal(b1, b2), knob
+    finally:
+        dsp.lib.svt_hip_tune(b"ois_no_nd_multi", 0)

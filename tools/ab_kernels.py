@@ -79,6 +79,16 @@ def workload(name, d):
             pred[nm] = (src[nm].to(torch.int16) + torch.randint(-20, 21, (ph, pw), dtype=torch.int16, device=dev, generator=g)).clamp(0, 255).to(torch.uint8)
         fp = frames.FramePass(d, pkg, src, pred)
         return (lambda: fp.run(qrow)), fp.pixels, 7, (lambda: fp.digest())
+    if name == "oisall":        # the four block sizes of a 1080p picture in one svt_hip_ois_search_frame call
+        W, H, pad = 1920, 1080, 64
+        plane = torch.randint(0, 256, (H + 2 * pad, W + 2 * pad), dtype=torch.uint8, device=dev, generator=g); pic = plane[pad:, pad:]
+        groups, nb = [], 0
+        for bsize in (8, 16, 32, 64):
+            blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
+            xy = torch.from_numpy(np.array([(y << 16) | x for x, y in blocks], np.uint32).view(np.int32)).to(dev)
+            modes, deltas = d.ois_candidates(bsize)
+            groups.append((xy, bsize, modes, deltas)); nb += len(blocks)
+        return (lambda: d.ois_search_frame(pic, W + 2 * pad, W, H, groups)), nb, 0
     if name.startswith("ois"):
         bsize = int(name[3:]); W, H, pad = 1920, 1080, 64
         plane = torch.randint(0, 256, (H + 2 * pad, W + 2 * pad), dtype=torch.uint8, device=dev, generator=g); pic = plane[pad:, pad:]

@@ -34,6 +34,17 @@ elif name == "me_sb":
     n = 510
     src = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev); ref = torch.randint(0, 256, (n, 127, 128), dtype=torch.uint8, device=dev)
     fn = lambda: dsp.me_sb_search(src, ref, 64, 64)
+elif name == "oisall":                # the four block sizes of a 1080p picture in one svt_hip_ois_search_frame call
+    import numpy as np
+    W, H, pad = 1920, 1080, 64
+    plane = torch.randint(0, 256, (H + 2 * pad, W + 2 * pad), dtype=torch.uint8, device=dev); pic = plane[pad:, pad:]
+    groups = []
+    for bsize in (8, 16, 32, 64):
+        blocks = [(x, y) for y in range(0, H - bsize + 1, bsize) for x in range(0, W - bsize + 1, bsize)]
+        xy = torch.from_numpy(np.array([(y << 16) | x for x, y in blocks], np.uint32).view(np.int32)).to(dev)
+        modes, deltas = dsp.ois_candidates(bsize)
+        groups.append((xy, bsize, modes, deltas))
+    fn = lambda: dsp.ois_search_frame(pic, W + 2 * pad, W, H, groups)
 elif name.startswith("ois"):          # ois8 / ois16: the open-loop intra search of one 1080p picture at that block size
     import numpy as np
     bsize = int(name[3:]); W, H, pad = 1920, 1080, 64
