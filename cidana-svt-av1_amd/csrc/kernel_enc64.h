@@ -270,15 +270,17 @@ __device__ __forceinline__ void enc64_body(
     }
 }
 
-template <typename PixT, int BD, bool KEEP>
+// SAD = false: the caller takes no SAD (the frame-level calls): without that path the 10-bit form needs 192 registers instead of
+// 256 + 30 AGPRs - two waves per SIMD (what the LDS allows) instead of one
+template <typename PixT, int BD, bool KEEP, bool SAD = true>
 __global__ __launch_bounds__(E64_WAVES * 64) void enc64_kernel(
     const PixT* __restrict__ src, const PixT* __restrict__ pred, PixT* __restrict__ recon,
     int32_t* __restrict__ coeff, int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff,
     uint16_t* __restrict__ eob, uint32_t* __restrict__ sad, const int16_t* __restrict__ iscan, QParams qp,
     uint32_t nblocks, const uint32_t* __restrict__ xy, uint32_t src_stride, uint32_t pred_stride, uint32_t recon_stride) {
     __shared__ __attribute__((aligned(16))) char lds[E64_WAVES * E64_WAVE_LDS];
-    enc64_body<PixT, BD, KEEP>(src, pred, recon, coeff, qcoeff, dqcoeff, eob, sad, iscan, qp, nblocks, xy, src_stride, pred_stride, recon_stride,
-                               blockIdx.x, lds);
+    enc64_body<PixT, BD, KEEP>(src, pred, recon, coeff, qcoeff, dqcoeff, eob, SAD ? sad : nullptr, iscan, qp, nblocks, xy, src_stride, pred_stride,
+                               recon_stride, blockIdx.x, lds);
 }
 
 // svt_hip_fwd_quant_*: the forward half (coeff, qcoeff, dqcoeff, eob, sad out; no three_quad_energy - the pruned networks never

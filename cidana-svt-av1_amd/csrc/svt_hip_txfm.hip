@@ -385,10 +385,10 @@ static int encode_recon_impl(const void* d_src_v, uint32_t src_stride, const voi
         if (ok && tx_size == SVT_TX_64X64 && !g_tune_no_enc64) {
             // two blocks per wave, pruned 64-point networks (kernel_enc64.h)
             const dim3 grid((uint32_t)((nblocks + 2 * E64_WAVES - 1) / (2 * E64_WAVES)));
-#define ENC64(T, B, KEEP) hipLaunchKernelGGL((enc64_kernel<T, B, KEEP>), grid, dim3(E64_WAVES * 64), 0, s, (const T*)d_src_v, (const T*)d_pred_v, (T*)d_recon_v, \
+#define ENC64(T, B, KEEP, SAD) hipLaunchKernelGGL((enc64_kernel<T, B, KEEP, SAD>), grid, dim3(E64_WAVES * 64), 0, s, (const T*)d_src_v, (const T*)d_pred_v, (T*)d_recon_v, \
                                             d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_sad, d_iscan, qp, (uint32_t)nblocks, d_xy, src_stride, pred_stride, recon_stride)
-            if (is_16bit) { if (d_coeff) ENC64(uint16_t, 10, true); else ENC64(uint16_t, 10, false); }
-            else { if (d_coeff) ENC64(uint8_t, 8, true); else ENC64(uint8_t, 8, false); }
+            if (is_16bit) { if (d_coeff) ENC64(uint16_t, 10, true, true); else if (d_sad) ENC64(uint16_t, 10, false, true); else ENC64(uint16_t, 10, false, false); }
+            else { if (d_coeff) ENC64(uint8_t, 8, true, true); else if (d_sad) ENC64(uint8_t, 8, false, true); else ENC64(uint8_t, 8, false, false); }
 #undef ENC64
             return launch_status("encode_recon_64x64");
         }
