@@ -201,12 +201,14 @@ def test_ois_search_frame_equals_per_size_calls(dsp):
     # six groups (more than one merged non-directional launch holds) and, second, one non-directional launch per group
     groups6 = groups + [groups[1], groups[3]]
     single6 = single + [single[1], single[3]]
+    orders = [list(range(6)), [0, 2, 3, 5, 4, 1], [1, 4, 0, 2, 3, 5], [2, 3, 1, 0, 5, 4]]      # the merged launches must not depend on the order
     try:
         for knob in (0, 1):
             assert dsp.lib.svt_hip_tune(b"ois_no_nd_multi", knob) == 0
-            outs = dsp.ois_search_frame(plane, W + 16, W, H, groups6)
-            torch.cuda.synchronize()
-            for (d1, b1), (d2, b2) in zip(single6, outs):
-                assert torch.equal(d1, d2) and torch.equal(b1, b2), knob
+            for od in orders:
+                outs = dsp.ois_search_frame(plane, W + 16, W, H, [groups6[i] for i in od])
+                torch.cuda.synchronize()
+                for i, (d2, b2) in zip(od, outs):
+                    assert torch.equal(single6[i][0], d2) and torch.equal(single6[i][1], b2), (knob, od, i)
     finally:
         dsp.lib.svt_hip_tune(b"ois_no_nd_multi", 0)
