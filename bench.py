@@ -210,6 +210,76 @@ def box_probe(torch, dsp, dev, big, src, iters=5):
     return out
 
 
+def clock_probe(torch, step, seconds=0.5):
+    """The shader clock and board power the device HOLDS while the timed kernel runs: the hwmon files of the card whose PCI address is
+    this device's, read from a thread while the kernel is replayed for ~ 0.5 s (outside the timed region).  Boxes whose memory probes
+    read the same run the kernel 20 % apart; this is the other half of 'slow box or slow kernel'.  {} when the files are not there."""
+    import glob
+    import threading
+    import time
+    try:
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        hw = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+        if not hw:
+            return {}
+        hw = hw[0]
+
+        def rd(name):
+            try:
+                return int(open(os.path.join(hw, name)).read().strip())
+            except Exception:
+                return None
+        labels = {}
+        for k in (1, 2):
+            try:
+                labels[open(os.path.join(hw, f"freq{k}_label")).read().strip()] = f"freq{k}_input"
+            except Exception:
+                pass
+        f_s = labels.get("sclk", "freq1_input"); f_m = labels.get("mclk")
+        stop, sclk, mclk, power = [False], [], [], []
+
+        def sampler():
+            while not stop[0]:
+                v = rd(f_s)
+                if v:
+                    sclk.append(v / 1e6)
+                if f_m:
+                    v = rd(f_m)
+                    if v:
+                        mclk.append(v / 1e6)
+                v = rd("power1_input")
+                if v:
+                    power.append(v / 1e6)
+                time.sleep(0.004)
+        th = threading.Thread(target=sampler, daemon=True)
+        t0 = time.perf_counter()
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        th.start()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
+        stop[0] = True
+        th.join(timeout=1.0)
+        if not sclk:
+            return {}
+        med = lambda v: sorted(v)[len(v) // 2]
+        out = {"sclk_MHz_under_load": round(med(sclk)), "sclk_MHz_min_max": [round(min(sclk)), round(max(sclk))], "clock_samples": len(sclk)}
+        if mclk:
+            out["mclk_MHz_under_load"] = round(med(mclk))
+        if power:
+            out["power_W_under_load"] = round(med(power))
+        cap = rd("power1_cap")
+        if cap:
+            out["power_cap_W"] = round(cap / 1e6)
+        return out
+    except Exception as e:            # a diagnostic, never a reason to lose the line
+        return {"clock_probe_error": str(e)[:120]}
+
+
 def pcie_inclusive(torch, dsp, pkg, dev, src, pred, qrow, iscan, ns):
     """SURVEY 8(d) secondary figure: the same chain when the caller hands over HOST buffers — pinned host src / pred up,
     kernel, every output back down, one stream, no overlap between consecutive batches.  Never `value`."""
@@ -378,6 +448,7 @@ def main():
             roofline["frac_of_box_fill"] = achieved / roofline["box_fill_GBps"]
             if "box_mix_1r6w_GBps" in roofline:
                 roofline["frac_of_box_mix"] = achieved / roofline["box_mix_1r6w_GBps"]
+            roofline.update(clock_probe(torch, step))      # (replays the timed kernel: the outputs are the step's again)
             for _ in range(2):
                 step()                          # the probes overwrote the outputs: restore them for the CPU comparison
             torch.cuda.synchronize()
