@@ -304,11 +304,13 @@ static int intra_pred_impl(void* d_dst, int32_t dst_stride, size_t dst_block_pit
     }
     const int cnt = mode == SVT_INTRA_DC ? bw + bh : (mode == SVT_INTRA_DC_TOP ? bw : bh);
     const uint32_t dc_magic = (uint32_t)(0x100000000ull / (uint64_t)cnt) + 1u;
-    constexpr int INTRA_IU = 2;                                    // blocks per lane in the wide kernels
-    const size_t grid_w = (grid + INTRA_IU - 1) / INTRA_IU;
+    // blocks per lane in the wide kernels: 4 for the modes with per-pixel arithmetic (SMOOTH*, PAETH: + 9 % on 2^21 32x32 blocks, A/B),
+    // 2 for the copy-like ones (DC*, V, H: 2 - 4 % SLOWER at 4)
+    const bool iu4 = mode == SVT_INTRA_SMOOTH || mode == SVT_INTRA_SMOOTH_V || mode == SVT_INTRA_SMOOTH_H || mode == SVT_INTRA_PAETH;
+    const size_t grid_w = (grid + (iu4 ? 4 : 2) - 1) / (iu4 ? 4 : 2);
 #define IPL(T, M)                                                                                                     \
     if (bw >= 16 / (int)sizeof(T))                                                                                    \
-        hipLaunchKernelGGL((intra_pred_kernel<T, M, true, INTRA_IU>), dim3((uint32_t)(per_block > 256 ? (grid_w + 1) & ~(size_t)1 : grid_w)), dim3(256), 0, s, (T*)d_dst, dst_stride, \
+        hipLaunchKernelGGL((intra_pred_kernel<T, M, true, (M == IM_SMOOTH || M == IM_SMOOTH_V || M == IM_SMOOTH_H || M == IM_PAETH) ? 4 : 2>), dim3((uint32_t)(per_block > 256 ? (grid_w + 1) & ~(size_t)1 : grid_w)), dim3(256), 0, s, (T*)d_dst, dst_stride, \
                            dst_block_pitch, d_dst_offsets, (const T*)d_above, (const T*)d_left, nb_pitch, bw, bh, bd,    \
                            dc_magic, (uint32_t)nblocks);                                                              \
     else                                                                                                              \

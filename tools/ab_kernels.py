@@ -96,6 +96,11 @@ def workload(name, d):
         xy = torch.from_numpy(np.array([(y << 16) | x for x, y in blocks], np.uint32).view(np.int32)).to(dev)
         modes, deltas = d.ois_candidates(bsize)
         return (lambda: d.ois_search(pic, W + 2 * pad, W, H, xy, bsize, modes, deltas)), len(blocks), bsize * bsize + 4 * len(modes)
+    if name.startswith("intra:"):        # intra:<mode> - dense 32x32 8-bit prediction batch, SVT_INTRA_* mode number (z1 / z2 / z3: 10 / 11 / 12)
+        mode = int(name[6:]); n = 1 << 21
+        ab_ = torch.randint(0, 256, (n, 16 + 2 * 64 + 16), dtype=torch.uint8, device=dev, generator=g); lf = torch.randint(0, 256, (n, 16 + 2 * 64 + 16), dtype=torch.uint8, device=dev, generator=g)
+        out = torch.empty((n, 32, 32), dtype=torch.uint8, device=dev)
+        return (lambda: d.intra_pred(ab_, lf, mode, 32, 32, 8, 0, 0, 64, 64, out=out)), n, 1024 + 130
     if name == "bip":
         n = 1 << 20
         top = torch.randint(0, 256, (n, 48), dtype=torch.uint8, device=dev, generator=g); left = torch.randint(0, 256, (n, 48), dtype=torch.uint8, device=dev, generator=g)
