@@ -97,8 +97,10 @@ def workload(name, d):
         modes, deltas = d.ois_candidates(bsize)
         return (lambda: d.ois_search(pic, W + 2 * pad, W, H, xy, bsize, modes, deltas)), len(blocks), bsize * bsize + 4 * len(modes)
     if name.startswith("intra:"):        # intra:<mode> - dense 32x32 8-bit prediction batch, SVT_INTRA_* mode number (z1 / z2 / z3: 10 / 11 / 12)
-        mode = int(name[6:]); n = 1 << 21
-        ab_ = torch.randint(0, 256, (n, 16 + 2 * 64 + 16), dtype=torch.uint8, device=dev, generator=g); lf = torch.randint(0, 256, (n, 16 + 2 * 64 + 16), dtype=torch.uint8, device=dev, generator=g)
+        parts = name.split(":")          # intra:<mode>[:<neighbour row pitch>]
+        mode = int(parts[1]); n = 1 << 21
+        pitch = int(parts[2]) if len(parts) > 2 else 16 + 2 * 64 + 16
+        ab_ = torch.randint(0, 256, (n, pitch), dtype=torch.uint8, device=dev, generator=g); lf = torch.randint(0, 256, (n, pitch), dtype=torch.uint8, device=dev, generator=g)
         out = torch.empty((n, 32, 32), dtype=torch.uint8, device=dev)
         return (lambda: d.intra_pred(ab_, lf, mode, 32, 32, 8, 0, 0, 64, 64, out=out)), n, 1024 + 130
     if name == "bip":
