@@ -30,8 +30,97 @@ static void *upload(const void *h, size_t bytes) {
     return d;
 }
 
+/* A second call on the same planes (argv[5] = luma size S): svt_hip_encode_recon_frame_ex on ONE pass (Y at S, Cb / Cr at S / 2) with
+ * chroma from luma on every chroma block (alpha_cb = (b % 33) - 16, alpha_cr = ((7 b) % 33) - 16 for chroma block b) and a level map
+ * for every block of the three groups.  Prints:  ex blocks <n> eob_sum <s> qcoeff_checksum <c> recon_sum <r> pred_sum <p> levels_sum <l> */
+static int run_ex(int S, const int *pw, const int *ph, void *const *d_src, uint8_t *const *pred, int16_t (*zb)[8], int16_t (*rn)[8], int16_t (*qu)[8],
+                  int16_t (*qs)[8], int16_t (*dq)[8], int qindex) {
+    static const int sides[5] = {64, 32, 16, 8, 4};
+    static const int txs[5] = {SVT_TX_64X64, SVT_TX_32X32, SVT_TX_16X16, SVT_TX_8X8, SVT_TX_4X4};
+    svt_hip_frame_group g[3];
+    svt_hip_frame_levels lv[3];
+    size_t nblk[3], lpitch[3];
+    int nc[3];
+    void *d_pred2[3];
+    for (int p = 0; p < 3; p++) {
+        const int side = p ? S / 2 : S;
+        int ti = 0;
+        while (ti < 5 && sides[ti] != side) ti++;
+        if (ti == 5) return 2;
+        const int k = side > 32 ? 32 : side;
+        nc[p] = k * k;
+        const int bx = pw[p] / side, by = ph[p] / side;
+        nblk[p] = (size_t)bx * by;
+        uint32_t *xy = malloc(nblk[p] * sizeof(uint32_t));
+        for (int y = 0; y < by; y++)
+            for (int x = 0; x < bx; x++) xy[(size_t)y * bx + x] = (uint32_t)(x * side) | ((uint32_t)(y * side) << 16);
+        int16_t scan[1024], iscan[1024];
+        if (svt_hip_get_scan(txs[ti], SVT_DCT_DCT, scan, iscan) != nc[p]) return 4;
+        const size_t pn = (size_t)pw[p] * ph[p];
+        d_pred2[p] = upload(pred[p], pn);                    /* the call predicts the chroma planes in place: its own copies */
+        memset(&g[p], 0, sizeof(g[p]));
+        g[p].d_src = d_src[p]; g[p].src_stride = (uint32_t)pw[p];
+        g[p].d_pred = d_pred2[p]; g[p].pred_stride = (uint32_t)pw[p];
+        g[p].d_recon = upload(pred[p], pn); g[p].recon_stride = (uint32_t)pw[p];
+        g[p].d_xy = upload(xy, nblk[p] * sizeof(uint32_t));
+        g[p].nblocks = (uint32_t)nblk[p]; g[p].tx_size = txs[ti]; g[p].tx_type = SVT_DCT_DCT;
+        g[p].d_iscan = upload(iscan, (size_t)nc[p] * sizeof(int16_t));
+        g[p].d_qcoeff = svt_hip_malloc(nblk[p] * (size_t)nc[p] * sizeof(int32_t));
+        g[p].d_eob = svt_hip_malloc(nblk[p] * sizeof(uint16_t));
+        lpitch[p] = (((size_t)(k + 4) * (k + 6) + 16) + 15) & ~(size_t)15;
+        lv[p].d_levels_buf = svt_hip_malloc(nblk[p] * lpitch[p]); lv[p].levels_block_pitch = lpitch[p];
+        if (!d_pred2[p] || !g[p].d_recon || !g[p].d_xy || !g[p].d_iscan || !g[p].d_qcoeff || !g[p].d_eob || !lv[p].d_levels_buf) return 4;
+        free(xy);
+    }
+    int32_t *a_cb = malloc(nblk[1] * sizeof(int32_t)), *a_cr = malloc(nblk[1] * sizeof(int32_t));
+    for (size_t b = 0; b < nblk[1]; b++) { a_cb[b] = (int32_t)(b % 33) - 16; a_cr[b] = (int32_t)((7 * b) % 33) - 16; }
+    svt_hip_frame_cfl_group c;
+    memset(&c, 0, sizeof(c));
+    c.d_luma_recon = g[0].d_recon; c.luma_stride = g[0].recon_stride;
+    c.d_pred_cb = d_pred2[1]; c.pred_stride_cb = (uint32_t)pw[1];
+    c.d_pred_cr = d_pred2[2]; c.pred_stride_cr = (uint32_t)pw[2];
+    c.d_xy = g[1].d_xy;
+    c.d_alpha_q3_cb = upload(a_cb, nblk[1] * sizeof(int32_t)); c.d_alpha_q3_cr = upload(a_cr, nblk[1] * sizeof(int32_t));
+    c.width = c.height = (uint32_t)(S / 2); c.nblocks = (uint32_t)nblk[1];
+    if (!c.d_alpha_q3_cb || !c.d_alpha_q3_cr) return 4;
+    CHECK(svt_hip_stream_sync(NULL));
+    CHECK(svt_hip_encode_recon_frame_ex(g, 3, 1, &c, 1, lv, 0, 8, zb[qindex], rn[qindex], qu[qindex], qs[qindex], dq[qindex], NULL));
+    CHECK(svt_hip_stream_sync(NULL));
+    const int64_t M = 2147483647;
+    int64_t blocks = 0, eob_sum = 0, qchk = 0, recon_sum = 0, pred_sum = 0, levels_sum = 0;
+    for (int p = 0; p < 3; p++) {
+        const size_t n = nblk[p], pn = (size_t)pw[p] * ph[p];
+        uint16_t *eob = malloc(n * sizeof(uint16_t));
+        int32_t *q = malloc(n * (size_t)nc[p] * sizeof(int32_t));
+        uint8_t *rec = malloc(pn), *prd = malloc(pn), *lev = malloc(n * lpitch[p]);
+        CHECK(svt_hip_memcpy_d2h(eob, g[p].d_eob, n * sizeof(uint16_t), NULL));
+        CHECK(svt_hip_memcpy_d2h(q, g[p].d_qcoeff, n * (size_t)nc[p] * sizeof(int32_t), NULL));
+        CHECK(svt_hip_memcpy_d2h(rec, g[p].d_recon, pn, NULL));
+        CHECK(svt_hip_memcpy_d2h(prd, d_pred2[p], pn, NULL));
+        CHECK(svt_hip_memcpy_d2h(lev, lv[p].d_levels_buf, n * lpitch[p], NULL));
+        CHECK(svt_hip_stream_sync(NULL));
+        blocks += (int64_t)n;
+        for (size_t b = 0; b < n; b++) eob_sum += eob[b];
+        int64_t s = 0;
+        for (size_t b = 0; b < n; b++)
+            for (int k = 0; k < nc[p]; k++) s += (int64_t)q[b * nc[p] + k] * (int64_t)((k % 8191) + 1);
+        s %= M; if (s < 0) s += M;
+        qchk += s;
+        for (size_t k = 0; k < pn; k++) { recon_sum += rec[k]; pred_sum += prd[k]; }
+        const int kk = nc[p] == 1024 ? 32 : (nc[p] == 256 ? 16 : (nc[p] == 64 ? 8 : 4));
+        const size_t used = (size_t)(kk + 4) * (kk + 6) + 16;
+        for (size_t b = 0; b < n; b++)
+            for (size_t k = 0; k < used; k++) levels_sum += lev[b * lpitch[p] + k];
+        free(eob); free(q); free(rec); free(prd); free(lev);
+    }
+    qchk %= M;
+    printf("ex blocks %lld eob_sum %lld qcoeff_checksum %lld recon_sum %lld pred_sum %lld levels_sum %lld\n", (long long)blocks, (long long)eob_sum,
+           (long long)qchk, (long long)recon_sum, (long long)pred_sum, (long long)levels_sum);
+    return 0;
+}
+
 int main(int argc, char **argv) {
-    if (argc != 5) { fprintf(stderr, "usage: %s width height qindex seed\n", argv[0]); return 2; }
+    if (argc != 5 && argc != 6) { fprintf(stderr, "usage: %s width height qindex seed [luma size of the _ex pass]\n", argv[0]); return 2; }
     const int W = atoi(argv[1]), H = atoi(argv[2]), qindex = atoi(argv[3]);
     uint32_t seed = (uint32_t)strtoul(argv[4], NULL, 0);
     if (W < 64 || H < 64 || (W & 1) || (H & 1) || qindex < 0 || qindex > 255) return 2;
@@ -125,5 +214,6 @@ int main(int argc, char **argv) {
     }
     qchk %= M;
     printf("blocks %lld eob_sum %lld qcoeff_checksum %lld recon_sum %lld\n", (long long)blocks, (long long)eob_sum, (long long)qchk, (long long)recon_sum);
+    if (argc == 6) return run_ex(atoi(argv[5]), pw, ph, d_src, pred, zbin, rnd, quant, qshift, deq, qindex);
     return 0;
 }
