@@ -856,8 +856,8 @@ class SvtHipDsp:
         hme_sad int64 [regions, n] and hme_mv int16 [regions, n, 2] (or None).  -> (center int16 [n, 2], area int16 [n, 4])"""
         t = self.torch
         n = sb_origin.shape[0]
-        center = t.zeros((n, 2), dtype=t.int16, device=sb_origin.device)
-        area = t.zeros((n, 4), dtype=t.int16, device=sb_origin.device)
+        center = t.empty((n, 2), dtype=t.int16, device=sb_origin.device)      # (every entry is written by the kernel)
+        area = t.empty((n, 4), dtype=t.int16, device=sb_origin.device)
         self._check(self.lib.svt_hip_me_setup_batch(self._p(src_pic00), src_stride, self._p(ref_pic00), ref_stride, self._p(sb_origin),
                                                     self._p(sb_size), self._p(hme_sad) if hme_sad is not None else None,
                                                     self._p(hme_mv) if hme_mv is not None else None, ctypes.byref(params), self._p(center),
@@ -888,7 +888,7 @@ class SvtHipDsp:
         n = sb_origin.shape[0]
         pitch = best_sad0.shape[1]
         bip = t.zeros((n, pitch), dtype=t.int32, device=sb_origin.device)
-        res = t.zeros((n, npus, ctypes.sizeof(self.MeResult)), dtype=t.uint8, device=sb_origin.device)
+        res = t.empty((n, npus, ctypes.sizeof(self.MeResult)), dtype=t.uint8, device=sb_origin.device)      # (every row is written)
         two = best_sad1 is not None
         self._check(self.lib.svt_hip_me_bipred_batch(self._p(src_pic00), src_stride, self._p(ref0_pic00) if two else None, ref0_stride,
                                                      self._p(ref1_pic00) if two else None, ref1_stride, self._p(sb_origin), self._p(best_sad0),

@@ -900,6 +900,19 @@ __global__ __launch_bounds__(256) void me_setup_kernel(
         if (row < (sbh >> 1)) {
             const uint8_t* a = src_pic + (ptrdiff_t)(oy + 2 * row) * (ptrdiff_t)src_stride + ox;
             const uint8_t* b = ref_pic + (ptrdiff_t)(oy + (second ? hy : 0) + 2 * row) * (ptrdiff_t)ref_stride + ox + (second ? hx : 0);
+            if (sbw == 64) {
+                // the full-width SB (all but the last column of a picture): the row's eight 16-byte loads in flight together - the general
+                // loop below is a chain of sixteen dependent 4-byte round trips, 23 us per picture for a kernel with one wave per SB
+                typedef unsigned me_v4u __attribute__((ext_vector_type(4), aligned(1)));
+                me_v4u va[4], vb[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { va[q] = reinterpret_cast<const me_v4u*>(a)[q]; vb[q] = reinterpret_cast<const me_v4u*>(b)[q]; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    sad = __builtin_amdgcn_sad_u8(va[q].x, vb[q].x, sad); sad = __builtin_amdgcn_sad_u8(va[q].y, vb[q].y, sad);
+                    sad = __builtin_amdgcn_sad_u8(va[q].z, vb[q].z, sad); sad = __builtin_amdgcn_sad_u8(va[q].w, vb[q].w, sad);
+                }
+            } else
             for (int c = 0; c < sbw; c += 4) {
                 uint32_t va = 0, vb = 0;
                 if (c + 4 <= sbw) { __builtin_memcpy(&va, a + c, 4); __builtin_memcpy(&vb, b + c, 4); }
@@ -959,43 +972,57 @@ __global__ __launch_bounds__(ME_THREADS) void me_bipred_kernel(
     uint32_t* __restrict__ bipred_sad /* [n][pu_pitch] storage order, or NULL */, MeResult* __restrict__ results /* [n][npus] raster order */,
     uint32_t nsb) {
     __shared__ unsigned s_bi[ME_PUS_ALL];
+    // the PU map in LDS: the item loop below looks a PU up by binary search and reads five of its fields - through the kernel arguments
+    // (per-lane indices: vector loads) that was a dozen dependent round trips per work item
+    __shared__ MePuMap s_map;
+    static_assert(sizeof(MePuMap) % 2 == 0 && alignof(MePuMap) >= 2, "copied as 16-bit words");
     const uint32_t sb = blockIdx.x;
     if (sb >= nsb) return;
     const int tid = threadIdx.x;
     const int ox = sb_origin[2 * sb], oy = sb_origin[2 * sb + 1];
     const bool two = best_sad1 != nullptr;
     for (int i = tid; i < ME_PUS_ALL; i += ME_THREADS) s_bi[i] = 0;
+    for (int i = tid; i < (int)(sizeof(MePuMap) / 2); i += ME_THREADS) reinterpret_cast<uint16_t*>(&s_map)[i] = reinterpret_cast<const uint16_t*>(&map)[i];
     __syncthreads();
     if (two) {
         const int nbi = bipred_all_pus ? npus : min(npus, 21);
-        const int nitems = sub_sad ? map.row0[nbi] : 2 * map.row0[nbi];
+        const int nitems = sub_sad ? s_map.row0[nbi] : 2 * s_map.row0[nbi];
         for (int it = tid; it < nitems; it += ME_THREADS) {
             const int key = sub_sad ? it : (it >> 1);        // position in the sub-sampled row numbering
             int lo = 0, hi = nbi - 1;                        // PU whose item range holds `key`
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (map.row0[mid] <= key) lo = mid; else hi = mid - 1; }
-            const int p = lo, n = map.storage[p];
-            const int row = sub_sad ? 2 * (key - map.row0[p]) : 2 * (key - map.row0[p]) + (it & 1);
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_map.row0[mid] <= key) lo = mid; else hi = mid - 1; }
+            const int p = lo, n = s_map.storage[p];
+            const int row = sub_sad ? 2 * (key - s_map.row0[p]) : 2 * (key - s_map.row0[p]) + (it & 1);
             const uint32_t m0 = best_mv0[(size_t)sb * pu_pitch + n], m1 = best_mv1[(size_t)sb * pu_pitch + n];
             const int x0 = (int16_t)(m0 & 0xffffu) >> 2, y0 = (int16_t)(m0 >> 16) >> 2, x1 = (int16_t)(m1 & 0xffffu) >> 2, y1 = (int16_t)(m1 >> 16) >> 2;
-            const int px = ox + 8 * map.x8[p], py = oy + 8 * map.y8[p] + row, w = 8 * map.w8[p];
+            const int px = ox + 8 * s_map.x8[p], py = oy + 8 * s_map.y8[p] + row, w = 8 * s_map.w8[p];
             const uint8_t* a = src_pic + (ptrdiff_t)py * (ptrdiff_t)src_stride + px;
             const uint8_t* b = ref0_pic + (ptrdiff_t)(py + y0) * (ptrdiff_t)ref0_stride + px + x0;
             const uint8_t* c = ref1_pic + (ptrdiff_t)(py + y1) * (ptrdiff_t)ref1_stride + px + x1;
             unsigned sad = 0;
-            for (int k = 0; k < w; k += 8) {
-                uint2 va, vb, vc;
-                __builtin_memcpy(&va, a + k, 8); __builtin_memcpy(&vb, b + k, 8); __builtin_memcpy(&vc, c + k, 8);
-                // rounded average of four byte pairs: (x | y) - (((x ^ y) >> 1) & 0x7f7f7f7f)
+            // rounded average of four byte pairs: (x | y) - (((x ^ y) >> 1) & 0x7f7f7f7f).  Two 8-byte chunks per round (w is 8 or a
+            // multiple of 16): six loads in flight instead of three
+            auto chunk = [&](const uint2 va, const uint2 vb, const uint2 vc) {
                 const uint32_t ax = (vb.x | vc.x) - (((vb.x ^ vc.x) >> 1) & 0x7f7f7f7fu), ay = (vb.y | vc.y) - (((vb.y ^ vc.y) >> 1) & 0x7f7f7f7fu);
                 sad = __builtin_amdgcn_sad_u8(va.x, ax, sad);
                 sad = __builtin_amdgcn_sad_u8(va.y, ay, sad);
+            };
+            if (w == 8) {
+                uint2 va, vb, vc;
+                __builtin_memcpy(&va, a, 8); __builtin_memcpy(&vb, b, 8); __builtin_memcpy(&vc, c, 8);
+                chunk(va, vb, vc);
+            } else
+            for (int k = 0; k < w; k += 16) {
+                uint2 va[2], vb[2], vc[2];
+                __builtin_memcpy(va, a + k, 16); __builtin_memcpy(vb, b + k, 16); __builtin_memcpy(vc, c + k, 16);
+                chunk(va[0], vb[0], vc[0]); chunk(va[1], vb[1], vc[1]);
             }
             atomicAdd(&s_bi[n], sub_sad ? sad << 1 : sad);
         }
     }
     __syncthreads();
     if (tid < npus) {
-        const int p = tid, n = map.storage[p];
+        const int p = tid, n = s_map.storage[p];
         const uint32_t l0 = best_sad0[(size_t)sb * pu_pitch + n], m0 = best_mv0[(size_t)sb * pu_pitch + n];
         const uint32_t l1 = two ? best_sad1[(size_t)sb * pu_pitch + n] : 0, m1 = two ? best_mv1[(size_t)sb * pu_pitch + n] : 0;
         const bool has_bi = two && (bipred_all_pus || p < 21);
