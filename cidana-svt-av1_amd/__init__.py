@@ -484,8 +484,8 @@ class SvtHipDsp:
         n = xy.shape[0]
         modes = np.ascontiguousarray(modes, np.uint8); angle_deltas = np.ascontiguousarray(angle_deltas, np.int8)
         nc = int(modes.shape[0])
-        dist = t.zeros((n, nc), dtype=t.int32, device=xy.device)
-        best = t.zeros(n, dtype=t.int8, device=xy.device)
+        dist = t.empty((n, nc), dtype=t.int32, device=xy.device)        # (the search writes every entry)
+        best = t.empty(n, dtype=t.int8, device=xy.device)
         wb = self.lib.svt_hip_ois_work_bytes(bsize, nc, n)
         work = t.empty(max(wb, 1), dtype=t.uint8, device=xy.device)
         self._check(self.lib.svt_hip_ois_search_batch(pic.data_ptr(), stride, width, height, self._p(xy), bsize,
@@ -511,8 +511,8 @@ class SvtHipDsp:
             n = xy.shape[0]
             modes = np.ascontiguousarray(modes, np.uint8); deltas = np.ascontiguousarray(deltas, np.int8)
             nc = int(modes.shape[0])
-            dist = t.zeros((n, nc), dtype=t.int32, device=xy.device)
-            best = t.zeros(n, dtype=t.int8, device=xy.device)
+            dist = t.empty((n, nc), dtype=t.int32, device=xy.device)        # (the search writes every entry)
+            best = t.empty(n, dtype=t.int8, device=xy.device)
             wb = self.lib.svt_hip_ois_work_bytes(bsize, nc, n)
             work = t.empty(max(wb, 1), dtype=t.uint8, device=xy.device)
             arr[i] = self.OisGroup(self._p(xy), bsize, modes.ctypes.data, deltas.ctypes.data, nc, self._p(dist), self._p(best), self._p(work), wb, n)
@@ -699,8 +699,8 @@ class SvtHipDsp:
         centers int16 [n, 2] or None.  -> (best_sad int64 [n], mv int16 [n, 2])"""
         t = self.torch
         n = sb_origin.shape[0]
-        best = t.zeros(n, dtype=t.int64, device=sb_origin.device)
-        mv = t.zeros((n, 2), dtype=t.int16, device=sb_origin.device)
+        best = t.empty(n, dtype=t.int64, device=sb_origin.device)         # (the kernel writes every task's entries)
+        mv = t.empty((n, 2), dtype=t.int16, device=sb_origin.device)
         self._check(self.lib.svt_hip_hme_level_batch(self._p(src_pic), src_stride, self._p(ref_pic00), ref_stride, self._p(sb_origin),
                                                      self._p(sb_size), self._p(centers) if centers is not None else None, center_shift,
                                                      ctypes.byref(params), self._p(best), self._p(mv), n, self._stream()),
@@ -746,8 +746,8 @@ class SvtHipDsp:
         t = self.torch
         n, nr = sb_origin.shape[0], len(params_list)
         arr = (self.HmeParams * nr)(*params_list)
-        best = t.zeros((nr, n), dtype=t.int64, device=sb_origin.device)
-        mv = t.zeros((nr, n, 2), dtype=t.int16, device=sb_origin.device)
+        best = t.empty((nr, n), dtype=t.int64, device=sb_origin.device)
+        mv = t.empty((nr, n, 2), dtype=t.int16, device=sb_origin.device)
         self._check(self.lib.svt_hip_hme_level_regions_batch(self._p(src_pic), src_stride, self._p(ref_pic00), ref_stride, self._p(sb_origin),
                                                              self._p(sb_size), self._p(centers) if centers is not None else None, center_shift,
                                                              ctypes.addressof(arr), nr, self._p(best), self._p(mv), n, self._stream()),
