@@ -237,7 +237,15 @@ def clock_probe(torch, step, seconds=0.5):
             except Exception:
                 pass
         f_s = labels.get("sclk", "freq1_input"); f_m = labels.get("mclk")
-        stop, sclk, mclk, power = [False], [], [], []
+        stop, sclk, mclk, power, dpm = [False], [], [], [], {}
+
+        def dpm_level(name):          # the level the driver marks current ('*') in pp_dpm_<name>, MHz
+            try:
+                for line in open(f"/sys/bus/pci/devices/{bdf}/pp_dpm_{name}").read().splitlines():
+                    if line.rstrip().endswith("*"):
+                        return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+            except Exception:
+                return None
 
         def sampler():
             while not stop[0]:
@@ -251,6 +259,11 @@ def clock_probe(torch, step, seconds=0.5):
                 v = rd("power1_input")
                 if v:
                     power.append(v / 1e6)
+                if len(sclk) == 40:                      # once, in the middle of the loaded period: fabric / SoC / memory DPM levels
+                    for nm in ("fclk", "socclk", "mclk"):
+                        lv = dpm_level(nm)
+                        if lv:
+                            dpm[nm] = lv
                 time.sleep(0.004)
         th = threading.Thread(target=sampler, daemon=True)
         t0 = time.perf_counter()
@@ -272,6 +285,8 @@ def clock_probe(torch, step, seconds=0.5):
             out["mclk_MHz_under_load"] = round(med(mclk))
         if power:
             out["power_W_under_load"] = round(med(power))
+        for nm, lv in dpm.items():
+            out[f"{nm}_dpm_MHz_under_load"] = lv
         cap = rd("power1_cap")
         if cap:
             out["power_cap_W"] = round(cap / 1e6)

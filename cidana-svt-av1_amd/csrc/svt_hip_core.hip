@@ -167,21 +167,23 @@ __global__ __launch_bounds__(256) void membw_copy_kernel(v4i_probe* __restrict__
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
 }
-// a workgroup reads 4 KiB and writes six 4-KiB runs (the fused 32x32 kernel: 2 KiB in, 12 KiB out per block)
-__global__ __launch_bounds__(256) void membw_mix_kernel(v4i_probe* __restrict__ dst, const v4i_probe* __restrict__ src, size_t n16) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n16) return;
-    v4i_probe v = __builtin_nontemporal_load(&src[i]);
-    const size_t o = (size_t)blockIdx.x * 6 * 256 + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < 6; k++) { v.x += k; __builtin_nontemporal_store(v, &dst[o + (size_t)k * 256]); }
+// 1 byte read : 6 bytes written (the fused 32x32 kernel: 2 KiB in, 12 KiB out per block) in the store shape that fills fastest - ONE
+// 16-byte store per lane, a grid as large as the job; every sixth workgroup also loads the 4 KiB it then stores.  (The
+// first form - a lane loaded once and stored six times - measured 5.2 TB/s on boxes where the fused kernel itself moves 6.5: six
+// stores per lane is the slow shape, so that probe was no ceiling.)
+__global__ __launch_bounds__(256) void membw_mix_kernel(v4i_probe* __restrict__ dst, const v4i_probe* __restrict__ src, size_t n16_written) {
+    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n16_written) return;
+    v4i_probe v = {(int)w, 1, 2, 3};
+    if (blockIdx.x % 6 == 0) v = __builtin_nontemporal_load(&src[(size_t)(blockIdx.x / 6) * 256 + threadIdx.x]);
+    __builtin_nontemporal_store(v, &dst[w]);
 }
 extern "C" int svt_hip_membw_probe(int mode, void* dst, const void* src, size_t bytes, void* stream) {
     if (int rc = require_init()) return rc;
     if (!dst || (mode != 0 && !src) || mode < 0 || mode > 2 || (bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))
         return set_err(SVT_HIP_ERR_INVALID, "membw_probe: bad arguments");
     if (mode == 2 && (bytes & 4095)) return set_err(SVT_HIP_ERR_INVALID, "membw_probe: mode 2 takes a multiple of 4096 bytes");
-    const size_t n16 = bytes >> 4;
+    const size_t n16 = mode == 2 ? 6 * (bytes >> 4) : bytes >> 4;          // mode 2: `bytes` are read, six times as many written
     if (!n16) return SVT_HIP_OK;
     const size_t grid = (n16 + 255) / 256;
     if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "membw_probe: more than 2^31 workgroups");

@@ -26,7 +26,7 @@ def run(iters=10):
     for _ in range(iters): dsp.fwd_quant_sad(src, pred, 3, 0, qrow, iscan, outs=outs)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-variants = [(nt, mw, wg) for nt in (0, 1) for mw in (1,) for wg in (0,)]
+variants = [(nt, mw, wg) for nt in (0, 1) for mw in (1,) for wg in (0, 2, 3, 4, 6)]
 times = {v: [] for v in variants}
 for rnd in range(8):
     for v in variants:
