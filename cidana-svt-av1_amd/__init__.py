@@ -235,6 +235,24 @@ class SvtHipDsp:
     def device_name(self):
         return self.lib.svt_hip_device_name().decode()
 
+    def alloc_spread(self, specs, gap_bytes=32 << 30):
+        """torch tensors that lie far apart in device memory (what svt_hip_malloc_spread does for C callers, through torch's
+        allocator so that the tensors are ordinary tensors): a temporary spacer between consecutive allocations, freed again.
+        specs: [(shape, dtype), ...].  Arrays a kernel writes at the same time run 20 - 25 % faster this way."""
+        t = self.torch
+        t.cuda.empty_cache()                                  # the tensors below must be fresh allocations, not cached blocks
+        out, spacers = [], []
+        for k, (shape, dt) in enumerate(specs):
+            out.append(t.empty(shape, dtype=dt, device=self.device))
+            if k + 1 < len(specs):
+                try:
+                    spacers.append(t.empty(gap_bytes, dtype=t.uint8, device=self.device))
+                except RuntimeError:                          # no room for a spacer: the next tensor follows directly
+                    pass
+        del spacers
+        t.cuda.empty_cache()
+        return out
+
     def membw_probe(self, mode, dst, src=None, nbytes=None):
         """svt_hip_membw_probe: mode 0 fill / 1 copy / 2 the fused kernel's 1 : 6 read / write mix; enqueues one kernel"""
         if nbytes is None:

@@ -178,6 +178,27 @@ __global__ __launch_bounds__(256) void membw_mix_kernel(v4i_probe* __restrict__ 
     if (blockIdx.x % 6 == 0) v = __builtin_nontemporal_load(&src[(size_t)(blockIdx.x / 6) * 256 + threadIdx.x]);
     __builtin_nontemporal_store(v, &dst[w]);
 }
+extern "C" int svt_hip_malloc_spread(const size_t* bytes, int n, size_t gap_bytes, void** ptrs) {
+    if (int rc = require_init()) return rc;
+    if (!bytes || !ptrs || n < 0 || n > 64) return set_err(SVT_HIP_ERR_INVALID, "malloc_spread: bad arguments");
+    const size_t gap = gap_bytes ? gap_bytes : ((size_t)32 << 30);
+    void* spacer[64];
+    int nsp = 0, rc = SVT_HIP_OK;
+    for (int i = 0; i < n; i++) ptrs[i] = nullptr;
+    for (int i = 0; i < n && rc == SVT_HIP_OK; i++) {
+        if (bytes[i] && hipMalloc(&ptrs[i], bytes[i]) != hipSuccess) { ptrs[i] = nullptr; rc = set_err(SVT_HIP_ERR_RUNTIME, "hipMalloc of %zu bytes failed", bytes[i]); break; }
+        if (i + 1 < n) {
+            void* sp = nullptr;
+            if (hipMalloc(&sp, gap) == hipSuccess) spacer[nsp++] = sp;
+            else (void)hipGetLastError();                  // no room for a spacer: the next buffer follows directly
+        }
+    }
+    for (int i = 0; i < nsp; i++) (void)hipFree(spacer[i]);
+    if (rc != SVT_HIP_OK)
+        for (int i = 0; i < n; i++) if (ptrs[i]) { (void)hipFree(ptrs[i]); ptrs[i] = nullptr; }
+    return rc;
+}
+
 extern "C" int svt_hip_membw_probe(int mode, void* dst, const void* src, size_t bytes, void* stream) {
     if (int rc = require_init()) return rc;
     if (!dst || (mode != 0 && !src) || mode < 0 || mode > 2 || (bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))
