@@ -335,18 +335,19 @@ class SvtHipDsp:
                     "svt_hip_fwd_quant_sad_batch")
         return outs
 
-    def encode_recon(self, src, pred, tx_size, tx_type, qrow, iscan, keep_coeff=True, want_sad=True):
+    def encode_recon(self, src, pred, tx_size, tx_type, qrow, iscan, keep_coeff=True, want_sad=True, outs=None):
         """Encode-pass chain (Av1EncodeLoop): src, pred uint8 [n, H, W] ->
-        dict(coeff, qcoeff, dqcoeff, eob, sad, recon); coeff/dqcoeff are None when keep_coeff is False."""
+        dict(coeff, qcoeff, dqcoeff, eob, sad, recon); coeff/dqcoeff are None when keep_coeff is False.
+        outs = (qcoeff, eob, recon): caller-placed outputs (see alloc_spread)."""
         t = self.torch
         n = src.shape[0]
         nc = min(TX_W[tx_size], 32) * min(TX_H[tx_size], 32)
         mk = lambda: t.empty((n, nc), dtype=t.int32, device=src.device)
         co, dq = (mk(), mk()) if keep_coeff else (None, None)
-        q = mk()
-        eob = t.zeros(n, dtype=t.int16, device=src.device)
+        q = outs[0] if outs else mk()
+        eob = outs[1] if outs else t.zeros(n, dtype=t.int16, device=src.device)
         sad = t.zeros(n, dtype=t.int32, device=src.device) if want_sad else None
-        recon = t.empty_like(pred)
+        recon = outs[2] if outs else t.empty_like(pred)
         tabs = [_np16(qrow[k]) for k in ("zbin", "round", "quant", "quant_shift", "dequant")]
         self._check(self.lib.svt_hip_encode_recon_batch(self._p(src), self._p(pred), n, tx_size, tx_type,
                                                          tabs[0].ctypes.data, tabs[1].ctypes.data, tabs[2].ctypes.data,
