@@ -96,14 +96,14 @@ void svt_hip_free(void *dptr);
 int svt_hip_memcpy_h2d(void *dptr, const void *hptr, size_t bytes, void *stream);
 int svt_hip_memcpy_d2h(void *hptr, const void *dptr, size_t bytes, void *stream);
 int svt_hip_stream_sync(void *stream);
-/* Allocates n device buffers that lie FAR APART in the device's address space: a temporary spacer of `gap_bytes` (0 = the
- * default, 32 GiB) is allocated between consecutive buffers and freed again before the call returns.  Why: a kernel that writes
- * several large output arrays at once (the fused chain: coeff, qcoeff, dqcoeff, 4 GiB each at 2^20 blocks) runs 20 - 25 % slower
- * when those arrays sit inside one contiguous stretch of device memory than when at least one of them lies 32 GiB or more away
- * (measured on MI355X: 368 against 455 M blocks/s, whatever the distance below 32 GiB and whatever the skew between the arrays;
- * DESIGN.md 5, profiles/r03_placement_probe*.log).  Callers that keep the coefficient arrays of a picture set resident should
- * allocate them through this.  If a spacer cannot be allocated the buffers are simply allocated one after the other.  Each
- * pointer is freed with svt_hip_free. */
+/* Allocates n device buffers as SEPARATE allocations with a temporary spacer of `gap_bytes` (0 = the default, 32 GiB) between
+ * consecutive ones, freed again before the call returns.  Why: a kernel that writes several large arrays at once (the fused chain:
+ * coeff, qcoeff, dqcoeff, 4 GiB each at 2^20 blocks) runs 20 - 25 % slower when those arrays are slices of ONE allocation - one
+ * contiguous block of device memory - than when at least one of them lies in another block (MI355X: 350 - 375 against 420 - 460 M
+ * blocks/s; no skew or offset inside the block changes it; DESIGN.md 5, profiles/r03_placement_probe*.log).  Separate allocations
+ * are in the fast band either way (420 - 455 measured for three plain svt_hip_malloc calls and for this call alike); with torch's
+ * allocator 32 GiB spacers were the reliable recipe.  If a spacer cannot be allocated the buffers simply follow each other.
+ * Each pointer is freed with svt_hip_free. */
 int svt_hip_malloc_spread(const size_t *bytes, int n, size_t gap_bytes, void **ptrs);
 /* Box calibration for the roofline report (bench.py): streams `bytes` through HBM in the access shape the kernels of this
  * library use (one 16-byte access per lane, a grid as large as the job, non-temporal stores) so that a measured kernel rate

@@ -402,3 +402,27 @@ def test_frame_ex_argument_errors_enqueue_nothing(dsp, pkg):
     fp.run_ex(qrow)                                                  # alpha 0 everywhere: the prediction does not change
     torch.cuda.synchronize()
     assert torch.equal(fp.groups[1]["pred"], to_dev(pred, 8)["U"]) and not torch.equal(before[0], fp.groups[0]["recon"])
+
+
+def test_malloc_spread_allocates_usable_buffers_far_apart(dsp, pkg):
+    """svt_hip_malloc_spread / SvtHipDsp.alloc_spread (arrays a kernel writes at the same time should lie 32 GiB apart):
+    the buffers are distinct and usable; bad arguments are refused"""
+    L = dsp.lib
+    L.svt_hip_malloc_spread.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    nbytes = (ctypes.c_size_t * 3)(1 << 26, 1 << 26, 1 << 20)
+    ptrs = (ctypes.c_void_p * 3)()
+    assert L.svt_hip_malloc_spread(nbytes, 3, 0, ptrs) == 0
+    p = [int(v) for v in ptrs]
+    assert all(p) and len(set(p)) == 3          # (virtual addresses say nothing about the distance that matters: small buffers reuse holes)
+    host = np.arange(1 << 18, dtype=np.int32)
+    back = np.zeros_like(host)
+    for q in p:                       # each buffer takes and returns data
+        assert L.svt_hip_memcpy_h2d(ctypes.c_void_p(q), host.ctypes.data, host.nbytes, None) == 0
+        assert L.svt_hip_memcpy_d2h(back.ctypes.data, ctypes.c_void_p(q), host.nbytes, None) == 0
+        assert L.svt_hip_stream_sync(None) == 0 and np.array_equal(host, back)
+        L.svt_hip_free(ctypes.c_void_p(q))
+    assert L.svt_hip_malloc_spread(nbytes, 65, 0, ptrs) != 0 and L.svt_hip_malloc_spread(None, 3, 0, ptrs) != 0
+    ts = dsp.alloc_spread([((1 << 20,), torch.int32), ((1 << 20,), torch.int32)], gap_bytes=1 << 30)
+    assert len(ts) == 2 and ts[0].data_ptr() != ts[1].data_ptr() and ts[0].is_cuda
+    ts[0].fill_(3); ts[1].fill_(5)
+    assert int(ts[0].sum()) == 3 << 20 and int(ts[1].sum()) == 5 << 20
