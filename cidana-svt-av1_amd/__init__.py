@@ -56,6 +56,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.svt_hip_malloc.restype = c_void_p
     L.svt_hip_malloc.argtypes = [c_size_t]
     L.svt_hip_free.argtypes = [c_void_p]
+    L.svt_hip_memcpy_h2d.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
+    L.svt_hip_memcpy_d2h.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
+    L.svt_hip_stream_sync.argtypes = [c_void_p]
+    L.svt_hip_malloc_spread.argtypes = [c_void_p, c_int, c_size_t, c_void_p]
     L.svt_hip_me_setup_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_uint32] + [c_void_p] * 7 + [c_size_t, c_void_p]
     L.svt_hip_me_fullpel_search_areas_batch.argtypes = [c_void_p, c_uint32, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                                         c_void_p, c_void_p, c_uint32, c_size_t, c_void_p]
