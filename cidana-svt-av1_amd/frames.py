@@ -28,7 +28,8 @@ class FramePass:
     """Device-side state of every group of one or more passes over one picture: origin tables, scan tables, output
     buffers, and the ctypes group array for svt_hip_encode_recon_frame.  Keeps every tensor alive."""
 
-    def __init__(self, dsp, pkg, planes_src, planes_pred, luma_sizes=LUMA_SIZES, is_16bit=False, keep_coeff=False, tx_types=None, rect_tx_sizes=()):
+    def __init__(self, dsp, pkg, planes_src, planes_pred, luma_sizes=LUMA_SIZES, is_16bit=False, keep_coeff=False, tx_types=None, rect_tx_sizes=(),
+                 spread_outputs=False):
         """tx_types: {block side: transform type} (default DCT_DCT everywhere); rect_tx_sizes: rectangular TxSize ids (5 .. 18) that
         tile the luma plane too (DCT_DCT), e.g. pkg.TX_SIZE_NAMES.index("TX_16X8")"""
         import torch
@@ -77,6 +78,27 @@ class FramePass:
                 g["coeff"] = torch.empty((n, nc), dtype=torch.int32, device=dev)
                 g["dqcoeff"] = torch.empty((n, nc), dtype=torch.int32, device=dev)
             self.groups.append(g)
+        # Placement: the two arrays a group's kernel writes at the same time - qcoeff and recon - are kept apart in device
+        # memory: every group's qcoeff first, a temporary 32 GiB spacer, then every group's reconstruction (was: interleaved, group by group)
+        if spread_outputs and self.groups and dev.type == "cuda":
+            recon_src = [(g["recon"], g) for g in self.groups]
+            for g in self.groups:
+                g["recon"] = None
+            del g
+            qshapes = [tuple(g["qcoeff"].shape) for g in self.groups]
+            for g in self.groups:
+                g["qcoeff"] = None
+            torch.cuda.empty_cache()
+            for g, shp in zip(self.groups, qshapes):
+                g["qcoeff"] = torch.empty(shp, dtype=torch.int32, device=dev)
+            try:
+                spacer = torch.empty(32 << 30, dtype=torch.uint8, device=dev)
+            except RuntimeError:
+                spacer = None
+            for old_recon, g in recon_src:
+                g["recon"] = old_recon.clone()
+            del recon_src, old_recon, spacer
+            torch.cuda.empty_cache()
         self.groups.sort(key=lambda g: g["name"] != "Y")      # luma groups first (stable): svt_hip_encode_recon_frame_ex's two phases
         self.n_luma = sum(g["name"] == "Y" for g in self.groups)
         self.array = dsp.make_frame_groups(self.groups)

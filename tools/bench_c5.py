@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--stack", type=int, default=1, help="pictures of a GOP handed to the device in ONE call (<= 65535 / height)")
     ap.add_argument("--single-launch", type=int, default=-1, help="1 / 0: force svt_hip_tune(frame_single_launch); -1: library default")
     ap.add_argument("--rehearse", action="store_true")
+    ap.add_argument("--interleaved-outputs", dest="spread_outputs", action="store_false",
+                    help="allocate every group's qcoeff and recon arrays one after the other (rounds 1 - 3); default: all qcoeff arrays, a temporary "
+                         "32 GiB spacer, all recon arrays - the placement rule of DESIGN 3, + 4.5 % on this config")
     ap.add_argument("--json-out", default=None)
     args = ap.parse_args()
 
@@ -88,11 +91,11 @@ def main():
         for i in range(0, len(pics), k):
             grp = pics[i:i + k]
             if len(grp) == 1:
-                passes.append(frames.FramePass(dsp, pkg, grp[0][0], grp[0][1], luma_sizes=sizes, is_16bit=True))
+                passes.append(frames.FramePass(dsp, pkg, grp[0][0], grp[0][1], luma_sizes=sizes, is_16bit=True, spread_outputs=args.spread_outputs))
             else:                                   # the pictures of this path are independent: one call for the stack
                 src = {n: torch.stack([q[0][n] for q in grp]) for n in ("Y", "U", "V")}
                 pred = {n: torch.stack([q[1][n] for q in grp]) for n in ("Y", "U", "V")}
-                passes.append(frames.FramePass(dsp, pkg, src, pred, luma_sizes=sizes, is_16bit=True))
+                passes.append(frames.FramePass(dsp, pkg, src, pred, luma_sizes=sizes, is_16bit=True, spread_outputs=args.spread_outputs))
                 passes[-1].nframes = len(grp)
         return passes
 
