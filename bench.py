@@ -482,6 +482,22 @@ def main():
             roofline["frac_of_box_fill"] = achieved / roofline["box_fill_GBps"]
             if "box_mix_1r6w_GBps" in roofline:
                 roofline["frac_of_box_mix"] = achieved / roofline["box_mix_1r6w_GBps"]
+            # the chain's own traffic and nothing else, on the SAME arrays: what this memory system gives the three-stream pattern here
+            def chain():
+                dsp.membw_probe_chain(src, pred, outs, n)
+            for _ in range(2):
+                chain()
+            torch.cuda.synchronize()
+            p0 = torch.cuda.Event(enable_timing=True); p1 = torch.cuda.Event(enable_timing=True)
+            p0.record()
+            for _ in range(5):
+                chain()
+            p1.record()
+            torch.cuda.synchronize()
+            pms = p0.elapsed_time(p1) / 5
+            roofline["box_chain_traffic_only_ms"] = pms
+            roofline["box_chain_traffic_only_GBps"] = 14336 * n / (pms * 1e-3) / 1e9
+            roofline["kernel_over_traffic_only_time"] = kernel_ms / pms
             roofline.update(clock_probe(torch, step))      # (replays the timed kernel: the outputs are the step's again)
             if placement == "spread":
                 # the same kernel with the three output arrays inside ONE 12 GiB allocation (the placement of rounds 1 - 3)

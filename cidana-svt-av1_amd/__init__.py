@@ -265,6 +265,12 @@ class SvtHipDsp:
         self._check(self.lib.svt_hip_membw_probe(mode, self._p(dst), self._p(src) if src is not None else None, nbytes,
                                                  self._stream()), "svt_hip_membw_probe")
 
+    def membw_probe_chain(self, in0, in1, outs, nblocks):
+        """svt_hip_membw_probe_chain: the fused 32x32 chain's traffic alone on the caller's arrays (2 x 1 KiB in, 3 x 4 KiB out per block)"""
+        self.lib.svt_hip_membw_probe_chain.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+        self._check(self.lib.svt_hip_membw_probe_chain(self._p(in0), self._p(in1), self._p(outs[0]), self._p(outs[1]), self._p(outs[2]), nblocks,
+                                                       self._stream()), "svt_hip_membw_probe_chain")
+
     # -- K1 ---------------------------------------------------------------------
     def fwd_txfm2d(self, residual, tx_size, tx_type, bd=8, out=None):
         """residual: int16 [n, H, W] contiguous (dense blocks). -> int32 [n, H*W]"""

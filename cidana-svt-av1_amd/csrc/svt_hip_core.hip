@@ -178,6 +178,36 @@ __global__ __launch_bounds__(256) void membw_mix_kernel(v4i_probe* __restrict__ 
     if (blockIdx.x % 6 == 0) v = __builtin_nontemporal_load(&src[(size_t)(blockIdx.x / 6) * 256 + threadIdx.x]);
     __builtin_nontemporal_store(v, &dst[w]);
 }
+// The fused 32x32 chain's traffic and nothing else: per block two 1 KiB reads and three 4 KiB runs written as 1 KiB stores of
+// one wave, into the caller's three arrays - what THIS memory system gives that stream pattern in THIS placement.
+__global__ __launch_bounds__(256) void membw_chain_kernel(const v4i_probe* __restrict__ in0, const v4i_probe* __restrict__ in1, v4i_probe* __restrict__ o0,
+                                                          v4i_probe* __restrict__ o1, v4i_probe* __restrict__ o2, size_t nblocks) {
+    const size_t b = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per block
+    if (b >= nblocks) return;
+    const int lane = threadIdx.x & 63;
+    v4i_probe a = __builtin_nontemporal_load(&in0[b * 64 + lane]);
+    const v4i_probe c = __builtin_nontemporal_load(&in1[b * 64 + lane]);
+    a += c;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        a.x += q;
+        __builtin_nontemporal_store(a, &o0[b * 256 + q * 64 + lane]);
+        __builtin_nontemporal_store(a, &o1[b * 256 + q * 64 + lane]);
+        __builtin_nontemporal_store(a, &o2[b * 256 + q * 64 + lane]);
+    }
+}
+extern "C" int svt_hip_membw_probe_chain(const void* d_in0, const void* d_in1, void* d_out0, void* d_out1, void* d_out2, size_t nblocks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (!d_in0 || !d_in1 || !d_out0 || !d_out1 || !d_out2 || (((uintptr_t)d_in0 | (uintptr_t)d_in1 | (uintptr_t)d_out0 | (uintptr_t)d_out1 | (uintptr_t)d_out2) & 15))
+        return set_err(SVT_HIP_ERR_INVALID, "membw_probe_chain: bad arguments");
+    if (!nblocks) return SVT_HIP_OK;
+    const size_t grid = (nblocks + 3) / 4;
+    if (grid > 0x7fffffffu) return set_err(SVT_HIP_ERR_INVALID, "membw_probe_chain: too many blocks");
+    membw_chain_kernel<<<dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream>>>((const v4i_probe*)d_in0, (const v4i_probe*)d_in1, (v4i_probe*)d_out0,
+                                                                                   (v4i_probe*)d_out1, (v4i_probe*)d_out2, nblocks);
+    return launch_status("membw_probe_chain");
+}
+
 extern "C" int svt_hip_malloc_spread(const size_t* bytes, int n, size_t gap_bytes, void** ptrs) {
     if (int rc = require_init()) return rc;
     if (!bytes || !ptrs || n < 0 || n > 64) return set_err(SVT_HIP_ERR_INVALID, "malloc_spread: bad arguments");

@@ -111,6 +111,11 @@ int svt_hip_malloc_spread(const size_t *bytes, int n, size_t gap_bytes, void **p
  * 2 = the headline kernel's 1 : 6 read / write mix (reads `bytes` from src, writes 6 x `bytes` to dst).  `bytes` is a
  * multiple of 16, pointers 16-byte aligned.  Enqueues one kernel on `stream`. */
 int svt_hip_membw_probe(int mode, void *dst, const void *src, size_t bytes, void *stream);
+/* ... and the fused 32x32 chain's own traffic, nothing else: per block 1 KiB read from each of d_in0 / d_in1 (nblocks x 1 KiB each) and
+ * 4 KiB written to each of d_out0 / d_out1 / d_out2 (nblocks x 4 KiB each) as 1 KiB stores of one wave - the time of this launch on
+ * the caller's own arrays is what the memory system gives that stream pattern in that placement. */
+int svt_hip_membw_probe_chain(const void *d_in0, const void *d_in1, void *d_out0, void *d_out1, void *d_out2, size_t nblocks,
+                              void *stream);
 
 /* ---- host-side tables for callers outside the encoder (csrc/host_tables.cpp; no device involved) ------------------
  * y-plane quantiser rows of av1_build_quantizer(bit_depth, 0, 0, 0, 0, 0) (EbModeDecisionConfigurationProcess.c:429-520):
