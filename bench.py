@@ -396,15 +396,6 @@ def main():
     def step():
         dsp.fwd_quant_sad(src, pred, pkg.TX_32X32, pkg.DCT_DCT, qrow, iscan, outs=outs)
 
-    pre = os.environ.get("SVT_BENCH_PRE", "")             # experiment: "sleep:<s>" or "busy:<s>" before the warm-up steps
-    if pre.startswith("sleep:"):
-        time.sleep(float(pre[6:]))
-    elif pre.startswith("busy:"):
-        tb = time.perf_counter()
-        while time.perf_counter() - tb < float(pre[5:]):
-            for _ in range(8):
-                step()
-            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
 
