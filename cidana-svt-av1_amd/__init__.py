@@ -410,10 +410,11 @@ class SvtHipDsp:
                                                 self._stream()), "svt_hip_sse_batch")
         return out
 
-    def residual(self, src, pred):
+    def residual(self, src, pred, out=None):
         t = self.torch
         n, h, w = src.shape
-        out = t.empty((n, h, w), dtype=t.int16, device=src.device)
+        if out is None:
+            out = t.empty((n, h, w), dtype=t.int16, device=src.device)
         self._check(self.lib.svt_hip_residual_batch(self._p(src), w, w * h, self._p(pred), w, w * h, self._p(out), w,
                                                      w * h, w, h, n, self._stream()), "svt_hip_residual_batch")
         return out
