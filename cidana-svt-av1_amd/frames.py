@@ -89,15 +89,28 @@ class FramePass:
             for g in self.groups:
                 g["qcoeff"] = None
             torch.cuda.empty_cache()
+            spacers = []
+
+            def gap():
+                try:
+                    spacers.append(torch.empty(32 << 30, dtype=torch.uint8, device=dev))
+                except RuntimeError:
+                    pass
+            if spread_outputs == "all":          # the source and prediction planes too: [src] gap [pred] gap [qcoeff] gap [recon]
+                for key in ("src", "pred"):
+                    fresh = {}
+                    for g in self.groups:
+                        t0 = g[key]
+                        if id(t0) not in fresh:
+                            fresh[id(t0)] = t0.clone()
+                        g[key] = fresh[id(t0)]
+                    gap()
             for g, shp in zip(self.groups, qshapes):
                 g["qcoeff"] = torch.empty(shp, dtype=torch.int32, device=dev)
-            try:
-                spacer = torch.empty(32 << 30, dtype=torch.uint8, device=dev)
-            except RuntimeError:
-                spacer = None
+            gap()
             for old_recon, g in recon_src:
                 g["recon"] = old_recon.clone()
-            del recon_src, old_recon, spacer
+            del recon_src, old_recon, spacers
             torch.cuda.empty_cache()
         self.groups.sort(key=lambda g: g["name"] != "Y")      # luma groups first (stable): svt_hip_encode_recon_frame_ex's two phases
         self.n_luma = sum(g["name"] == "Y" for g in self.groups)

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--stack", type=int, default=1, help="pictures of a GOP handed to the device in ONE call (<= 65535 / height)")
     ap.add_argument("--single-launch", type=int, default=-1, help="1 / 0: force svt_hip_tune(frame_single_launch); -1: library default")
     ap.add_argument("--rehearse", action="store_true")
+    ap.add_argument("--spread-all", dest="spread_outputs", action="store_const", const="all", help="source and prediction planes apart as well")
     ap.add_argument("--interleaved-outputs", dest="spread_outputs", action="store_false",
                     help="allocate every group's qcoeff and recon arrays one after the other (rounds 1 - 3); default: all qcoeff arrays, a temporary "
                          "32 GiB spacer, all recon arrays - the placement rule of DESIGN 3, + 4.5 % on this config")
